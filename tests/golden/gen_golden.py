@@ -1,0 +1,337 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ -- runs ONLY in the build container.
+
+Sources of truth (nothing here travels to the GPU box except the .npz outputs):
+  * scikit-learn 1.7.2 (``uv.lock:2411`` pin of the reference; it is the arithmetic
+    ``bask/bayesgpr.py:374`` reaches): GaussianProcessRegressor.log_marginal_likelihood /
+    kernels / predict.
+  * the reference's own modules imported from /root/reference with the tier-1 shim of
+    SURVEY.md Appendix A (P2): bask.priors, bask.utils, bask.acquisition.  ``bask/__init__``
+    is never executed (emcee / skopt / arviz are absent from this image).
+
+Usage:  python tests/golden/gen_golden.py      (writes tests/golden/*.npz)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+from scipy.linalg import cho_solve, cholesky, solve_triangular
+from sklearn.gaussian_process import GaussianProcessRegressor
+from sklearn.gaussian_process import kernels as sk
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+# ---------------------------------------------------------------------------------------
+def import_reference_tier1():
+    """SURVEY.md Appendix A, P2."""
+    for name in ("skopt", "skopt.learning", "skopt.learning.gaussian_process"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["skopt.learning.gaussian_process.kernels"] = sk
+    pkg = types.ModuleType("bask")
+    pkg.__path__ = [os.path.join(REF, "bask")]
+    sys.modules["bask"] = pkg
+    mods = {}
+    for m in ("priors", "init", "utils", "acquisition"):
+        mods[m] = importlib.import_module("bask." + m)
+    return mods
+
+
+def synth(n, d, seed):
+    """SURVEY.md 8(d) synthetic inputs."""
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+    y = (y - y.mean()) / y.std()
+    return X, y
+
+
+def make_kernel(stationary, form, d, ard=True):
+    ls = [0.3] * d if ard else 0.3
+    if stationary == "rbf":
+        S = sk.RBF(length_scale=ls)
+    else:
+        nu = {"matern12": 0.5, "matern32": 1.5, "matern52": 2.5}[stationary]
+        S = sk.Matern(length_scale=ls, nu=nu)
+    C = sk.ConstantKernel(1.0)
+    k = C * S if form == "product" else C + S
+    return k + sk.WhiteKernel()
+
+
+def thetas(d, B, seed, spread=0.3):
+    rng = np.random.RandomState(seed)
+    base = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+    return base + spread * rng.randn(B, d + 2)
+
+
+def sk_gpr(kernel, X, y, alpha):
+    g = GaussianProcessRegressor(kernel=kernel, optimizer=None, alpha=alpha)
+    g.fit(X, y)
+    return g
+
+
+# ---------------------------------------------------------------------------------------
+def gen_lml_small(out):
+    """Every kernel form at small n: K, LML, alpha, diag(L)."""
+    rec = {}
+    case = 0
+    for n, d in ((24, 2), (40, 3)):
+        X, y = synth(n, d, seed=100 + n)
+        avec = 1e-10 + 0.05 * np.random.RandomState(7).rand(n)
+        for stationary in ("rbf", "matern12", "matern32", "matern52"):
+            for form in ("product", "sum"):
+                for alpha in (1e-10, avec):
+                    k = make_kernel(stationary, form, d)
+                    g = sk_gpr(k, X, y, alpha)
+                    TH = thetas(d, 6, seed=case)
+                    Ks, lmls, alphas, Ldiag = [], [], [], []
+                    for th in TH:
+                        kk = g.kernel_.clone_with_theta(th)
+                        K = kk(X)
+                        Kj = K.copy()
+                        Kj[np.diag_indices_from(Kj)] += alpha
+                        L = cholesky(Kj, lower=True)
+                        Ks.append(Kj)
+                        Ldiag.append(np.diag(L))
+                        alphas.append(cho_solve((L, True), y))
+                        lmls.append(g.log_marginal_likelihood(th))
+                    pre = f"c{case}_"
+                    rec[pre + "X"] = X
+                    rec[pre + "y"] = y
+                    rec[pre + "alpha_diag"] = np.broadcast_to(alpha, (n,)).copy()
+                    rec[pre + "theta"] = TH
+                    rec[pre + "K"] = np.array(Ks)
+                    rec[pre + "lml"] = np.array(lmls)
+                    rec[pre + "alpha_vec"] = np.array(alphas)
+                    rec[pre + "Ldiag"] = np.array(Ldiag)
+                    rec[pre + "meta"] = np.array([stationary, form])
+                    case += 1
+    rec["n_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(out, "lml_small.npz"), **rec)
+    print("lml_small:", case, "cases")
+
+
+def gen_lml_sizes(out):
+    """Config A at full size with data; mid-size ragged n; B/C/D as seed + scalars."""
+    rec = {}
+    # A: n=128, d=2
+    X, y = synth(128, 2, seed=0)
+    g = sk_gpr(make_kernel("matern52", "product", 2), X, y, 1e-10)
+    TH = thetas(2, 16, seed=11)
+    # edge cases: tiny / huge length scale, tiny noise
+    TH[12, 1:3] = np.log(0.01)
+    TH[13, 1:3] = np.log(10.0)
+    TH[14, 3] = np.log(1e-10)
+    TH[15, 0] = np.log(50.0)
+    rec["A_X"], rec["A_y"], rec["A_theta"] = X, y, TH
+    rec["A_lml"] = np.array([g.log_marginal_likelihood(t) for t in TH])
+    # ragged mid size with vector alpha: n=300,d=5 and n=777,d=3
+    for tag, n, d, seed in (("M1", 300, 5, 1), ("M2", 777, 3, 2), ("M3", 129, 4, 3), ("M4", 257, 1, 4)):
+        X, y = synth(n, d, seed)
+        avec = 1e-10 + 0.02 * np.random.RandomState(seed).rand(n)
+        g = sk_gpr(make_kernel("matern52", "product", d), X, y, avec)
+        TH = thetas(d, 5, seed=20 + seed)
+        rec[tag + "_nd_seed"] = np.array([n, d, seed])
+        rec[tag + "_alpha_diag"] = avec
+        rec[tag + "_theta"] = TH
+        rec[tag + "_lml"] = np.array([g.log_marginal_likelihood(t) for t in TH])
+    # B / C / D: seeds + scalars only (X regenerated by synth())
+    for tag, n, d, nb in (("B", 1024, 8, 4), ("C", 2048, 16, 3), ("D", 4096, 32, 2)):
+        X, y = synth(n, d, seed=0)
+        g = sk_gpr(make_kernel("matern52", "product", d), X, y, 1e-10)
+        TH = thetas(d, nb, seed=30, spread=0.2)
+        rec[tag + "_nd_seed"] = np.array([n, d, 0])
+        rec[tag + "_theta"] = TH
+        rec[tag + "_lml"] = np.array([g.log_marginal_likelihood(t) for t in TH])
+        print(tag, rec[tag + "_lml"])
+    # exactly singular: duplicated rows, alpha = 0, no noise -> -inf (sklearn:_gpr.py:588-589)
+    X, y = synth(16, 2, seed=5)
+    X[1] = X[0]
+    k = sk.ConstantKernel(1.0) * sk.Matern([0.3, 0.3], nu=2.5) + sk.WhiteKernel(1.0)
+    g = sk_gpr(k, X, y, 0.0)
+    th = np.array([0.0, np.log(0.3), np.log(0.3), -np.inf])
+    with np.errstate(all="ignore"):
+        val = g.log_marginal_likelihood(np.array([0.0, np.log(0.3), np.log(0.3), -745.0]))
+    rec["S_X"], rec["S_y"], rec["S_theta"], rec["S_lml"] = X, y, th[None], np.array([val])
+    assert val == -np.inf, val
+    np.savez_compressed(os.path.join(out, "lml_sizes.npz"), **rec)
+
+
+def gen_grad(out):
+    rec = {}
+    case = 0
+    for stationary in ("rbf", "matern32", "matern52"):
+        for form in ("product", "sum"):
+            n, d = 50, 3
+            X, y = synth(n, d, seed=40 + case)
+            g = sk_gpr(make_kernel(stationary, form, d), X, y, 1e-10)
+            TH = thetas(d, 3, seed=50 + case)
+            vals, grads = [], []
+            for t in TH:
+                v, gr = g.log_marginal_likelihood(t, eval_gradient=True)
+                vals.append(v)
+                grads.append(gr)
+            pre = f"c{case}_"
+            rec[pre + "X"], rec[pre + "y"], rec[pre + "theta"] = X, y, TH
+            rec[pre + "lml"], rec[pre + "grad"] = np.array(vals), np.array(grads)
+            rec[pre + "meta"] = np.array([stationary, form])
+            case += 1
+    rec["n_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(out, "lml_grad.npz"), **rec)
+
+
+def skopt_predict(g, K_inv, X, return_cov=False):
+    """skopt 0.10.2 GaussianProcessRegressor.predict restated on a fitted
+    sklearn GPR: mean = K_trans alpha_; var = diag - einsum(K_trans, K_trans, K_inv_)."""
+    K_trans = g.kernel_(X, g.X_train_)
+    mean = K_trans.dot(g.alpha_)
+    var = g.kernel_.diag(X).copy()
+    var -= np.einsum("ki,kj,ij->k", K_trans, K_trans, K_inv)
+    var[var < 0] = 0.0
+    out = [mean, np.sqrt(var)]
+    if return_cov:
+        v = cho_solve((g.L_, True), K_trans.T)
+        out.append(g.kernel_(X) - K_trans.dot(v))
+    return out
+
+
+def gen_predict(out):
+    rec = {}
+    case = 0
+    for stationary, form, n, d, m in (("matern52", "product", 60, 3, 40), ("rbf", "product", 33, 1, 17),
+                                      ("matern32", "sum", 45, 2, 25), ("matern52", "product", 200, 4, 64)):
+        X, y = synth(n, d, seed=60 + case)
+        Xq = np.random.RandomState(70 + case).uniform(size=(m, d))
+        avec = 1e-10 + 0.03 * np.random.RandomState(case).rand(n)
+        for alpha in (1e-10, avec):
+            th = thetas(d, 1, seed=80 + case, spread=0.2)[0]
+            k = make_kernel(stationary, form, d).clone_with_theta(th)
+            g = sk_gpr(k, X, y, alpha)
+            L_inv = solve_triangular(g.L_.T, np.eye(n))
+            K_inv = L_inv.dot(L_inv.T)
+            mean, std, cov = skopt_predict(g, K_inv, Xq, return_cov=True)
+            # cross-check against sklearn's own predict
+            m2, s2 = g.predict(Xq, return_std=True)
+            assert np.allclose(mean, m2, rtol=1e-9, atol=1e-12)
+            assert np.allclose(std, s2, rtol=1e-5, atol=1e-7), np.abs(std - s2).max()
+            # noise_set_to_zero: swap the white kernel for WhiteKernel(0) WITHOUT refitting
+            g.kernel_.set_params(k2=sk.WhiteKernel(noise_level=0.0))
+            mean0, std0, cov0 = skopt_predict(g, K_inv, Xq, return_cov=True)
+            pre = f"c{case}_"
+            rec[pre + "X"], rec[pre + "y"], rec[pre + "Xq"] = X, y, Xq
+            rec[pre + "alpha_diag"] = np.broadcast_to(alpha, (n,)).copy()
+            rec[pre + "theta"] = th
+            rec[pre + "mean"], rec[pre + "std"], rec[pre + "cov"] = mean, std, cov
+            rec[pre + "mean0"], rec[pre + "std0"], rec[pre + "cov0"] = mean0, std0, cov0
+            rec[pre + "L"], rec[pre + "K_inv"], rec[pre + "alpha_vec"] = g.L_, K_inv, g.alpha_
+            rec[pre + "meta"] = np.array([stationary, form])
+            case += 1
+    rec["n_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(out, "predict.npz"), **rec)
+    print("predict:", case, "cases")
+
+
+def gen_reference_tier1(out):
+    ref = import_reference_tier1()
+    rec = {}
+    # --- priors: known answers of tests/test_utils.py:20-40 + a grid
+    kernel = sk.ConstantKernel(1.0, (0.1, 2.0)) * sk.Matern([0.3, 0.3], (0.2, 0.5), nu=2.5) + sk.WhiteKernel()
+    pri = ref["utils"].guess_priors(kernel)
+    assert len(pri) == 4
+    grid = np.linspace(-8.0, 3.0, 111)
+    rec["prior_grid"] = grid
+    rec["prior_variance"] = np.array([pri[0](t) for t in grid])
+    rec["prior_lengthscale"] = np.array([pri[1](t) for t in grid])
+    rec["prior_noise"] = np.array([pri[3](t) for t in grid])
+    rec["prior_known_x"] = np.array(-0.9)
+    rec["prior_known_roundflat"] = np.array(pri[1](-0.9))
+    rec["prior_known_halfnorm"] = np.array(pri[0](-0.9))
+    assert abs(pri[1](-0.9) - (-0.02116327824572739)) < 1e-12
+    assert abs(pri[0](-0.9) - (-2.112906921232193)) < 1e-12
+    rf = ref["priors"].make_roundflat()
+    rec["roundflat_x"] = np.linspace(0.02, 2.0, 100)
+    rec["roundflat_val"] = np.array([rf(t) for t in rec["roundflat_x"]])
+    rf2 = ref["priors"].make_roundflat(0.2, 0.9, 3.0, 4.0)
+    rec["roundflat2_val"] = np.array([rf2(t) for t in rec["roundflat_x"]])
+    # --- geometric median
+    rng = np.random.RandomState(3)
+    for i, (S, p) in enumerate(((200, 4), (1000, 10), (50, 2))):
+        C = rng.randn(S, p) * rng.rand(p) + rng.randn(p)
+        if i == 2:
+            C[:20] = C[0]  # repeated rows -> exercises the num_zeros branch
+        rec[f"gm{i}_chain"] = C
+        rec[f"gm{i}_median"] = ref["utils"].geometric_median(C)
+    # --- default kernel (bask/utils.py:127-151)
+    dk = ref["utils"].construct_default_kernel([0, 1, 2])
+    rec["default_kernel_theta"] = dk.theta
+    rec["default_kernel_bounds"] = dk.bounds
+    # --- closed-form acquisitions on fixed (mu, std)
+    acq = ref["acquisition"]
+    mu = rng.randn(64)
+    std = np.abs(rng.randn(64)) * 0.5
+    std[:3] = 0.0
+    rec["acq_mu"], rec["acq_std"] = mu, std
+    rec["acq_ei"] = acq.ExpectedImprovement()(mu, std)
+    rec["acq_ei_yopt"] = acq.ExpectedImprovement()(mu, std, y_opt=-0.3)
+    rec["acq_lcb"] = acq.LCB()(mu, std)
+    rec["acq_lcb3"] = acq.LCB()(mu, std, alpha=3.0)
+    rec["acq_mean"] = acq.Expectation()(mu, std)
+    rec["acq_ttei"] = acq.TopTwoEI()(mu, std)
+
+    # --- PVRS / VR with a duck-typed GP and injected Thompson samples
+    class DuckGP:
+        warp_inputs = False
+
+        def __init__(self, X, kernel_, alpha, thompson):
+            self.X_train_, self.kernel_, self.alpha, self._th = X, kernel_, alpha, thompson
+
+        def sample_y(self, X, sample_mean=True, n_samples=1, random_state=None):
+            return self._th
+
+    case = 0
+    for n, d, m, T, vec in ((30, 2, 50, 5, True), (64, 3, 40, 10, False), (130, 2, 33, 4, True)):
+        X, y = synth(n, d, seed=90 + case)
+        Xc = np.random.RandomState(95 + case).uniform(size=(m, d))
+        th = thetas(d, 1, seed=97 + case, spread=0.2)[0]
+        k = make_kernel("matern52", "product", d).clone_with_theta(th)
+        alpha = (1e-10 + 0.01 * np.random.RandomState(case).rand(n)) if vec else 1e-10
+        thompson = np.random.RandomState(99 + case).randn(m, T)
+        gp = DuckGP(X, k, alpha, thompson)
+        covs = acq.PVRS()(Xc, gp, n_thompson=T, random_state=0)
+        pre = f"pvrs{case}_"
+        rec[pre + "X"], rec[pre + "Xc"], rec[pre + "theta"] = X, Xc, th
+        rec[pre + "alpha_vec"] = alpha if vec else np.array([])
+        rec[pre + "thompson"] = thompson
+        rec[pre + "covs"] = covs
+        if case < 2:
+            rec[pre + "vr"] = acq.VarianceReduction()(Xc, gp)
+        case += 1
+    rec["pvrs_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(out, "reference_tier1.npz"), **rec)
+    print("tier1 ok")
+
+
+def gen_mvn(out):
+    """numpy legacy multivariate_normal (SVD path) used by sklearn sample_y
+    (sklearn:_gpr.py:522-526)."""
+    rec = {}
+    rng = np.random.RandomState(5)
+    A = rng.randn(12, 12)
+    cov = A @ A.T / 12 + 1e-8 * np.eye(12)
+    mean = rng.randn(12)
+    rec["mean"], rec["cov"] = mean, cov
+    rec["draws"] = np.random.RandomState(0).multivariate_normal(mean, cov, 7).T
+    np.savez_compressed(os.path.join(out, "mvn.npz"), **rec)
+
+
+if __name__ == "__main__":
+    gen_lml_small(HERE)
+    gen_lml_sizes(HERE)
+    gen_grad(HERE)
+    gen_predict(HERE)
+    gen_reference_tier1(HERE)
+    gen_mvn(HERE)
+    print("done")
