@@ -1,0 +1,242 @@
+"""ctypes binding of libbgp.so (the C-ABI declared in include/bgp.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C bayes-skopt_amd/csrc``.
+There is NO CPU fallback: if the shared object is missing, or no gfx950 device is visible when
+a context is created, the product path raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbgp.so")
+
+FORM = {"product": 0, "sum": 1}
+STATIONARY = {"rbf": 0, "matern12": 1, "matern32": 2, "matern52": 3}
+
+
+class BgpError(RuntimeError):
+    pass
+
+
+class KernelSpecStruct(C.Structure):
+    _fields_ = [("form", C.c_int), ("stationary", C.c_int), ("d", C.c_int)]
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/bgp.h declares
+SIGNATURES = {
+    "bgp_device_count": (C.c_int, []),
+    "bgp_last_error": (C.c_char_p, []),
+    "bgp_version": (C.c_char_p, []),
+    "bgp_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(KernelSpecStruct), C.c_int,
+                                 C.POINTER(_vp)]),
+    "bgp_ctx_update_data": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
+    "bgp_ctx_destroy": (None, [_vp]),
+    "bgp_lml_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _ip]),
+    "bgp_lml_grad_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip]),
+    "bgp_kernel_matrix": (C.c_int, [_vp, _dp, _dp]),
+    "bgp_posterior_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "bgp_predict_batch": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "bgp_pvrs": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
+    "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
+    "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
+    "bgp_mfma_f64_layout": (C.c_int, [C.c_int, _ip, _ip]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libbgp.so (once) and declare every prototype.  Raises BgpError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BgpError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C bayes-skopt_amd/csrc`). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise BgpError(f"{what} failed (code {rc}): {load().bgp_last_error().decode()}")
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp if a.dtype == np.float64 else _ip)
+
+
+def device_count():
+    return int(load().bgp_device_count())
+
+
+class Context:
+    """Owns one device context: training set resident in HBM + the batched-Cholesky workspace."""
+
+    def __init__(self, X, y, alpha_diag, form="product", stationary="matern52", max_batch=64, device=0):
+        lib = load()
+        X = _c(np.atleast_2d(X))
+        n, d = X.shape
+        y = _c(y).reshape(n)
+        alpha_diag = _c(np.broadcast_to(np.asarray(alpha_diag, dtype=np.float64), (n,)))
+        self.n, self.d, self.p = n, d, d + 2
+        self.form, self.stationary = form, stationary
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        spec = KernelSpecStruct(FORM[form], STATIONARY[stationary], d)
+        h = _vp()
+        if device_count() <= 0:
+            raise BgpError("no HIP device visible: the BayesGPR hot path needs an MI355X (no CPU fallback)")
+        _check(lib.bgp_ctx_create(self.device, n, d, _p(X), _p(y), _p(alpha_diag), C.byref(spec), self.max_batch,
+                                  C.byref(h)), "bgp_ctx_create")
+        self._h = h
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bgp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_data(self, X, y, alpha_diag):
+        X = _c(np.atleast_2d(X))
+        n, d = X.shape
+        if d != self.d:
+            raise ValueError("input dimension changed")
+        y = _c(y).reshape(n)
+        alpha_diag = _c(np.broadcast_to(np.asarray(alpha_diag, dtype=np.float64), (n,)))
+        _check(self._lib.bgp_ctx_update_data(self._h, n, _p(X), _p(y), _p(alpha_diag)), "bgp_ctx_update_data")
+        self.n = n
+
+    def _H(self, H):
+        H = _c(np.atleast_2d(H))
+        if H.shape[1] != self.p:
+            raise ValueError(f"canonical hyper-parameter vectors must have length d+2={self.p}, got {H.shape[1]}")
+        return H
+
+    def lml(self, H, return_status=False):
+        H = self._H(H)
+        B = H.shape[0]
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_lml_batch(self._h, B, _p(H), _p(out), _p(st)), "bgp_lml_batch")
+        return (out, st) if return_status else out
+
+    def lml_grad(self, H):
+        H = self._H(H)
+        B = H.shape[0]
+        out = np.empty(B)
+        grad = np.empty((B, self.p))
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_lml_grad_batch(self._h, B, _p(H), _p(out), _p(grad), _p(st)), "bgp_lml_grad_batch")
+        return out, grad, st
+
+    def kernel_matrix(self, h):
+        H = self._H(h)
+        K = np.empty((self.n, self.n))
+        _check(self._lib.bgp_kernel_matrix(self._h, _p(H), _p(K)), "bgp_kernel_matrix")
+        return K
+
+    def posterior(self, H, want_L=False, want_alpha=True, want_K_inv=False):
+        H = self._H(H)
+        B, n = H.shape[0], self.n
+        L = np.empty((B, n, n)) if want_L else None
+        a = np.empty((B, n)) if want_alpha else None
+        Ki = np.empty((B, n, n)) if want_K_inv else None
+        lml = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        nul = C.cast(None, _dp)
+        _check(self._lib.bgp_posterior_batch(self._h, B, _p(H), _p(L) if want_L else nul,
+                                             _p(a) if want_alpha else nul, _p(Ki) if want_K_inv else nul, _p(lml),
+                                             _p(st)), "bgp_posterior_batch")
+        return {"L": L, "alpha": a, "K_inv": Ki, "lml": lml, "status": st}
+
+    def predict(self, H_kernel, Xq, return_cov=False):
+        H = self._H(H_kernel)
+        B = H.shape[0]
+        Xq = _c(np.atleast_2d(Xq))
+        m = Xq.shape[0]
+        mean = np.empty((B, m))
+        var = np.empty((B, m))
+        cov = np.empty((B, m, m)) if return_cov else None
+        nul = C.cast(None, _dp)
+        _check(self._lib.bgp_predict_batch(self._h, B, _p(H), m, _p(Xq), _p(mean), _p(var),
+                                           _p(cov) if return_cov else nul), "bgp_predict_batch")
+        return (mean, var, cov) if return_cov else (mean, var)
+
+    def pvrs(self, h_kernel, Xcand, Xthompson):
+        H = self._H(h_kernel)
+        Xc = _c(np.atleast_2d(Xcand))
+        Xt = _c(np.atleast_2d(Xthompson))
+        covs = np.empty(Xc.shape[0])
+        _check(self._lib.bgp_pvrs(self._h, _p(H), Xc.shape[0], _p(Xc), Xt.shape[0], _p(Xt), _p(covs)), "bgp_pvrs")
+        return covs
+
+    def sample_y(self, b, h_kernel, Xq, z, jitter=0.0):
+        H = self._H(h_kernel)
+        Xq = _c(np.atleast_2d(Xq))
+        z = _c(np.atleast_2d(z))
+        m = Xq.shape[0]
+        if z.shape[1] != m:
+            raise ValueError("z must be (n_draws, m)")
+        out = np.empty_like(z)
+        _check(self._lib.bgp_sample_y(self._h, int(b), _p(H), m, _p(Xq), z.shape[0], _p(z), float(jitter), _p(out)),
+               "bgp_sample_y")
+        return out
+
+    def set_timing(self, enable):
+        _check(self._lib.bgp_set_timing(self._h, int(bool(enable))), "bgp_set_timing")
+
+    def last_timing(self):
+        ms = np.zeros(5)
+        cnt = np.zeros(4, dtype=np.int32)
+        _check(self._lib.bgp_last_timing(self._h, _p(ms), _p(cnt)), "bgp_last_timing")
+        names = ("kbuild", "potrf", "trsm", "syrk")
+        out = {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(names)}
+        out["device_total_ms"] = float(ms[4])
+        return out
+
+
+def bench_mfma_f64(device=0, iters=20000):
+    v = C.c_double(0.0)
+    _check(load().bgp_bench_mfma_f64(device, iters, C.byref(v)), "bgp_bench_mfma_f64")
+    return v.value
+
+
+def bench_hbm_copy(device=0, nbytes=1 << 30, iters=10):
+    v = C.c_double(0.0)
+    _check(load().bgp_bench_hbm_copy(device, nbytes, iters, C.byref(v)), "bgp_bench_hbm_copy")
+    return v.value
+
+
+def mfma_f64_layout(device=0):
+    rows = np.zeros(256, dtype=np.int32)
+    cols = np.zeros(256, dtype=np.int32)
+    _check(load().bgp_mfma_f64_layout(device, _p(rows), _p(cols)), "bgp_mfma_f64_layout")
+    return rows.reshape(64, 4), cols.reshape(64, 4)

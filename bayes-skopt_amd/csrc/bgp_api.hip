@@ -1,0 +1,267 @@
+// C-ABI entry points of libbgp.so (see include/bgp.h for the contract and the reference seams).
+#include "bgp_common.h"
+
+static thread_local std::string g_err;
+
+void bgp_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+extern "C" const char* bgp_last_error(void) { return g_err.c_str(); }
+extern "C" const char* bgp_version(void) { return "bgp 0.1 (gfx950, fp64 MFMA blocked Cholesky)"; }
+
+extern "C" int bgp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+static void free_dev(void* p) {
+  if (p) (void)hipFree(p);
+}
+
+static int alloc_data(bgp_ctx* c, int n) {
+  // training-set buffers sized for npad rows; grow-only
+  const size_t npad = (size_t)((n + BGP_NB - 1) / BGP_NB) * BGP_NB;
+  if (npad > c->cap_n) {
+    free_dev(c->dX);
+    free_dev(c->dy);
+    free_dev(c->dalpha);
+    c->dX = c->dy = c->dalpha = nullptr;
+    BGP_HIP(hipMalloc(&c->dX, npad * c->d * sizeof(double)));
+    BGP_HIP(hipMalloc(&c->dy, npad * sizeof(double)));
+    BGP_HIP(hipMalloc(&c->dalpha, npad * sizeof(double)));
+    c->cap_n = npad;
+  }
+  return BGP_OK;
+}
+
+static int alloc_work(bgp_ctx* c) {
+  const size_t npad = c->npad, nblk = c->nblk, mb = c->max_batch;
+  const size_t need_mat = mb * npad * npad;
+  const size_t need_w = mb * nblk * 128 * 128;
+  if (need_mat > c->cap_mat) {
+    free_dev(c->dK);
+    c->dK = nullptr;
+    BGP_HIP(hipMalloc(&c->dK, need_mat * sizeof(double)));
+    c->cap_mat = need_mat;
+  }
+  if (need_w > c->cap_w) {
+    free_dev(c->dW);
+    free_dev(c->dyw);
+    free_dev(c->dalpha_sol);
+    c->dW = c->dyw = c->dalpha_sol = nullptr;
+    BGP_HIP(hipMalloc(&c->dW, need_w * sizeof(double)));
+    BGP_HIP(hipMalloc(&c->dyw, mb * npad * sizeof(double)));
+    BGP_HIP(hipMalloc(&c->dalpha_sol, mb * npad * sizeof(double)));
+    c->cap_w = need_w;
+  }
+  return BGP_OK;
+}
+
+static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, const double* alpha_diag) {
+  if (n <= 0 || !X || !y || !alpha_diag) {
+    bgp_set_error("bgp: n must be > 0 and X, y, alpha_diag non-NULL");
+    return BGP_ERR_INVALID;
+  }
+  int rc = alloc_data(c, n);
+  if (rc) return rc;
+  c->n = n;
+  c->npad = ((n + BGP_NB - 1) / BGP_NB) * BGP_NB;
+  c->nblk = c->npad / BGP_NB;
+  rc = alloc_work(c);
+  if (rc) return rc;
+  std::vector<double> yp(c->npad, 0.0), ap(c->npad, 0.0);
+  memcpy(yp.data(), y, n * sizeof(double));
+  memcpy(ap.data(), alpha_diag, n * sizeof(double));
+  BGP_HIP(hipMemcpyAsync(c->dX, X, (size_t)n * c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpyAsync(c->dy, yp.data(), c->npad * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpyAsync(c->dalpha, ap.data(), c->npad * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  c->post_B = 0;
+  return BGP_OK;
+}
+
+extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const double* y, const double* alpha_diag,
+                              const bgp_kernel_spec* ks, int max_batch, bgp_ctx** out) {
+  if (!out || !ks) {
+    bgp_set_error("bgp_ctx_create: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  *out = nullptr;
+  if (d <= 0 || d > BGP_MAX_D || ks->d != d) {
+    bgp_set_error("bgp_ctx_create: d=%d out of range (1..%d) or != spec.d=%d", d, BGP_MAX_D, ks->d);
+    return BGP_ERR_INVALID;
+  }
+  if (ks->form < 0 || ks->form > 1 || ks->stationary < 0 || ks->stationary > 3) {
+    bgp_set_error("bgp_ctx_create: bad kernel spec (form=%d stationary=%d)", ks->form, ks->stationary);
+    return BGP_ERR_INVALID;
+  }
+  if (max_batch <= 0) {
+    bgp_set_error("bgp_ctx_create: max_batch must be > 0");
+    return BGP_ERR_INVALID;
+  }
+  int ndev = bgp_device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev) {
+    bgp_set_error("bgp_ctx_create: no usable HIP device (count=%d, requested=%d)", ndev, device);
+    return BGP_ERR_NODEVICE;
+  }
+  BGP_HIP(hipSetDevice(device));
+  bgp_ctx* c = new bgp_ctx();
+  c->device = device;
+  c->d = d;
+  c->ks = *ks;
+  c->max_batch = max_batch;
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    bgp_set_error("hipStreamCreate failed");
+    delete c;
+    return BGP_ERR_HIP;
+  }
+  const size_t mb = max_batch;
+  int rc = BGP_OK;
+  do {
+    if (hipMalloc(&c->dacc, mb * 4 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->dh, mb * (d + 2) * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->dlml, mb * sizeof(double)) != hipSuccess ||
+        hipMalloc(&c->dstatus, mb * sizeof(int)) != hipSuccess) {
+      bgp_set_error("hipMalloc of per-batch buffers failed");
+      rc = BGP_ERR_HIP;
+      break;
+    }
+    rc = upload_data(c, n, X, y, alpha_diag);
+  } while (0);
+  if (rc) {
+    bgp_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return BGP_OK;
+}
+
+extern "C" int bgp_ctx_update_data(bgp_ctx* c, int n, const double* X, const double* y, const double* alpha_diag) {
+  if (!c) {
+    bgp_set_error("bgp_ctx_update_data: NULL ctx");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  return upload_data(c, n, X, y, alpha_diag);
+}
+
+extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  free_dev(c->dX);
+  free_dev(c->dy);
+  free_dev(c->dalpha);
+  free_dev(c->dK);
+  free_dev(c->dW);
+  free_dev(c->dyw);
+  free_dev(c->dacc);
+  free_dev(c->dh);
+  free_dev(c->dlml);
+  free_dev(c->dstatus);
+  free_dev(c->dalpha_sol);
+  free_dev(c->dscratch);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int bgp_ensure_scratch(bgp_ctx* c, size_t doubles) {
+  if (doubles > c->cap_scratch) {
+    free_dev(c->dscratch);
+    c->dscratch = nullptr;
+    c->cap_scratch = 0;
+    BGP_HIP(hipMalloc(&c->dscratch, doubles * sizeof(double)));
+    c->cap_scratch = doubles;
+  }
+  return BGP_OK;
+}
+
+// Factorise one chunk (<= max_batch) of hyper-parameter vectors already validated by the caller.
+static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
+  const size_t p = c->d + 2;
+  BGP_HIP(hipMemcpyAsync(c->dh, h, B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemsetAsync(c->dstatus, 0, B * sizeof(int), c->stream));
+  int rc = bgp_launch_kbuild(c, B, full_square);
+  if (rc) return rc;
+  return BGP_OK;
+}
+
+extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, int* status) {
+  if (!c || !h || !lml || B < 0) {
+    bgp_set_error("bgp_lml_batch: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (B == 0) return BGP_OK;
+  BGP_HIP(hipSetDevice(c->device));
+  const size_t p = c->d + 2;
+  for (int k = 0; k < 5; k++) c->t_ms[k] = 0.0;
+  for (int k = 0; k < 4; k++) c->t_cnt[k] = 0;
+  c->post_B = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  for (int off = 0; off < B; off += c->max_batch) {
+    const int nb = std::min(c->max_batch, B - off);
+    if (c->timing) {
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, c->stream);
+    }
+    int rc = factor_chunk(c, nb, h + (size_t)off * p, 0);
+    if (rc) return rc;
+    rc = bgp_launch_cholesky(c, nb);
+    if (rc) return rc;
+    BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) {
+      BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (c->timing) (void)hipEventRecord(e1, c->stream);
+    BGP_HIP(hipStreamSynchronize(c->stream));
+    bgp_tcollect(c);
+    if (c->timing) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      c->t_ms[4] += ms;
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
+  }
+  return BGP_OK;
+}
+
+extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
+  if (!c || !h || !K) {
+    bgp_set_error("bgp_kernel_matrix: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  c->post_B = 0;
+  int rc = factor_chunk(c, 1, h, 1);
+  if (rc) return rc;
+  BGP_HIP(hipMemcpy2DAsync(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),
+                           (size_t)c->n * sizeof(double), c->n, hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
+}
+
+extern "C" int bgp_set_timing(bgp_ctx* c, int enable) {
+  if (!c) return BGP_ERR_INVALID;
+  c->timing = enable ? 1 : 0;
+  return BGP_OK;
+}
+
+extern "C" int bgp_last_timing(bgp_ctx* c, double* out_ms, int* counts) {
+  if (!c || !out_ms) return BGP_ERR_INVALID;
+  for (int k = 0; k < 5; k++) out_ms[k] = c->t_ms[k];
+  if (counts)
+    for (int k = 0; k < 4; k++) counts[k] = c->t_cnt[k];
+  return BGP_OK;
+}

@@ -1,0 +1,108 @@
+// Internal definitions shared by the libbgp translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bgp.h"
+
+#define BGP_NB 128          // block size of the right-looking Cholesky == tile edge
+#define BGP_TILE_LD 129     // LDS leading dimension of a 128x128 tile (odd -> conflict-free columns)
+#define BGP_MAX_D 256       // maximum input dimension
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+void bgp_set_error(const char* fmt, ...);
+
+#define BGP_HIP(call)                                                                        \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      bgp_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return BGP_ERR_HIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+
+struct bgp_ctx {
+  int device = 0;
+  int n = 0, d = 0, npad = 0, nblk = 0;
+  int max_batch = 0;
+  bgp_kernel_spec ks{};
+  hipStream_t stream = nullptr;
+  // resident training set
+  double* dX = nullptr;      // n*d
+  double* dy = nullptr;      // npad (zero padded)
+  double* dalpha = nullptr;  // npad
+  size_t cap_n = 0;          // capacity (rows) of the three buffers above
+  // per-batch workspace
+  double* dK = nullptr;      // max_batch * npad*npad   working matrices (become L in place)
+  double* dW = nullptr;      // max_batch * nblk * 128*128  inverses of the diagonal blocks
+  double* dyw = nullptr;     // max_batch * npad        working rhs (becomes z = L^-1 y)
+  double* dacc = nullptr;    // max_batch * 4           {logdet, z^T z, -, -}
+  double* dh = nullptr;      // max_batch * (d+2)       canonical hyper-parameters
+  double* dlml = nullptr;    // max_batch
+  int* dstatus = nullptr;    // max_batch
+  double* dalpha_sol = nullptr;  // max_batch * npad    K^-1 y of the resident posteriors
+  size_t cap_mat = 0;        // capacity in doubles of dK
+  size_t cap_w = 0;
+  // resident posterior state
+  int post_B = 0;            // number of resident posteriors (0 = none)
+  std::vector<double> post_h;
+  // scratch for predict / pvrs (grown on demand)
+  double* dscratch = nullptr;
+  size_t cap_scratch = 0;
+  // timing
+  int timing = 0;
+  double t_ms[5] = {0, 0, 0, 0, 0};
+  int t_cnt[4] = {0, 0, 0, 0};
+  std::vector<hipEvent_t> ev;  // (start, stop) pairs of the launches of the current call
+  std::vector<int> evcat;
+};
+
+// Per-launch HIP-event timing on the context's stream (only when ctx->timing != 0).
+// Categories: 0 K-build, 1 potrf, 2 trsm, 3 syrk.
+static inline void bgp_tbegin(bgp_ctx* c, int cat) {
+  if (!c->timing) return;
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, c->stream);
+  c->ev.push_back(a);
+  c->ev.push_back(b);
+  c->evcat.push_back(cat);
+}
+static inline void bgp_tend(bgp_ctx* c) {
+  if (!c->timing) return;
+  (void)hipEventRecord(c->ev.back(), c->stream);
+}
+static inline void bgp_tcollect(bgp_ctx* c) {
+  if (!c->timing) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (size_t i = 0; i < c->evcat.size(); i++) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]);
+    c->t_ms[c->evcat[i]] += ms;
+    c->t_cnt[c->evcat[i]] += 1;
+    (void)hipEventDestroy(c->ev[2 * i]);
+    (void)hipEventDestroy(c->ev[2 * i + 1]);
+  }
+  c->ev.clear();
+  c->evcat.clear();
+}
+
+int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
+
+// ---- kernels launched across translation units ----
+// K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).
+int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square);
+// Cross kernel matrix k(Xq, X_train) for hyper-vector index b: out is m x ldo row-major (device).
+int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
+                      double* dout, int ldo, int symmetric_diag_fix);
+// Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
+int bgp_launch_cholesky(bgp_ctx* ctx, int B);

@@ -1,0 +1,37 @@
+// Device helpers shared by the libbgp kernels (gfx950 only).
+#pragma once
+#include "bgp_common.h"
+
+static __device__ __forceinline__ double bgp_stationary(double r2, int stat) {
+  // same operation order as sklearn/kernels.py:1553-1560 and :1713-1733
+  if (stat == BGP_RBF) return exp(-0.5 * r2);
+  double dist = sqrt(r2);
+  if (stat == BGP_MATERN12) return exp(-dist);
+  if (stat == BGP_MATERN32) {
+    double t = dist * 1.7320508075688772;  // math.sqrt(3)
+    return (1.0 + t) * exp(-t);
+  }
+  double t = dist * 2.23606797749979;  // math.sqrt(5)
+  return (1.0 + t + t * t / 3.0) * exp(-t);
+}
+
+// XCD-aware block -> (matrix b, tile t) map.  The dispatcher places block id on XCD id % 8
+// (MI355X_MICROARCH.md "Workgroup dispatch"); matrix b is pinned to XCD b % 8 and each XCD walks
+// through its matrices one after another so that the panels a matrix's tiles share stay in that
+// XCD's private 4 MiB L2.  Placement only affects speed, never results.
+static __device__ __forceinline__ void bgp_map_block(int id, int tiles, int& b, int& t) {
+  int x = id & 7;
+  int q = id >> 3;
+  int m = q / tiles;
+  t = q - m * tiles;
+  b = 8 * m + x;
+}
+
+static __device__ __forceinline__ void bgp_tri_decode(int t, int& ti, int& tj) {
+  int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (r * (r + 1) / 2 > t) r--;
+  while ((r + 1) * (r + 2) / 2 <= t) r++;
+  ti = r;
+  tj = t - r * (r + 1) / 2;
+}
+

@@ -1,0 +1,140 @@
+// Kernel-matrix build: tiled pairwise-distance kernel staging X tiles in LDS.
+//
+// Replaces kernel_(X_train_) + diagonal add -- sklearn/kernels.py:1708-1738 (Matern.__call__),
+// :1553-1560 (RBF), :966 (Product), :866 (Sum), :1273 (Constant), :1402 (White),
+// sklearn/_gpr.py:585 / bask/bayesgpr.py:204 (K[diag] += alpha).
+//
+// One 256-thread workgroup produces one 128x128 tile; thread (tx,ty) of the 16x16 thread grid owns
+// the 8x8 strided micro-tile rows ty+16r, cols tx+16c, so that for a fixed (r,c) the 16 lanes of a
+// row write 128 contiguous bytes (full cache lines) and LDS reads of the column operand are
+// conflict-free.  X tiles are pre-divided by the walker's length scales while being staged.
+// HBM-bound by design: 8 B written per pair, X re-read from L2.
+#include "bgp_common.h"
+#include "bgp_device.h"
+
+#define KB_DK 16  // input dimensions staged per pass
+
+// Generic tile body: out[(i0+..)][(j0+..)] = k(A_i, B_j); A is (na x d), Bm is (nb x d), row-major.
+// gram != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.
+template <int GRAM>
+__device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na, const double* __restrict__ Bm,
+                                            int nb, int d, const double* __restrict__ h,
+                                            const double* __restrict__ alpha, int form, int stat, int i0, int j0,
+                                            double* __restrict__ out, size_t ldo, int out_rows, int out_cols) {
+  __shared__ double xi[KB_DK][BGP_TILE_LD];
+  __shared__ double xj[KB_DK][BGP_TILE_LD];
+  __shared__ double ell[KB_DK];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; r++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[r][c] = 0.0;
+
+  for (int k0 = 0; k0 < d; k0 += KB_DK) {
+    const int kc = min(KB_DK, d - k0);
+    __syncthreads();
+    if (tid < kc) ell[tid] = exp(h[1 + k0 + tid]);
+    __syncthreads();
+    for (int idx = tid; idx < kc * 128; idx += 256) {
+      int row = idx / kc, k = idx - row * kc;
+      int gi = i0 + row, gj = j0 + row;
+      double l = ell[k];
+      xi[k][row] = (gi < na) ? A[(size_t)gi * d + k0 + k] / l : 0.0;
+      xj[k][row] = (gj < nb) ? Bm[(size_t)gj * d + k0 + k] / l : 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < kc; k++) {
+      double a[8], b[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) a[r] = xi[k][ty + 16 * r];
+#pragma unroll
+      for (int c = 0; c < 8; c++) b[c] = xj[k][tx + 16 * c];
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          double df = a[r] - b[c];
+          acc[r][c] += df * df;
+        }
+    }
+  }
+  const double cst = exp(h[0]);
+  const double s2 = exp(h[d + 1]);
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int gi = i0 + ty + 16 * r;
+    if (gi >= out_rows) continue;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gj = j0 + tx + 16 * c;
+      if (gj >= out_cols) continue;
+      double v;
+      if (GRAM && (gi >= na || gj >= nb)) {
+        v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
+      } else if (GRAM && gi == gj) {
+        // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
+        double base = (form == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+        v = (base + s2) + alpha[gi];
+      } else {
+        double s = bgp_stationary(acc[r][c], stat);
+        v = (form == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+      }
+      out[(size_t)gi * ldo + gj] = v;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restrict__ X,
+                                                           const double* __restrict__ alpha,
+                                                           const double* __restrict__ H, double* __restrict__ Kbuf,
+                                                           const double* __restrict__ y, double* __restrict__ yw,
+                                                           int n, int d, int npad, int nblk, int form, int stat,
+                                                           int B, int full) {
+  const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
+  int b, t;
+  bgp_map_block(blockIdx.x, ntiles, b, t);
+  if (b >= B) return;
+  int ti, tj;
+  if (full) {
+    ti = t / nblk;
+    tj = t - ti * nblk;
+  } else {
+    bgp_tri_decode(t, ti, tj);
+  }
+  const double* h = H + (size_t)b * (d + 2);
+  double* out = Kbuf + (size_t)b * npad * npad;
+  // working right-hand side of walker b (becomes z = L^-1 y during the factorisation)
+  if (ti == tj && threadIdx.x < 128) yw[(size_t)b * npad + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
+  kbuild_tile<1>(X, n, X, n, d, h, alpha, form, stat, ti * 128, tj * 128, out, (size_t)npad, npad, npad);
+}
+
+__global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restrict__ Xq, int m,
+                                                            const double* __restrict__ Xt, int n, int d,
+                                                            const double* __restrict__ h, int form, int stat,
+                                                            double* __restrict__ out, int ldo, int tiles_j) {
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+  kbuild_tile<0>(Xq, m, Xt, n, d, h, nullptr, form, stat, ti * 128, tj * 128, out, (size_t)ldo, m, n);
+}
+
+int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square) {
+  const int nblk = ctx->nblk;
+  const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
+  const int grid = 8 * ((B + 7) / 8) * ntiles;
+  bgp_tbegin(ctx, 0);
+  hipLaunchKernelGGL(kbuild_gram_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dX, ctx->dalpha, ctx->dh,
+                     ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, ctx->ks.form, ctx->ks.stationary, B, full_square);
+  bgp_tend(ctx);
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
+}
+
+int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
+                      double* dout, int ldo, int /*unused*/) {
+  const int tiles_i = (m + 127) / 128, tiles_j = (nx + 127) / 128;
+  hipLaunchKernelGGL(kbuild_cross_kernel, dim3(tiles_i * tiles_j), dim3(256), 0, ctx->stream, dXq, m, dXt, nx,
+                     ctx->d, dh_b, ctx->ks.form, ctx->ks.stationary, dout, ldo, tiles_j);
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
+}

@@ -1,0 +1,163 @@
+/*
+ * bgp.h -- C-ABI of the MI355X-native BayesGPR hot path (libbgp.so).
+ *
+ * The reference (kiudee/bayes-skopt 0.11.0) has no FFI boundary: the seams this library sits
+ * behind are Python call sites.  Each entry point below names the
+ * reference interface it replaces.  The host side that binds these symbols with ctypes lives in
+ * bayes-skopt_amd/_lib.py; INTEGRATION.md shows the stub a bask maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; all host buffers are caller-owned, C-contiguous, fp64 (double) / int32;
+ *  - return value 0 == BGP_OK, anything else is an error whose text bgp_last_error() returns
+ *    (thread-local); no C++ exception crosses the ABI;
+ *  - NUMERICAL failures (non-positive pivot == "not positive definite") are per-item:
+ *    status[b] != 0 and lml[b] = -inf  (sklearn/_gpr.py:586-589 returns -inf there), never a
+ *    call failure;
+ *  - hyper-parameters are passed in the CANONICAL log-space layout
+ *        h = [ log c, log l_1 .. log l_d, log s2 ]            (d + 2 doubles per item)
+ *    with   K = c * S(r) + s2 * I   (form BGP_FORM_PRODUCT; ConstantKernel * Matern + WhiteKernel,
+ *                                    bask/utils.py:144-150 + skopt's added WhiteKernel)
+ *           K = c + S(r) + s2 * I   (form BGP_FORM_SUM;     examples/Fit-GP.ipynb cell 6)
+ *    r_ij^2 = sum_k ((x_ik - x_jk) / l_k)^2 ; -inf encodes an absent / zeroed component
+ *    (bask/bayesgpr.py:328-333 swaps in WhiteKernel(0.0)).  The mapping from a kernel object's
+ *    theta (sklearn/kernels.py:733-760 concatenation order, fixed hyper-parameters dropped,
+ *    isotropic length scale replicated) to h is host logic (bayes-skopt_amd/kernels.py);
+ *  - one context per (host thread, device); calls on a context are serialised on its HIP stream.
+ */
+#ifndef BGP_H
+#define BGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BGP_OK 0
+#define BGP_ERR_INVALID 1  /* bad argument                      */
+#define BGP_ERR_HIP 2      /* a HIP runtime call failed          */
+#define BGP_ERR_NODEVICE 3 /* no usable gfx950 device            */
+#define BGP_ERR_STATE 4    /* call order (e.g. predict before posterior) */
+
+enum { BGP_FORM_PRODUCT = 0, BGP_FORM_SUM = 1 };
+enum { BGP_RBF = 0, BGP_MATERN12 = 1, BGP_MATERN32 = 2, BGP_MATERN52 = 3 };
+
+typedef struct bgp_kernel_spec {
+  int form;       /* BGP_FORM_*                                   */
+  int stationary; /* BGP_RBF / BGP_MATERN*  (sklearn/kernels.py:1553-1560, 1713-1733) */
+  int d;          /* input dimension                              */
+} bgp_kernel_spec;
+
+typedef struct bgp_ctx bgp_ctx;
+
+/* Number of visible HIP devices (0 when none / runtime unusable). */
+int bgp_device_count(void);
+/* Text of the last error on this thread. */
+const char* bgp_last_error(void);
+/* Library version string. */
+const char* bgp_version(void);
+
+/*
+ * Create a context on `device` holding the training set (copied to HBM and kept resident):
+ * X (n*d row-major), y (n, already normalised by the caller as bask/bayesgpr.py:470-478 does),
+ * alpha_diag (n; the diagonal term sklearn/_gpr.py:585 adds -- scalar alpha already broadcast,
+ * noise vector already added, bask/bayesgpr.py:338-349).
+ * max_batch bounds the number of hyper-parameter vectors factorised concurrently (workspace is
+ * max_batch * n_pad^2 doubles); larger B are processed in chunks.
+ * Replaces: the data the reference keeps on self.X_train_/y_train_/alpha (bask/bayesgpr.py:485-488).
+ */
+int bgp_ctx_create(int device, int n, int d, const double* X, const double* y, const double* alpha_diag,
+                   const bgp_kernel_spec* ks, int max_batch, bgp_ctx** out);
+
+/* tell() grows the data set (bask/optimizer.py:288-320 -> bask/bayesgpr.py:469-488). d is fixed. */
+int bgp_ctx_update_data(bgp_ctx* ctx, int n, const double* X, const double* y, const double* alpha_diag);
+
+void bgp_ctx_destroy(bgp_ctx* ctx);
+
+/*
+ * Batched log-marginal-likelihood: for each of B canonical vectors h_b
+ *     K_b = kernel(X) ; K_b[diag] += alpha_diag ; L_b = chol(K_b) ;
+ *     lml_b = -1/2 y^T K_b^-1 y - sum log diag(L_b) - n/2 log(2 pi)
+ * Replaces: GaussianProcessRegressor.log_marginal_likelihood(theta) (sklearn/_gpr.py:537-613)
+ * as called per walker by BayesGPR._log_prob_fn (bask/bayesgpr.py:374) from
+ * emcee.EnsembleSampler.compute_log_prob (bask/bayesgpr.py:510-524).
+ * status[b] = 0 ok, >0 = 1-based index of the failing pivot (lml[b] = -inf). status may be NULL.
+ */
+int bgp_lml_batch(bgp_ctx* ctx, int B, const double* h, double* lml, int* status);
+
+/*
+ * LML and its gradient w.r.t. the canonical vector (grad is B*(d+2)):
+ *     g_k = 1/2 tr((alpha alpha^T - K^-1) dK/dh_k)
+ * Replaces: log_marginal_likelihood(theta, eval_gradient=True) (sklearn/_gpr.py:615-647,
+ * kernels.py:1746-1766) driven by L-BFGS-B inside fit (bask/bayesgpr.py:607).
+ */
+int bgp_lml_grad_batch(bgp_ctx* ctx, int B, const double* h, double* lml, double* grad, int* status);
+
+/*
+ * Parity helper: the jittered Gram matrix K(h) itself, n*n row-major (both triangles filled).
+ * Replaces: kernel_(X_train_) + diagonal add (bask/bayesgpr.py:203-204).
+ */
+int bgp_kernel_matrix(bgp_ctx* ctx, const double* h, double* K);
+
+/*
+ * Posterior build for B hyper-posterior samples; factors stay RESIDENT on the device for the
+ * predict / pvrs calls that follow.  Any of the output pointers may be NULL.
+ *   L      B*n*n row-major lower Cholesky factors (upper triangle zero)   -> BayesGPR.L_
+ *   alpha  B*n            K^-1 y                                          -> BayesGPR.alpha_
+ *   K_inv  B*n*n          explicit inverse                                -> BayesGPR.K_inv_
+ * Replaces: the BayesGPR.theta setter (bask/bayesgpr.py:200-217), called once per sample()
+ * (:544) and once per hyper-posterior sample by evaluate_acquisitions (bask/acquisition.py:112-121).
+ */
+int bgp_posterior_batch(bgp_ctx* ctx, int B, const double* h, double* L, double* alpha, double* K_inv,
+                        double* lml, int* status);
+
+/*
+ * Predict at m query points with the B resident posteriors.  h_kernel (B*(d+2)) are the
+ * hyper-parameters currently in kernel_ -- they differ from the posterior's only inside
+ * noise_set_to_zero() (log s2 = -inf), which does NOT rebuild the factors
+ * (bask/bayesgpr.py:318-336).  Outputs (normalised-y units; the caller undoes y
+ * normalisation): mean B*m, var B*m (clipped at 0), optional cov B*m*m (may be NULL).
+ *   mean = K_* alpha ; var = k_** - diag(K_* K^-1 K_*^T) ; cov = K_** - K_* K^-1 K_*^T
+ * Replaces: BayesGPR.predict (bask/bayesgpr.py:622-635 -> skopt predict).
+ */
+int bgp_predict_batch(bgp_ctx* ctx, int B, const double* h_kernel, int m, const double* Xq, double* mean,
+                      double* var, double* cov);
+
+/*
+ * PVRS inner loop with resident posterior 0 (built WITHOUT the candidate row; alpha_diag as in
+ * the context when has_alpha_vec != 0, else the reference adds nothing to the augmented
+ * diagonal -- bask/acquisition.py:332-333):  for every candidate i
+ *   covs[i] = sum_t k_t,aug^T K_aug,i^-1 k_t,aug ,   K_aug,i = kernel([X_train; x_i])
+ * computed with the bordered-Cholesky identity instead of m factorizations.
+ * Replaces: PVRS.__call__ loop (bask/acquisition.py:328-338); with thompson == candidates it is
+ * VarianceReduction (bask/acquisition.py:287-300).
+ */
+int bgp_pvrs(bgp_ctx* ctx, const double* h_kernel, int m, const double* Xcand, int T, const double* Xthompson,
+             double* covs);
+
+/*
+ * Draw f ~ N(mean, cov) at m points for resident posterior b using standard normals supplied by
+ * the host (z: n_draws*m), via a Cholesky factor of cov (+jitter) instead of numpy's SVD.
+ * Replaces: sklearn sample_y (sklearn/_gpr.py:522-526) reached from BayesGPR.sample_y
+ * (bask/bayesgpr.py:637-718).  out: n_draws*m.
+ */
+int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
+                 const double* z, double jitter, double* out);
+
+/* ---- measurement hooks (bench.py / profiling; not part of the reference surface) ---- */
+
+/* Average device time (ms, HIP events on the context's stream) of the kernels of the last
+ * bgp_lml_batch call: out[0]=K-build, out[1]=potrf (diagonal blocks), out[2]=trsm (panels),
+ * out[3]=syrk (trailing update), out[4]=whole call on device; counts[0..3] = launches. */
+int bgp_last_timing(bgp_ctx* ctx, double* out_ms, int* counts);
+/* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
+int bgp_set_timing(bgp_ctx* ctx, int enable);
+/* fp64 MFMA micro-benchmark: TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on the whole chip. */
+int bgp_bench_mfma_f64(int device, int iters, double* tflops);
+/* HBM copy micro-benchmark: GB/s (read+write) of a streaming double2 copy of `bytes` bytes. */
+int bgp_bench_hbm_copy(int device, long long bytes, int iters, double* gbps);
+/* Empirical C/D fragment layout of v_mfma_f64_16x16x4_f64: rows[64*4], cols[64*4] (lane*4+reg). */
+int bgp_mfma_f64_layout(int device, int* rows, int* cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGP_H */

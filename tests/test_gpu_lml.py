@@ -1,0 +1,108 @@
+"""GPU parity of the LML hot path (kernel build -> blocked Cholesky -> fused solve -> LML) through the
+C-ABI against the golden vectors (sklearn 1.7.2) and the oracle.  Tolerance: 1e-6 relative
+(BASELINE.json north_star); observed errors are reported by tools/gpu_probe.py."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import _lib
+
+    assert _lib.device_count() >= 1, "no HIP device: GPU tests need an MI355X"
+    return _lib
+
+
+def test_mfma_f64_fragment_layout(lib):
+    rows, cols = lib.mfma_f64_layout()
+    lane = np.arange(64)[:, None]
+    reg = np.arange(4)[None, :]
+    np.testing.assert_array_equal(cols, np.broadcast_to(lane & 15, (64, 4)))
+    np.testing.assert_array_equal(rows, (lane >> 4) + 4 * reg)
+
+
+def test_kernel_matrix_all_forms(lib):
+    g = load_golden("lml_small.npz")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        st, form = [str(s) for s in g[pre + "meta"]]
+        ctx = lib.Context(g[pre + "X"], g[pre + "y"], g[pre + "alpha_diag"], form=form, stationary=st, max_batch=8)
+        for b, th in enumerate(g[pre + "theta"][:2]):
+            K = ctx.kernel_matrix(th)
+            np.testing.assert_allclose(K, g[pre + "K"][b], rtol=1e-12, atol=1e-14)
+        ctx.close()
+
+
+def test_lml_small_all_forms(lib):
+    g = load_golden("lml_small.npz")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        st, form = [str(s) for s in g[pre + "meta"]]
+        ctx = lib.Context(g[pre + "X"], g[pre + "y"], g[pre + "alpha_diag"], form=form, stationary=st, max_batch=4)
+        got, status = ctx.lml(g[pre + "theta"], return_status=True)  # B=6 > max_batch: exercises chunking
+        assert np.all(status == 0)
+        np.testing.assert_allclose(got, g[pre + "lml"], rtol=RTOL)
+        ctx.close()
+
+
+def test_lml_config_A_and_edge_thetas(lib):
+    g = load_golden("lml_sizes.npz")
+    ctx = lib.Context(g["A_X"], g["A_y"], 1e-10, max_batch=16)
+    got = ctx.lml(g["A_theta"])
+    np.testing.assert_allclose(got, g["A_lml"], rtol=RTOL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["M1", "M2", "M3", "M4"])
+def test_lml_ragged_sizes_vector_alpha(lib, tag):
+    g = load_golden("lml_sizes.npz")
+    n, d, seed = [int(v) for v in g[tag + "_nd_seed"]]
+    X, y = synth(n, d, seed)
+    ctx = lib.Context(X, y, g[tag + "_alpha_diag"], max_batch=8)
+    got = ctx.lml(g[tag + "_theta"])
+    np.testing.assert_allclose(got, g[tag + "_lml"], rtol=RTOL)
+    ctx.close()
+
+
+def test_singular_matrix_gives_minus_inf_and_status(lib):
+    g = load_golden("lml_sizes.npz")
+    ctx = lib.Context(g["S_X"], g["S_y"], np.zeros(16), max_batch=4)
+    ok = np.array([0.0, np.log(0.3), np.log(0.3), np.log(0.1)])
+    H = np.vstack([g["S_theta"][0], ok, g["S_theta"][0]])
+    got, status = ctx.lml(H, return_status=True)
+    assert got[0] == -np.inf and got[2] == -np.inf and np.isfinite(got[1])
+    assert status[0] == 2 and status[2] == 2 and status[1] == 0  # second pivot is exactly zero
+    ctx.close()
+
+
+@pytest.mark.parametrize("tag", ["B", "C", "D"])
+def test_lml_baseline_configs_full_size(lib, tag):
+    g = load_golden("lml_sizes.npz")
+    n, d, seed = [int(v) for v in g[tag + "_nd_seed"]]
+    X, y = synth(n, d, seed)
+    ctx = lib.Context(X, y, 1e-10, max_batch=4)
+    got = ctx.lml(g[tag + "_theta"])
+    np.testing.assert_allclose(got, g[tag + "_lml"], rtol=RTOL)
+    ctx.close()
+
+
+def test_update_data_grows_n(lib):
+    """tell() appends points: same context, larger n (bask/optimizer.py:288-320)."""
+    from oracle import gp_oracle as O
+
+    X, y = synth(200, 3, 9)
+    th = np.array([[0.1, -1.0, -1.2, -0.9, -4.0]])
+    ctx = lib.Context(X[:100], y[:100], 1e-10, max_batch=2)
+    for n in (100, 129, 200):
+        if n != 100:
+            ctx.update_data(X[:n], y[:n], np.full(n, 1e-10))
+        got = ctx.lml(th)
+        np.testing.assert_allclose(got[0], O.lml(X[:n], y[:n], np.full(n, 1e-10), th[0]), rtol=RTOL)
+    ctx.close()
