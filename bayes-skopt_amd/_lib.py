@@ -20,6 +20,13 @@ class BgpError(RuntimeError):
     pass
 
 
+class NotPositiveDefinite(BgpError):
+    """bgp_sample_y: predictive covariance (+ jitter) is not numerically positive definite."""
+
+
+BGP_ERR_NOTPD = 5
+
+
 class KernelSpecStruct(C.Structure):
     _fields_ = [("form", C.c_int), ("stationary", C.c_int), ("d", C.c_int)]
 
@@ -43,6 +50,7 @@ SIGNATURES = {
     "bgp_posterior_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
     "bgp_predict_batch": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp]),
     "bgp_pvrs": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]),
+    "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
@@ -112,6 +120,9 @@ class Context:
                                   C.byref(h)), "bgp_ctx_create")
         self._h = h
         self._lib = lib
+        # canonical vectors of the posteriors whose K^-1 / alpha are resident on the device
+        # (None after a call that overwrites them: gradient / pvrs_prepare / update_data)
+        self.resident_H = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -133,6 +144,7 @@ class Context:
         alpha_diag = _c(np.broadcast_to(np.asarray(alpha_diag, dtype=np.float64), (n,)))
         _check(self._lib.bgp_ctx_update_data(self._h, n, _p(X), _p(y), _p(alpha_diag)), "bgp_ctx_update_data")
         self.n = n
+        self.resident_H = None
 
     def _H(self, H):
         H = _c(np.atleast_2d(H))
@@ -154,6 +166,7 @@ class Context:
         out = np.empty(B)
         grad = np.empty((B, self.p))
         st = np.zeros(B, dtype=np.int32)
+        self.resident_H = None
         _check(self._lib.bgp_lml_grad_batch(self._h, B, _p(H), _p(out), _p(grad), _p(st)), "bgp_lml_grad_batch")
         return out, grad, st
 
@@ -172,9 +185,12 @@ class Context:
         lml = np.empty(B)
         st = np.zeros(B, dtype=np.int32)
         nul = C.cast(None, _dp)
+        self.resident_H = None
         _check(self._lib.bgp_posterior_batch(self._h, B, _p(H), _p(L) if want_L else nul,
                                              _p(a) if want_alpha else nul, _p(Ki) if want_K_inv else nul, _p(lml),
                                              _p(st)), "bgp_posterior_batch")
+        if np.all(st == 0):
+            self.resident_H = H.copy()
         return {"L": L, "alpha": a, "K_inv": Ki, "lml": lml, "status": st}
 
     def predict(self, H_kernel, Xq, return_cov=False):
@@ -189,6 +205,13 @@ class Context:
         _check(self._lib.bgp_predict_batch(self._h, B, _p(H), m, _p(Xq), _p(mean), _p(var),
                                            _p(cov) if return_cov else nul), "bgp_predict_batch")
         return (mean, var, cov) if return_cov else (mean, var)
+
+    def pvrs_prepare(self, h_kernel, has_alpha_vec):
+        H = self._H(h_kernel)
+        st = np.zeros(1, dtype=np.int32)
+        self.resident_H = None
+        _check(self._lib.bgp_pvrs_prepare(self._h, _p(H), int(bool(has_alpha_vec)), _p(st)), "bgp_pvrs_prepare")
+        return int(st[0])
 
     def pvrs(self, h_kernel, Xcand, Xthompson):
         H = self._H(h_kernel)
@@ -206,8 +229,10 @@ class Context:
         if z.shape[1] != m:
             raise ValueError("z must be (n_draws, m)")
         out = np.empty_like(z)
-        _check(self._lib.bgp_sample_y(self._h, int(b), _p(H), m, _p(Xq), z.shape[0], _p(z), float(jitter), _p(out)),
-               "bgp_sample_y")
+        rc = self._lib.bgp_sample_y(self._h, int(b), _p(H), m, _p(Xq), z.shape[0], _p(z), float(jitter), _p(out))
+        if rc == BGP_ERR_NOTPD:
+            raise NotPositiveDefinite(self._lib.bgp_last_error().decode())
+        _check(rc, "bgp_sample_y")
         return out
 
     def set_timing(self, enable):

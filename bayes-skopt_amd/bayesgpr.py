@@ -1,0 +1,560 @@
+"""BayesGPR: fully Bayesian Gaussian-process regressor whose posterior arithmetic runs on the MI355X.
+
+Host-side mirror of ``bask.BayesGPR`` (``bask/bayesgpr.py``): same constructor, ``fit`` / ``sample`` /
+``predict`` / ``sample_y`` / ``theta`` / ``noise_set_to_zero`` surface and the same derived
+quantities (walker count, step count, start ball, chain flattening, geometric median, warm start
+through ``pos_``).  Everything numerical -- kernel matrices, Cholesky factorisations, solves, the
+log-marginal likelihood evaluated for every MCMC proposal, predictive means / variances -- is done
+by the HIP kernels behind the C-ABI (``include/bgp.h``); there is no CPU fallback.
+
+Where the reference relies on inherited third-party code, the behaviour restated here is:
+  * skopt's GaussianProcessRegressor.fit: append ``+ WhiteKernel()`` when ``noise="gaussian"``,
+    MAP-fit theta, remember ``noise_``, replace the fitted WhiteKernel by ``WhiteKernel(0.0)`` in
+    ``kernel_`` (so ``theta[-1] == -inf`` afterwards), keep factors that include the noise
+    (SURVEY.md 2b, Appendix B.1);
+  * sklearn's fit: y normalisation, L-BFGS-B on -LML from ``kernel_.theta`` within ``kernel_.bounds``
+    (``sklearn/_gpr.py:296-341``) -- objective and gradient are evaluated on the device;
+  * skopt's predict: ``var = diag - einsum(K*, K*, K_inv_)`` clipped at 0.
+"""
+import warnings
+from contextlib import contextmanager, nullcontext
+
+import numpy as np
+import scipy.optimize
+from sklearn.base import clone
+from sklearn.utils import check_random_state
+
+from . import _lib
+from .kernels import ConstantKernel, WhiteKernel, analyse_kernel, param_for_white_kernel_in_sum
+from .kernels import RBF as _RBF
+from .sampler import EnsembleSampler
+from .utils import geometric_median, guess_priors
+
+__all__ = ["BayesGPR"]
+
+_PD_MESSAGE = (
+    "The kernel, %s, is not returning a positive definite matrix. Try gradually increasing the "
+    "'alpha' parameter of your GaussianProcessRegressor estimator."
+)
+
+
+class BayesGPR:
+    """Gaussian process regressor of which the kernel hyper-parameters are inferred in a fully
+    Bayesian framework (constructor arguments as ``bask/bayesgpr.py:148-159``).
+
+    Extra, MI355X-specific keyword: ``device`` (HIP device ordinal, default 0) and
+    ``max_batch`` (matrices factorised concurrently; default = half the walkers).
+    """
+
+    def __init__(
+        self,
+        kernel=None,
+        alpha=1e-10,
+        optimizer="fmin_l_bfgs_b",
+        n_restarts_optimizer=0,
+        normalize_y=False,
+        warp_inputs=False,
+        copy_X_train=True,
+        random_state=None,
+        noise="gaussian",
+        device=0,
+        max_batch=None,
+    ):
+        self._kernel = None if kernel is None else kernel.clone_with_theta(kernel.theta)
+        self.kernel = kernel
+        self.alpha = alpha
+        self._alpha = alpha
+        self.optimizer = optimizer
+        self.n_restarts_optimizer = n_restarts_optimizer
+        self.normalize_y = normalize_y
+        if warp_inputs:
+            raise NotImplementedError(
+                "warp_inputs=True (input warping, bask/bayesgpr.py:219-316) is not available on the "
+                "MI355X path yet (SURVEY.md 8f row f3)"
+            )
+        self.warp_inputs = False
+        self.copy_X_train = copy_X_train
+        self.random_state = check_random_state(random_state)
+        self.noise = noise
+        self.device = device
+        self.max_batch = max_batch
+        self._sampler = None
+        self.chain_ = None
+        self.pos_ = None
+        self.kernel_ = None
+        self.noise_ = None
+        self._ctx = None
+        self._plan = None
+        self._post_theta = None  # theta the resident posterior (L_, alpha_, K_inv_) was built with
+        self._L = self._K_inv = None
+        self.alpha_ = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _ensure_context(self, batch_hint=None):
+        """(Re)create / update the device context for the current training set."""
+        X, y = self._X_train_, self.y_train_
+        n = X.shape[0]
+        alpha_diag = np.broadcast_to(np.asarray(self.alpha, dtype=np.float64), (n,)) if not np.iterable(self.alpha) \
+            else np.asarray(self.alpha, dtype=np.float64)
+        if alpha_diag.shape[0] != n:
+            raise ValueError(f"alpha must be a scalar or an array with same number of entries as y. "
+                             f"({alpha_diag.shape[0]} != {n})")
+        plan = analyse_kernel(self.kernel_)
+        want_batch = int(self.max_batch or batch_hint or 64)
+        ctx = self._ctx
+        if (ctx is None or ctx.d != X.shape[1] or ctx.form != plan.form or ctx.stationary != plan.stationary
+                or ctx.max_batch < want_batch):
+            if ctx is not None:
+                ctx.close()
+            ctx = _lib.Context(X, y, alpha_diag, form=plan.form, stationary=plan.stationary,
+                               max_batch=max(want_batch, ctx.max_batch if ctx is not None else 0), device=self.device)
+        else:
+            ctx.update_data(X, y, alpha_diag)
+        self._ctx, self._plan = ctx, plan
+        self._post_theta = None
+        self._L = self._K_inv = None
+        return ctx
+
+    def _canonical(self, theta):
+        return self._plan.canonical(theta, self._X_train_.shape[1])
+
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False, clone_kernel=True):
+        """``sklearn/_gpr.py:537-652`` on the device.  theta may be (p,) or a (B, p) block."""
+        if theta is None:
+            if eval_gradient:
+                raise ValueError("Gradient can only be evaluated for theta!=None")
+            return self.log_marginal_likelihood_value_
+        theta = np.asarray(theta, dtype=np.float64)
+        single = theta.ndim == 1
+        H = self._canonical(theta)
+        if eval_gradient:
+            lml, gh, _ = self._ctx.lml_grad(H)
+            g = self._plan.grad_to_theta(gh, self._X_train_.shape[1])
+            return (float(lml[0]), g[0]) if single else (lml, g)
+        lml = self._ctx.lml(H)
+        return float(lml[0]) if single else lml
+
+    # ------------------------------------------------------------------ theta / posterior
+    @property
+    def theta(self):
+        """Current (geometric-median) kernel hyper-parameters in log space
+        (``bask/bayesgpr.py:182-198``)."""
+        if self.kernel_ is not None:
+            with np.errstate(divide="ignore"):
+                return np.copy(self.kernel_.theta)
+        return None
+
+    @theta.setter
+    def theta(self, theta):
+        """Posterior build, ``bask/bayesgpr.py:200-217``: K, L_, K_inv_, alpha_ on the device."""
+        theta = np.asarray(theta, dtype=np.float64)
+        self.kernel_.theta = theta
+        self._build_posterior(theta)
+
+    def _build_posterior(self, theta):
+        res = self._ctx.posterior(self._canonical(theta), want_L=False, want_alpha=True, want_K_inv=False)
+        if res["status"][0] != 0:
+            raise np.linalg.LinAlgError(
+                _PD_MESSAGE % self.kernel_,
+                "%d-th leading minor of the array is not positive definite" % res["status"][0],
+            )
+        self.alpha_ = res["alpha"][0]
+        self._post_theta = np.array(theta, copy=True)
+        self._L = self._K_inv = None
+
+    def _fetch_factor(self, which):
+        if self._post_theta is None:
+            raise AttributeError("no posterior has been built yet")
+        res = self._ctx.posterior(self._canonical(self._post_theta), want_L=(which == "L"), want_alpha=False,
+                                  want_K_inv=(which == "K_inv"))
+        return res[which][0]
+
+    @property
+    def L_(self):
+        """Lower Cholesky factor of the kernel matrix (fetched from the device on demand)."""
+        if self._L is None:
+            self._L = self._fetch_factor("L")
+        return self._L
+
+    @L_.setter
+    def L_(self, value):
+        self._L = value
+
+    @property
+    def K_inv_(self):
+        """Explicit inverse K^-1 (``bask/bayesgpr.py:207-208``), fetched on demand."""
+        if self._K_inv is None:
+            self._K_inv = self._fetch_factor("K_inv")
+        return self._K_inv
+
+    @K_inv_.setter
+    def K_inv_(self, value):
+        self._K_inv = value
+
+    @property
+    def X_train_(self):
+        return getattr(self, "_X_train_", None)
+
+    @X_train_.setter
+    def X_train_(self, X_train):
+        X_train = np.asarray(X_train, dtype=np.float64)
+        self._X_train_ = np.copy(X_train) if self.copy_X_train else X_train
+
+    # ------------------------------------------------------------------ warping API (identity)
+    def warp(self, X):
+        return X
+
+    def unwarp(self, X):
+        return X
+
+    def rewarp(self):
+        pass
+
+    def create_warpers(self, alphas, betas):
+        pass
+
+    @contextmanager
+    def noise_set_to_zero(self):
+        """Context in which kernel_'s white-noise level is 0 WITHOUT recomputing alpha_ / L_ /
+        K_inv_ (``bask/bayesgpr.py:318-336``)."""
+        current_theta = self.theta
+        try:
+            present, white_param = param_for_white_kernel_in_sum(self.kernel_)
+            self.kernel_.set_params(**{white_param: WhiteKernel(noise_level=0.0)})
+            yield self
+        finally:
+            self.kernel_.theta = current_theta
+
+    def _apply_noise_vector(self, n_instances, noise_vector):
+        """``bask/bayesgpr.py:338-349``."""
+        if noise_vector is not None:
+            base = self.alpha if not np.iterable(self.alpha) else self._alpha
+            if np.iterable(base):
+                raise ValueError("alpha passed to the constructor must be a scalar when a noise_vector is used")
+            alpha = np.ones(n_instances) * base
+            alpha[: len(noise_vector)] += noise_vector
+            self.alpha = alpha
+
+    # ------------------------------------------------------------------ log posterior
+    def _log_prob_batch(self, Theta, priors):
+        """Vectorised ``_log_prob_fn`` (``bask/bayesgpr.py:351-379``): sum of priors (host) + LML
+        (device) for a (Ns, p) block; non-finite -> -inf."""
+        Theta = np.atleast_2d(Theta)
+        lp = _eval_priors(priors, Theta)
+        with np.errstate(invalid="ignore"):
+            lp = lp + self._ctx.lml(self._canonical(Theta))
+        lp[~np.isfinite(lp)] = -np.inf
+        return lp
+
+    def _log_prob_fn(self, x, priors, warp_priors=None):
+        return float(self._log_prob_batch(np.asarray(x, dtype=np.float64)[None, :], priors)[0])
+
+    # ------------------------------------------------------------------ sample
+    def sample(
+        self,
+        X=None,
+        y=None,
+        noise_vector=None,
+        n_threads=1,
+        n_desired_samples=100,
+        n_burnin=0,
+        n_thin=1,
+        n_walkers_per_thread=100,
+        progress=False,
+        priors=None,
+        warp_priors=None,
+        position=None,
+        add=False,
+        **kwargs,
+    ):
+        """Sample the hyper-parameter posterior with the ensemble sampler
+        (``bask/bayesgpr.py:381-548``; same arguments and derived quantities)."""
+        if (X is None and self.X_train_ is None) or self.kernel_ is None:
+            raise ValueError(
+                "It looks like you are trying to sample from the GP posterior without data. "
+                "Pass X and y, or ensure that you call fit before sample."
+            )
+        if priors is None:
+            priors = guess_priors(self.kernel_)
+
+        if X is not None:
+            X = np.asarray(X, dtype=np.float64)
+            y = np.asarray(y, dtype=np.float64)
+            if self.normalize_y:
+                self._y_train_mean = np.mean(y, axis=0)
+                self._y_train_std = np.std(y, axis=0)
+            else:
+                self._y_train_mean = np.zeros(1)
+                self._y_train_std = 1
+            self.y_train_std_ = self._y_train_std
+            self.y_train_mean_ = self._y_train_mean
+            y = (y - self.y_train_mean_) / self.y_train_std_
+            if noise_vector is not None:
+                noise_vector = np.array(noise_vector) / np.power(self.y_train_std_, 2)
+            self.X_train_ = X
+            self.y_train_ = np.copy(y) if self.copy_X_train else y
+
+        self._apply_noise_vector(len(self.y_train_), noise_vector)
+
+        n_dim = len(self.theta)
+        n_walkers = n_threads * n_walkers_per_thread
+        n_samples = int(np.ceil(n_desired_samples / n_walkers) + n_burnin)
+        pos = None
+        if position is not None:
+            pos = position
+        elif self.pos_ is not None:
+            pos = self.pos_
+        if pos is None:
+            theta = self.theta
+            theta[np.isinf(theta)] = np.log(self.noise_)
+            pos = [theta + 1e-2 * self.random_state.randn(n_dim) for _ in range(n_walkers)]
+
+        self._ensure_context(batch_hint=(n_walkers + 1) // 2)
+        self._sampler = EnsembleSampler(
+            nwalkers=n_walkers,
+            ndim=n_dim,
+            log_prob_fn=self._log_prob_batch,
+            kwargs=dict(priors=priors),
+            threads=n_threads,
+            **kwargs,
+        )
+        rng = np.random.RandomState(self.random_state.randint(0, np.iinfo(np.int32).max))
+        self._sampler.random_state = rng.get_state()
+        pos, prob, state = self._sampler.run_mcmc(pos, n_samples, progress=progress)
+        chain = self._sampler.get_chain(flat=True, discard=n_burnin, thin=n_thin)
+        if add and self.chain_ is not None:
+            self.chain_ = np.concatenate([self.chain_, chain])
+        else:
+            self.chain_ = chain
+        self.theta = geometric_median(self.chain_)
+        self.log_marginal_likelihood_value_ = self.log_marginal_likelihood(self.kernel_.theta, clone_kernel=False)
+        self.pos_ = pos
+
+    # ------------------------------------------------------------------ fit
+    def fit(
+        self,
+        X,
+        y,
+        noise_vector=None,
+        n_threads=1,
+        n_desired_samples=100,
+        n_burnin=10,
+        n_walkers_per_thread=100,
+        progress=True,
+        priors=None,
+        warp_priors=None,
+        position=None,
+        **kwargs,
+    ):
+        """MAP initialisation (L-BFGS-B on the device LML) followed by ``sample``
+        (``bask/bayesgpr.py:550-620``)."""
+        self.kernel = self._kernel
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        if self.normalize_y and noise_vector is not None:
+            y_std = np.std(y, axis=0)
+            noise_vector = np.array(noise_vector) / np.power(y_std, 2)
+        self._apply_noise_vector(len(y), noise_vector)
+        self._map_fit(X, y)
+        self.sample(
+            n_threads=n_threads,
+            n_desired_samples=n_desired_samples,
+            n_burnin=n_burnin,
+            n_walkers_per_thread=n_walkers_per_thread,
+            progress=progress,
+            priors=priors,
+            warp_priors=warp_priors,
+            position=position,
+            add=False,
+            **kwargs,
+        )
+        return self
+
+    def _map_fit(self, X, y):
+        """skopt GPR.fit -> sklearn GPR.fit restated (module docstring) with device LML/gradient."""
+        if isinstance(self.noise, str) and self.noise != "gaussian":
+            raise ValueError("expected noise to be 'gaussian', got %s" % self.noise)
+        if self.kernel is None:
+            self.kernel = ConstantKernel(1.0, constant_value_bounds="fixed") * _RBF(1.0, length_scale_bounds="fixed")
+        if self.noise and not param_for_white_kernel_in_sum(self.kernel)[0]:
+            if self.noise == "gaussian":
+                self.kernel = self.kernel + WhiteKernel()
+            else:
+                self.kernel = self.kernel + WhiteKernel(noise_level=self.noise, noise_level_bounds="fixed")
+        self.kernel_ = clone(self.kernel)
+
+        if self.normalize_y:
+            self._y_train_mean = np.mean(y, axis=0)
+            std = np.std(y, axis=0)
+            self._y_train_std = 1.0 if std == 0.0 else std  # _handle_zeros_in_scale
+            y = (y - self._y_train_mean) / self._y_train_std
+        else:
+            self._y_train_mean = np.zeros(1)
+            self._y_train_std = np.ones(1)
+        if np.iterable(self.alpha) and np.shape(self.alpha)[0] != y.shape[0]:
+            if np.shape(self.alpha)[0] == 1:
+                self.alpha = self.alpha[0]
+            else:
+                raise ValueError(
+                    "alpha must be a scalar or an array with same number of "
+                    f"entries as y. ({np.shape(self.alpha)[0]} != {y.shape[0]})"
+                )
+        self.X_train_ = X
+        self.y_train_ = np.copy(y) if self.copy_X_train else y
+        self.y_train_std_ = self._y_train_std
+        self.y_train_mean_ = self._y_train_mean
+        self._ensure_context()
+
+        if self.optimizer is not None and self.kernel_.n_dims > 0:
+            def obj(theta):
+                lml, grad = self.log_marginal_likelihood(theta, eval_gradient=True, clone_kernel=False)
+                return -lml, -grad
+
+            optima = [self._constrained_optimization(obj, self.kernel_.theta, self.kernel_.bounds)]
+            if self.n_restarts_optimizer > 0:
+                bounds = self.kernel_.bounds
+                if not np.isfinite(bounds).all():
+                    raise ValueError(
+                        "Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite."
+                    )
+                for _ in range(self.n_restarts_optimizer):
+                    theta_initial = self.random_state.uniform(bounds[:, 0], bounds[:, 1])
+                    optima.append(self._constrained_optimization(obj, theta_initial, bounds))
+            vals = [o[1] for o in optima]
+            self.kernel_.theta = optima[int(np.argmin(vals))][0]
+            self.log_marginal_likelihood_value_ = -np.min(vals)
+        else:
+            self.log_marginal_likelihood_value_ = self.log_marginal_likelihood(self.kernel_.theta)
+
+        # factors built WITH the fitted noise ...
+        self._build_posterior(self.kernel_.theta)
+        # ... then kernel_'s WhiteKernel is zeroed (skopt's post-fit step)
+        self.noise_ = None
+        if self.noise:
+            if isinstance(self.kernel_, WhiteKernel):
+                self.kernel_.set_params(noise_level=0.0)
+            else:
+                present, white_param = param_for_white_kernel_in_sum(self.kernel_)
+                if present:
+                    self.noise_ = self.kernel_.get_params()[white_param].noise_level
+                    self.kernel_.set_params(**{white_param: WhiteKernel(noise_level=0.0)})
+
+    def _constrained_optimization(self, obj_func, initial_theta, bounds):
+        if self.optimizer == "fmin_l_bfgs_b":
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                res = scipy.optimize.minimize(obj_func, initial_theta, method="L-BFGS-B", jac=True, bounds=bounds)
+            return res.x, res.fun
+        if callable(self.optimizer):
+            return self.optimizer(obj_func, initial_theta, bounds=bounds)
+        raise ValueError(f"Unknown optimizer {self.optimizer}.")
+
+    # ------------------------------------------------------------------ predict
+    def _kernel_theta_for_predict(self):
+        with np.errstate(divide="ignore"):
+            return np.copy(self.kernel_.theta)
+
+    def predict(self, X, return_std=False, return_cov=False, return_mean_grad=False, return_std_grad=False):
+        """Predictive mean [, std | cov] (``bask/bayesgpr.py:622-635`` -> skopt predict)."""
+        if return_std and return_cov:
+            raise RuntimeError("Not returning standard deviation of predictions when returning full covariance.")
+        if return_mean_grad or return_std_grad:
+            raise NotImplementedError("prediction gradients are not implemented on the MI355X path")
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if self._post_theta is None or self.X_train_ is None:
+            raise RuntimeError("predict before fit is not supported on the MI355X path")
+        self._make_resident()
+        Hk = self._canonical(self._kernel_theta_for_predict())
+        if return_cov:
+            mean, var, cov = self._ctx.predict(Hk, X, return_cov=True)
+            y_mean = self.y_train_std_ * mean[0] + self.y_train_mean_
+            return y_mean, cov[0] * self.y_train_std_**2
+        mean, var = self._ctx.predict(Hk, X)
+        y_mean = self.y_train_std_ * mean[0] + self.y_train_mean_
+        if return_std:
+            return y_mean, np.sqrt(var[0] * self.y_train_std_**2)
+        return y_mean
+
+    def _make_resident(self):
+        """Make sure the device holds the posterior that alpha_/L_/K_inv_ describe."""
+        H = self._canonical(self._post_theta)
+        res = self._ctx.resident_H
+        if res is None or res.shape[0] < 1 or not np.array_equal(res[0], H[0]):
+            self._ctx.posterior(H, want_alpha=False)
+
+    def sample_y(self, X, sample_mean=False, noise=False, n_samples=1, random_state=0):
+        """Function realisations of the GP(s) (``bask/bayesgpr.py:637-718``).  The multivariate
+        normal draw uses a device Cholesky factor of the predictive covariance instead of numpy's
+        SVD (``sklearn/_gpr.py:522-526``): same distribution, different variates."""
+        rng = check_random_state(random_state)
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if sample_mean:
+            cm = nullcontext(self) if noise else self.noise_set_to_zero()
+            with cm:
+                return self._draw(X, n_samples, rng)
+        ind = rng.choice(len(self.chain_), size=n_samples, replace=True)
+        current_theta = self.theta
+        saved = (self._post_theta, self.alpha_, self._L, self._K_inv)
+        result = np.empty((X.shape[0], n_samples))
+        for i, j in enumerate(ind):
+            self.theta = self.chain_[j]
+            cm = nullcontext(self) if noise else self.noise_set_to_zero()
+            with cm:
+                result[:, i] = self._draw(X, 1, rng).flatten()
+        self.kernel_.theta = current_theta
+        self._post_theta, self.alpha_, self._L, self._K_inv = saved
+        return result
+
+    def _draw(self, X, n_samples, rng):
+        self._make_resident()
+        Hk = self._canonical(self._kernel_theta_for_predict())
+        z = rng.standard_normal((n_samples, X.shape[0]))
+        jitter = 1e-10
+        while True:
+            try:
+                out = self._ctx.sample_y(0, Hk, X, z, jitter=jitter)
+                break
+            except _lib.NotPositiveDefinite:
+                # numpy's SVD-based draw tolerates a numerically semi-definite covariance; the
+                # Cholesky-based draw needs a growing diagonal jitter instead
+                jitter *= 100.0
+                if jitter > 1e-2:
+                    raise
+        return (self.y_train_std_ * out + self.y_train_mean_).T
+
+    def __del__(self):
+        ctx = getattr(self, "_ctx", None)
+        if ctx is not None:
+            try:
+                ctx.close()
+            except Exception:
+                pass
+
+
+def _eval_priors(priors, Theta):
+    """Sum of log-priors for a (Ns, p) block.  A list holds one callable per hyper-parameter
+    (``bask/bayesgpr.py:368-370``), evaluated column-wise when the callable broadcasts and
+    element-wise otherwise; a single callable receives each full parameter vector (:371-372)."""
+    Ns, p = Theta.shape
+    if callable(priors):
+        return np.array([float(priors(row)) for row in Theta])
+    priors = list(priors)
+    if len(priors) != p:
+        raise ValueError(f"zip() argument 2 is {'shorter' if p < len(priors) else 'longer'} than argument 1: "
+                         f"{len(priors)} priors for {p} hyper-parameters")
+    lp = np.zeros(Ns)
+    for k, prior in enumerate(priors):
+        col = Theta[:, k]
+        vals = None
+        try:
+            with np.errstate(all="ignore"):
+                v = np.asarray(prior(col), dtype=np.float64)
+            if v.shape == (Ns,):
+                vals = v
+        except Exception:
+            vals = None
+        if vals is None:
+            with np.errstate(all="ignore"):
+                vals = np.array([float(prior(t)) for t in col])
+        lp += vals
+    return lp

@@ -48,21 +48,38 @@ static int alloc_work(bgp_ctx* c) {
   const size_t npad = c->npad, nblk = c->nblk, mb = c->max_batch;
   const size_t need_mat = mb * npad * npad;
   const size_t need_w = mb * nblk * 128 * 128;
+  const size_t need_yw = mb * 2 * npad;  // augmented right-hand sides are 2 npad long
   if (need_mat > c->cap_mat) {
     free_dev(c->dK);
     c->dK = nullptr;
+    c->cap_mat = 0;
     BGP_HIP(hipMalloc(&c->dK, need_mat * sizeof(double)));
     c->cap_mat = need_mat;
   }
   if (need_w > c->cap_w) {
     free_dev(c->dW);
-    free_dev(c->dyw);
-    free_dev(c->dalpha_sol);
-    c->dW = c->dyw = c->dalpha_sol = nullptr;
+    c->dW = nullptr;
+    c->cap_w = 0;
     BGP_HIP(hipMalloc(&c->dW, need_w * sizeof(double)));
-    BGP_HIP(hipMalloc(&c->dyw, mb * npad * sizeof(double)));
-    BGP_HIP(hipMalloc(&c->dalpha_sol, mb * npad * sizeof(double)));
     c->cap_w = need_w;
+  }
+  if (need_yw > c->cap_yw) {
+    free_dev(c->dyw);
+    c->dyw = nullptr;
+    c->cap_yw = 0;
+    BGP_HIP(hipMalloc(&c->dyw, need_yw * sizeof(double)));
+    c->cap_yw = need_yw;
+  }
+  return BGP_OK;
+}
+
+int bgp_grow_workspace(bgp_ctx* c, size_t doubles) {
+  if (doubles > c->cap_mat) {
+    free_dev(c->dK);
+    c->dK = nullptr;
+    c->cap_mat = 0;
+    BGP_HIP(hipMalloc(&c->dK, doubles * sizeof(double)));
+    c->cap_mat = doubles;
   }
   return BGP_OK;
 }
@@ -170,6 +187,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dlml);
   free_dev(c->dstatus);
   free_dev(c->dalpha_sol);
+  free_dev(c->dKinv);
   free_dev(c->dscratch);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -191,7 +209,7 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
   const size_t p = c->d + 2;
   BGP_HIP(hipMemcpyAsync(c->dh, h, B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemsetAsync(c->dstatus, 0, B * sizeof(int), c->stream));
-  int rc = bgp_launch_kbuild(c, B, full_square);
+  int rc = bgp_launch_kbuild(c, B, full_square, 0, 1);
   if (rc) return rc;
   return BGP_OK;
 }
@@ -206,7 +224,6 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
   const size_t p = c->d + 2;
   for (int k = 0; k < 5; k++) c->t_ms[k] = 0.0;
   for (int k = 0; k < 4; k++) c->t_cnt[k] = 0;
-  c->post_B = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   for (int off = 0; off < B; off += c->max_batch) {
     const int nb = std::min(c->max_batch, B - off);
@@ -217,7 +234,7 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
     }
     int rc = factor_chunk(c, nb, h + (size_t)off * p, 0);
     if (rc) return rc;
-    rc = bgp_launch_cholesky(c, nb);
+    rc = bgp_launch_cholesky(c, nb, 0);
     if (rc) return rc;
     BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (status) {
@@ -243,7 +260,6 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
     return BGP_ERR_INVALID;
   }
   BGP_HIP(hipSetDevice(c->device));
-  c->post_B = 0;
   int rc = factor_chunk(c, 1, h, 1);
   if (rc) return rc;
   BGP_HIP(hipMemcpy2DAsync(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),

@@ -20,63 +20,7 @@
 #include "bgp_common.h"
 #include "bgp_device.h"
 
-#define GK_KC 32
-#define GK_LD 34
-
-struct __attribute__((aligned(16))) GemmSmem {
-  double A[128 * GK_LD];
-  double B[128 * GK_LD];
-  double ypart[128];
-};
-
-// 128 x 32 chunk of a row-major matrix (leading dimension ld) -> LDS tile [128][GK_LD].
-static __device__ __forceinline__ void gk_load_chunk(double* __restrict__ dst, const double* __restrict__ src,
-                                                     size_t ld, int tid) {
-  d2 v[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int c = tid + 256 * i;
-    const int row = c >> 4, seg = c & 15;
-    v[i] = *reinterpret_cast<const d2*>(src + (size_t)row * ld + seg * 2);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const int c = tid + 256 * i;
-    const int row = c >> 4, seg = c & 15;
-    *reinterpret_cast<d2*>(dst + row * GK_LD + seg * 2) = v[i];
-  }
-}
-
-// acc[i][j] (+)= sum_k A[64wr+16i+.. ][k] * B[64wc+16j+..][k] over one 32-wide chunk.
-// MFMA operand layout (cdna_hip_programming.md section 3): A operand lane l = A[l&15][l>>4],
-// B operand lane l = B[k=l>>4][j=l&15] = Bmat[l&15][l>>4]: both read [row = l&15][k = l>>4].
-// TRI != 0: the B matrix is lower triangular (W_kk): column block j only needs k <= its last column.
-template <int NEG, int TRI>
-static __device__ __forceinline__ void gk_mma_chunk(const double* __restrict__ As, const double* __restrict__ Bs,
-                                                    d4 (&acc)[4][4], int wr, int wc, int lane, int k0) {
-  const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-  for (int kk = 0; kk < GK_KC / 4; kk++) {
-    double a[4], b[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      double av = As[(wr * 64 + i * 16 + lr) * GK_LD + kk * 4 + lk];
-      a[i] = NEG ? -av : av;
-      b[i] = Bs[(wc * 64 + i * 16 + lr) * GK_LD + kk * 4 + lk];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (TRI && (k0 + kk * 4 > wc * 64 + j * 16 + 15)) continue;  // wave-uniform
-#pragma unroll
-      for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  }
-}
-
-// C/D fragment layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
-// (cdna_hip_programming.md:247-251; verified at run time by bgp_mfma_f64_layout + tests).
-#define GK_ROW(wr, i, lane, r) ((wr) * 64 + (i) * 16 + ((lane) >> 4) + 4 * (r))
-#define GK_COL(wc, j, lane) ((wc) * 64 + (j) * 16 + ((lane) & 15))
+#include "bgp_gemm.h"
 
 // ------------------------------------------------------------------------------------------
 // potrf: diagonal block k of every walker.
@@ -84,17 +28,17 @@ static __device__ __forceinline__ void gk_mma_chunk(const double* __restrict__ A
 __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                      double* __restrict__ yw, double* __restrict__ accb,
                                                      double* __restrict__ lml, int* __restrict__ status, int n,
-                                                     int npad, int nblk, int k) {
+                                                     int ld, size_t mstride, int ystride, int nblk, int k) {
   const int b = blockIdx.x;
   if (status[b] != 0) return;
   __shared__ double s[128 * BGP_TILE_LD];
   __shared__ double red[256];
   const int tid = threadIdx.x;
-  double* T = Kbuf + (size_t)b * npad * npad + (size_t)(k * 128) * npad + k * 128;
+  double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
 
   for (int idx = tid; idx < 128 * 64; idx += 256) {
     const int row = idx >> 6, seg = idx & 63;
-    d2 v = *reinterpret_cast<const d2*>(T + (size_t)row * npad + seg * 2);
+    d2 v = *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2);
     s[row * BGP_TILE_LD + seg * 2] = v.x;
     s[row * BGP_TILE_LD + seg * 2 + 1] = v.y;
   }
@@ -137,7 +81,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   red[tid] = (hh == 0) ? log(s[i * BGP_TILE_LD + i]) : 0.0;
   for (int idx = tid; idx < 128 * 128; idx += 256) {
     const int row = idx >> 7, col = idx & 127;
-    T[(size_t)row * npad + col] = (col <= row) ? s[row * BGP_TILE_LD + col] : 0.0;
+    T[(size_t)row * ld + col] = (col <= row) ? s[row * BGP_TILE_LD + col] : 0.0;
   }
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) {
@@ -172,7 +116,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     W[idx] = (col <= row) ? s[row * BGP_TILE_LD + col] : 0.0;
   }
   // z_k = W_kk y_k
-  double* yk = yw + (size_t)b * npad + k * 128;
+  double* yk = yw + (size_t)b * ystride + k * 128;
   if (hh == 0) red[i] = yk[i];
   __syncthreads();
   double z = 0.0;
@@ -202,17 +146,26 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
 // ------------------------------------------------------------------------------------------
 // trsm: X_i = A_ik W_kk^T for every row block i > k, then y_i -= X_i z_k.
 // ------------------------------------------------------------------------------------------
+// Active row blocks below the diagonal at step k: the nlow = nblk-k-1 remaining blocks of K, then
+// (posterior builds only) the first k+1 block rows of the identity part of the augmented matrix
+// [[K, .], [I, 0]], which starts at block row `aug`.  Running the same three kernels on the
+// augmented matrix for nblk steps leaves L (top-left), L^-T (bottom-left), the Schur complement
+// -K^-1 (bottom-right) and -alpha = -(K^-1 y) in the lower half of the working right-hand side.
+static __device__ __forceinline__ int bgp_rowblk(int t, int k, int nlow, int aug) {
+  return (t < nlow) ? (k + 1 + t) : (aug + (t - nlow));
+}
+
 __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf,
                                                     double* __restrict__ yw, const int* __restrict__ status,
-                                                    int npad, int nblk, int k, int B) {
-  const int nrb = nblk - k - 1;
+                                                    int ld, size_t mstride, int ystride, int nblk, int k, int nact,
+                                                    int aug, int B) {
   int b, t;
-  bgp_map_block(blockIdx.x, nrb, b, t);
+  bgp_map_block(blockIdx.x, nact, b, t);
   if (b >= B || status[b] != 0) return;
   __shared__ GemmSmem sm;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-  const int ib = k + 1 + t;
-  double* Atile = Kbuf + (size_t)b * npad * npad + (size_t)(ib * 128) * npad + k * 128;
+  const int ib = bgp_rowblk(t, k, nblk - k - 1, aug);
+  double* Atile = Kbuf + (size_t)b * mstride + (size_t)(ib * 128) * ld + k * 128;
   const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
 
   d4 acc[4][4];
@@ -224,14 +177,14 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
 
   for (int k0 = 0; k0 < 128; k0 += GK_KC) {
     __syncthreads();
-    gk_load_chunk(sm.A, Atile + k0, (size_t)npad, tid);
+    gk_load_chunk(sm.A, Atile + k0, (size_t)ld, tid);
     gk_load_chunk(sm.B, W + k0, (size_t)128, tid);
     __syncthreads();
     gk_mma_chunk<0, 1>(sm.A, sm.B, acc, wr, wc, lane, k0);
   }
   // In-place overwrite is safe: every global read of this A tile was staged into LDS before the
   // last chunk's barrier, and no other workgroup touches the tile in this launch.
-  const double* zk = yw + (size_t)b * npad + k * 128;
+  const double* zk = yw + (size_t)b * ystride + k * 128;
   double zc[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) zc[j] = zk[GK_COL(wc, j, lane)];
@@ -244,7 +197,7 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const double x = acc[i][j][r];
-        Atile[(size_t)row * npad + GK_COL(wc, j, lane)] = x;
+        Atile[(size_t)row * ld + GK_COL(wc, j, lane)] = x;
         part += x * zc[j];
       }
       // reduce over the 16 lanes that share this row (lane & 15 varies)
@@ -256,28 +209,28 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
     }
   }
   __syncthreads();
-  if (tid < 128) yw[(size_t)b * npad + ib * 128 + tid] -= sm.ypart[tid];
+  if (tid < 128) yw[(size_t)b * ystride + ib * 128 + tid] -= sm.ypart[tid];
 }
 
 // ------------------------------------------------------------------------------------------
 // syrk: trailing update A_ij -= X_i X_j^T for k < j <= i.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) syrk_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
-                                                    int npad, int nblk, int k, int B) {
-  const int ntr = nblk - k - 1;
-  const int ntile = ntr * (ntr + 1) / 2;
+                                                    int ld, size_t mstride, int nblk, int k, int nact, int aug,
+                                                    int B) {
+  const int ntile = nact * (nact + 1) / 2;
   int b, t;
   bgp_map_block(blockIdx.x, ntile, b, t);
   if (b >= B || status[b] != 0) return;
   int ti, tj;
   bgp_tri_decode(t, ti, tj);
-  const int I = k + 1 + ti, J = k + 1 + tj;
+  const int I = bgp_rowblk(ti, k, nblk - k - 1, aug), J = bgp_rowblk(tj, k, nblk - k - 1, aug);
   __shared__ GemmSmem sm;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-  double* M = Kbuf + (size_t)b * npad * npad;
-  const double* XI = M + (size_t)(I * 128) * npad + k * 128;
-  const double* XJ = M + (size_t)(J * 128) * npad + k * 128;
-  double* C = M + (size_t)(I * 128) * npad + J * 128;
+  double* M = Kbuf + (size_t)b * mstride;
+  const double* XI = M + (size_t)(I * 128) * ld + k * 128;
+  const double* XJ = M + (size_t)(J * 128) * ld + k * 128;
+  double* C = M + (size_t)(I * 128) * ld + J * 128;
 
   d4 acc[4][4];
 #pragma unroll
@@ -285,13 +238,13 @@ __global__ void __launch_bounds__(256) syrk_kernel(double* __restrict__ Kbuf, co
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) acc[i][j][r] = C[(size_t)GK_ROW(wr, i, lane, r) * npad + GK_COL(wc, j, lane)];
+      for (int r = 0; r < 4; r++) acc[i][j][r] = C[(size_t)GK_ROW(wr, i, lane, r) * ld + GK_COL(wc, j, lane)];
 
   const bool diag = (I == J);
   for (int k0 = 0; k0 < 128; k0 += GK_KC) {
     __syncthreads();
-    gk_load_chunk(sm.A, XI + k0, (size_t)npad, tid);
-    if (!diag) gk_load_chunk(sm.B, XJ + k0, (size_t)npad, tid);
+    gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+    if (!diag) gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
     __syncthreads();
     gk_mma_chunk<1, 0>(sm.A, diag ? sm.A : sm.B, acc, wr, wc, lane, k0);
   }
@@ -300,27 +253,33 @@ __global__ void __launch_bounds__(256) syrk_kernel(double* __restrict__ Kbuf, co
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) C[(size_t)GK_ROW(wr, i, lane, r) * npad + GK_COL(wc, j, lane)] = acc[i][j][r];
+      for (int r = 0; r < 4; r++) C[(size_t)GK_ROW(wr, i, lane, r) * ld + GK_COL(wc, j, lane)] = acc[i][j][r];
 }
 
 // ------------------------------------------------------------------------------------------
-int bgp_launch_cholesky(bgp_ctx* ctx, int B) {
+int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
+  // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
+  // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
+  const int ld = augmented ? 2 * npad : npad;
+  const size_t mstride = (size_t)ld * ld;
+  const int ystride = ld;
   const int B8 = 8 * ((B + 7) / 8);
   for (int k = 0; k < nblk; k++) {
     bgp_tbegin(ctx, 1);
     hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, ctx->stream, ctx->dK, ctx->dW, ctx->dyw, ctx->dacc,
-                       ctx->dlml, ctx->dstatus, ctx->n, npad, nblk, k);
+                       ctx->dlml, ctx->dstatus, ctx->n, ld, mstride, ystride, nblk, k);
     bgp_tend(ctx);
-    const int ntr = nblk - k - 1;
-    if (ntr > 0) {
+    const int nlow = nblk - k - 1;
+    const int nact = augmented ? nblk : nlow;
+    if (nact > 0) {
       bgp_tbegin(ctx, 2);
-      hipLaunchKernelGGL(trsm_kernel, dim3(B8 * ntr), dim3(256), 0, ctx->stream, ctx->dK, ctx->dW, ctx->dyw,
-                         ctx->dstatus, npad, nblk, k, B);
+      hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, ctx->stream, ctx->dK, ctx->dW, ctx->dyw,
+                         ctx->dstatus, ld, mstride, ystride, nblk, k, nact, nblk, B);
       bgp_tend(ctx);
       bgp_tbegin(ctx, 3);
-      hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (ntr * (ntr + 1) / 2)), dim3(256), 0, ctx->stream, ctx->dK,
-                         ctx->dstatus, npad, nblk, k, B);
+      hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, ctx->stream, ctx->dK,
+                         ctx->dstatus, ld, mstride, nblk, k, nact, nblk, B);
       bgp_tend(ctx);
     }
   }

@@ -48,9 +48,13 @@ struct bgp_ctx {
   double* dh = nullptr;      // max_batch * (d+2)       canonical hyper-parameters
   double* dlml = nullptr;    // max_batch
   int* dstatus = nullptr;    // max_batch
-  double* dalpha_sol = nullptr;  // max_batch * npad    K^-1 y of the resident posteriors
   size_t cap_mat = 0;        // capacity in doubles of dK
   size_t cap_w = 0;
+  size_t cap_yw = 0;
+  // resident posteriors (K^-1 full symmetric npad x npad each, alpha = K^-1 y)
+  double* dKinv = nullptr;
+  double* dalpha_sol = nullptr;
+  size_t cap_kinv = 0;
   // resident posterior state
   int post_B = 0;            // number of resident posteriors (0 = none)
   std::vector<double> post_h;
@@ -97,12 +101,17 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 }
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
+// make the matrix workspace at least `doubles` large (and the per-item side buffers consistent)
+int bgp_grow_workspace(bgp_ctx* ctx, size_t doubles);
+// posterior build on the augmented matrices; use_alpha == 0 drops alpha_diag (PVRS quirk)
+int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, double* L, double* alpha, double* K_inv,
+                        double* lml, int* status);
 
 // ---- kernels launched across translation units ----
 // K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).
-int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square);
+int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha);
 // Cross kernel matrix k(Xq, X_train) for hyper-vector index b: out is m x ldo row-major (device).
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int symmetric_diag_fix);
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
-int bgp_launch_cholesky(bgp_ctx* ctx, int B);
+int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);

@@ -76,7 +76,8 @@ __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na
       } else if (GRAM && gi == gj) {
         // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
         double base = (form == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
-        v = (base + s2) + alpha[gi];
+        v = (base + s2);
+        if (alpha) v += alpha[gi];
       } else {
         double s = bgp_stationary(acc[r][c], stat);
         v = (form == BGP_FORM_PRODUCT) ? cst * s : cst + s;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
                                                            const double* __restrict__ H, double* __restrict__ Kbuf,
                                                            const double* __restrict__ y, double* __restrict__ yw,
                                                            int n, int d, int npad, int nblk, int form, int stat,
-                                                           int B, int full) {
+                                                           int B, int full, int ld, int use_alpha) {
   const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
   int b, t;
   bgp_map_block(blockIdx.x, ntiles, b, t);
@@ -104,10 +105,12 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
     bgp_tri_decode(t, ti, tj);
   }
   const double* h = H + (size_t)b * (d + 2);
-  double* out = Kbuf + (size_t)b * npad * npad;
+  // ld == npad for LML batches, 2*npad for the augmented matrices of posterior builds
+  double* out = Kbuf + (size_t)b * ld * ld;
   // working right-hand side of walker b (becomes z = L^-1 y during the factorisation)
-  if (ti == tj && threadIdx.x < 128) yw[(size_t)b * npad + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
-  kbuild_tile<1>(X, n, X, n, d, h, alpha, form, stat, ti * 128, tj * 128, out, (size_t)npad, npad, npad);
+  if (ti == tj && threadIdx.x < 128) yw[(size_t)b * ld + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
+  kbuild_tile<1>(X, n, X, n, d, h, use_alpha ? alpha : nullptr, form, stat, ti * 128, tj * 128, out, (size_t)ld,
+                 npad, npad);
 }
 
 __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restrict__ Xq, int m,
@@ -118,13 +121,14 @@ __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restr
   kbuild_tile<0>(Xq, m, Xt, n, d, h, nullptr, form, stat, ti * 128, tj * 128, out, (size_t)ldo, m, n);
 }
 
-int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square) {
+int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
   const int nblk = ctx->nblk;
   const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
   bgp_tbegin(ctx, 0);
   hipLaunchKernelGGL(kbuild_gram_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dX, ctx->dalpha, ctx->dh,
-                     ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, ctx->ks.form, ctx->ks.stationary, B, full_square);
+                     ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, ctx->ks.form, ctx->ks.stationary, B, full_square,
+                     augmented ? 2 * ctx->npad : ctx->npad, use_alpha);
   bgp_tend(ctx);
   BGP_HIP(hipGetLastError());
   return BGP_OK;

@@ -1,0 +1,213 @@
+"""Kernel objects on the host and their mapping to the device's canonical hyper-parameter vector.
+
+The reference builds its GP kernels from skopt's kernel classes, which are scikit-learn's kernels
+plus ``gradient_x`` (``bask/utils.py:6``, ``bask/bayesgpr.py:12``); scikit-learn ships in the image,
+skopt does not, so the host-side kernel *objects* (theta get/set in log space, bounds,
+``clone_with_theta``; ``sklearn/kernels.py:285-338, 733-760``) are scikit-learn's.  No kernel
+*arithmetic* runs on the host: a kernel expression tree is analysed once into a ``KernelPlan`` that
+maps its ``theta`` to the canonical device vector ``h = [log c, log l_1..log l_d, log s2]``
+(``include/bgp.h``), and every K(X, X) / K(X*, X) is evaluated by the HIP kernels.
+
+Supported expression trees (anything else raises ``NotImplementedError`` -- there is no CPU path):
+    [ConstantKernel *] S(length_scale) [+ WhiteKernel]        form "product"
+    [ConstantKernel +] S(length_scale) [+ WhiteKernel]        form "sum"
+with S in {RBF, Matern(nu = 0.5 | 1.5 | 2.5)}, isotropic or anisotropic, in any operand order, any
+hyper-parameter optionally "fixed".
+"""
+import numpy as np
+from sklearn.gaussian_process.kernels import (  # noqa: F401  (re-exported: the bask kernel vocabulary)
+    RBF,
+    ConstantKernel,
+    Kernel,
+    Matern,
+    Product,
+    Sum,
+    WhiteKernel,
+)
+
+__all__ = ["RBF", "ConstantKernel", "Matern", "WhiteKernel", "Sum", "Product", "KernelPlan", "analyse_kernel",
+           "param_for_white_kernel_in_sum"]
+
+
+def param_for_white_kernel_in_sum(kernel, kernel_str=""):
+    """Locate a WhiteKernel inside (nested) Sum kernels; returns (present, param_name).
+
+    Same contract as skopt's ``_param_for_white_kernel_in_Sum`` imported at
+    ``bask/bayesgpr.py:9-11`` and used at ``:328-333``.
+    """
+    if kernel_str != "":
+        kernel_str = kernel_str + "__"
+    if isinstance(kernel, Sum):
+        for param, child in kernel.get_params(deep=False).items():
+            if isinstance(child, WhiteKernel):
+                return True, kernel_str + param
+            present, child_str = param_for_white_kernel_in_sum(child, kernel_str + param)
+            if present:
+                return True, child_str
+    return False, "_"
+
+
+def _stationary_name(k):
+    if isinstance(k, Matern):  # NB: sklearn's Matern subclasses RBF -- test it first
+        nu = float(k.nu)
+        for val, name in ((0.5, "matern12"), (1.5, "matern32"), (2.5, "matern52")):
+            if nu == val:
+                return name
+        if np.isinf(nu):
+            return "rbf"
+        raise NotImplementedError(f"Matern nu={nu} has no device kernel (supported: 0.5, 1.5, 2.5, inf)")
+    if isinstance(k, RBF):
+        return "rbf"
+    return None
+
+
+class _Leaf:
+    __slots__ = ("kind", "kernel", "theta_index", "n_free")
+
+    def __init__(self, kind, kernel, theta_index, n_free):
+        self.kind, self.kernel, self.theta_index, self.n_free = kind, kernel, theta_index, n_free
+
+
+class KernelPlan:
+    """theta (p,) of one kernel expression tree  <->  canonical h (d+2,)."""
+
+    def __init__(self, form, stationary, const, ell, white, n_theta, ard):
+        self.form = form  # "product" | "sum"
+        self.stationary = stationary
+        # each of const / white: ("free", theta_index) | ("fixed", log_value) | ("absent", log_value)
+        # ell: ("free", [theta indices]) | ("fixed", log_values array)
+        self.const, self.ell, self.white = const, ell, white
+        self.n_theta = n_theta
+        self.ard = ard
+
+    def canonical(self, theta, d):
+        """(B, p) or (p,) theta -> (B, d+2) canonical vectors."""
+        T = np.atleast_2d(np.asarray(theta, dtype=np.float64))
+        if T.shape[1] != self.n_theta:
+            raise ValueError(f"theta has {T.shape[1]} entries, kernel has {self.n_theta} free hyper-parameters")
+        B = T.shape[0]
+        H = np.empty((B, d + 2))
+        kind, v = self.const
+        H[:, 0] = T[:, v] if kind == "free" else v
+        kind, v = self.ell
+        if kind == "free":
+            if len(v) == 1:
+                H[:, 1 : d + 1] = T[:, v[0]][:, None]
+            else:
+                if len(v) != d:
+                    raise ValueError(f"anisotropic length scale has {len(v)} entries but X has {d} columns")
+                H[:, 1 : d + 1] = T[:, v]
+        else:
+            v = np.asarray(v, dtype=np.float64)
+            if v.size not in (1, d):
+                raise ValueError(f"anisotropic length scale has {v.size} entries but X has {d} columns")
+            H[:, 1 : d + 1] = v
+        kind, v = self.white
+        H[:, d + 1] = T[:, v] if kind == "free" else v
+        return H
+
+    def grad_to_theta(self, G, d):
+        """Chain rule: dLML/dh (B, d+2) -> dLML/dtheta (B, p) (fixed entries dropped, isotropic
+        length scale = sum over the replicated columns)."""
+        G = np.atleast_2d(G)
+        out = np.zeros((G.shape[0], self.n_theta))
+        if self.const[0] == "free":
+            out[:, self.const[1]] += G[:, 0]
+        if self.ell[0] == "free":
+            idx = self.ell[1]
+            if len(idx) == 1:
+                out[:, idx[0]] += G[:, 1 : d + 1].sum(axis=1)
+            else:
+                out[:, idx] += G[:, 1 : d + 1]
+        if self.white[0] == "free":
+            out[:, self.white[1]] += G[:, d + 1]
+        return out
+
+
+def _flatten(kernel, cls):
+    if isinstance(kernel, cls):
+        return _flatten(kernel.k1, cls) + _flatten(kernel.k2, cls)
+    return [kernel]
+
+
+def _leaves_in_theta_order(kernel, start=0):
+    """Leaves of the tree in ``KernelOperator.theta`` order (k1 then k2, kernels.py:747) with the
+    index of their first free hyper-parameter in theta."""
+    if isinstance(kernel, (Sum, Product)):
+        left, nxt = _leaves_in_theta_order(kernel.k1, start)
+        right, nxt = _leaves_in_theta_order(kernel.k2, nxt)
+        return left + right, nxt
+    n_free = int(kernel.n_dims)
+    return [(kernel, start, n_free)], start + n_free
+
+
+def analyse_kernel(kernel):
+    """Analyse a kernel expression tree into a KernelPlan (raises NotImplementedError if the tree
+    is not one of the canonical forms)."""
+    if not isinstance(kernel, Kernel):
+        raise TypeError(f"expected a scikit-learn kernel object, got {type(kernel)}")
+    leaves, n_theta = _leaves_in_theta_order(kernel)
+    index_of = {id(k): (i0, nf) for k, i0, nf in leaves}
+
+    def slot(k):
+        i0, nf = index_of[id(k)]
+        return i0, nf
+
+    terms = _flatten(kernel, Sum)
+    white = ("absent", -np.inf)
+    const_add = None
+    stat_term = None
+    for t in terms:
+        if isinstance(t, WhiteKernel):
+            if white[0] != "absent":
+                raise NotImplementedError("more than one WhiteKernel in the kernel")
+            i0, nf = slot(t)
+            white = ("free", i0) if nf == 1 else ("fixed", float(np.log(t.noise_level)) if t.noise_level > 0 else -np.inf)
+        elif isinstance(t, ConstantKernel):
+            if const_add is not None:
+                raise NotImplementedError("more than one additive ConstantKernel")
+            const_add = t
+        else:
+            if stat_term is not None:
+                raise NotImplementedError(f"more than one non-constant term in the sum: {kernel}")
+            stat_term = t
+    if stat_term is None:
+        raise NotImplementedError(f"kernel has no stationary (RBF/Matern) component: {kernel}")
+
+    factors = _flatten(stat_term, Product)
+    const_mul = None
+    stat = None
+    for f in factors:
+        if isinstance(f, ConstantKernel):
+            if const_mul is not None:
+                raise NotImplementedError("more than one multiplicative ConstantKernel")
+            const_mul = f
+        elif _stationary_name(f) is not None:
+            if stat is not None:
+                raise NotImplementedError("product of two stationary kernels is not supported")
+            stat = f
+        else:
+            raise NotImplementedError(f"unsupported kernel component {type(f).__name__} in {kernel}")
+    if stat is None:
+        raise NotImplementedError(f"kernel has no stationary (RBF/Matern) component: {kernel}")
+    if const_mul is not None and const_add is not None:
+        raise NotImplementedError("kernel with both a multiplicative and an additive constant is not supported")
+
+    def const_slot(ck):
+        i0, nf = slot(ck)
+        return ("free", i0) if nf == 1 else ("fixed", float(np.log(ck.constant_value)))
+
+    if const_add is not None:
+        form, const = "sum", const_slot(const_add)
+    elif const_mul is not None:
+        form, const = "product", const_slot(const_mul)
+    else:
+        form, const = "product", ("absent", 0.0)  # c = 1
+
+    i0, nf = slot(stat)
+    ard = bool(stat.anisotropic)
+    if nf > 0:
+        ell = ("free", list(range(i0, i0 + nf)))
+    else:
+        ell = ("fixed", np.log(np.atleast_1d(np.asarray(stat.length_scale, dtype=np.float64))))
+    return KernelPlan(form, _stationary_name(stat), const, ell, white, n_theta, ard)

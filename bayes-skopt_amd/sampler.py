@@ -1,0 +1,190 @@
+"""Affine-invariant ensemble sampler (Goodman & Weare stretch move, red-blue split) -- the host
+driver of the MCMC loop, written from scratch.
+
+The reference constructs ``emcee.EnsembleSampler`` (3.1.6, absent from this image) at
+``bask/bayesgpr.py:510-517``, seeds it at ``:518-521``, runs it at ``:522-524`` and reads the chain
+at ``:528-530``.  This class keeps that interface (``run_mcmc``, ``get_chain``, ``random_state``
+setter, ``acceptance_fraction``) and consumes the numpy ``RandomState`` in emcee's published
+order: per step one move-selection draw and a shuffle of the red/blue
+labels; per half-step ``rand(Ns)`` (stretch factors), ``randint(Nc, size=Ns)`` (partners) and Ns
+uniform draws (accept tests).
+
+What is MI355X-specific: ``log_prob_fn`` is called ONCE per half-step with the whole (Ns, ndim)
+block of proposals -- the data-parallel axis of the hot path -- so that all Ns
+kernel-matrix builds + Cholesky factorisations of a half-step run as one batch on the GPU.  The
+accept/reject bookkeeping (O(W) scalar work per half-step) stays on the host.
+"""
+import numpy as np
+
+__all__ = ["EnsembleSampler", "walkers_independent"]
+
+
+def walkers_independent(coords):
+    """True when the ensemble spans the parameter space: finite, non-degenerate columns, and a
+    condition number of the centred/normalised ensemble <= 1e8 (emcee's initial-state check)."""
+    coords = np.asarray(coords, dtype=np.float64)
+    if not np.all(np.isfinite(coords)):
+        return False
+    C = coords - coords.mean(axis=0)[None, :]
+    colmax = np.abs(C).max(axis=0)
+    if np.any(colmax == 0):
+        return False
+    C = C / colmax
+    C = C / np.sqrt((C * C).sum(axis=0))
+    return np.linalg.cond(C.astype(float)) <= 1e8
+
+
+class State:
+    """Unpacks like emcee's State: ``coords, log_prob, random_state = sampler.run_mcmc(...)``."""
+
+    def __init__(self, coords, log_prob, random_state):
+        self.coords, self.log_prob, self.random_state = coords, log_prob, random_state
+
+    def __iter__(self):
+        return iter((self.coords, self.log_prob, self.random_state))
+
+
+class EnsembleSampler:
+    def __init__(self, nwalkers, ndim, log_prob_fn, args=None, kwargs=None, a=2.0, vectorize=True,
+                 live_dangerously=False, threads=None, **_ignored):
+        """log_prob_fn: callable mapping an (Ns, ndim) block to (Ns,) log-probabilities when
+        ``vectorize`` (default), else a per-walker callable (mapped over rows)."""
+        self.nwalkers, self.ndim = int(nwalkers), int(ndim)
+        self.log_prob_fn = log_prob_fn
+        self.args = tuple(args) if args is not None else ()
+        self.kwargs = dict(kwargs) if kwargs is not None else {}
+        self.a = float(a)
+        self.vectorize = vectorize
+        self.live_dangerously = live_dangerously
+        self._random = np.random.RandomState()
+        self.reset()
+
+    # -- emcee-compatible RNG plumbing (bask/bayesgpr.py:518-521 assigns a get_state() tuple) --
+    @property
+    def random_state(self):
+        return self._random.get_state()
+
+    @random_state.setter
+    def random_state(self, state):
+        try:
+            self._random.set_state(state)
+        except Exception:
+            pass
+
+    def reset(self):
+        self._chain = None
+        self._log_prob = None
+        self.iteration = 0
+        self.naccepted = np.zeros(self.nwalkers, dtype=np.int64)
+        self.n_log_prob_evals = 0
+
+    def compute_log_prob(self, coords):
+        p = np.asarray(coords, dtype=np.float64)
+        if np.any(np.isinf(p)):
+            raise ValueError("At least one parameter value was infinite")
+        if np.any(np.isnan(p)):
+            raise ValueError("At least one parameter value was NaN")
+        if self.vectorize:
+            lp = np.asarray(self.log_prob_fn(p, *self.args, **self.kwargs), dtype=np.float64)
+        else:
+            lp = np.array([float(self.log_prob_fn(row, *self.args, **self.kwargs)) for row in p])
+        if lp.shape != (p.shape[0],):
+            raise ValueError(f"log_prob_fn returned shape {lp.shape}, expected ({p.shape[0]},)")
+        if np.any(np.isnan(lp)):
+            raise ValueError("Probability function returned NaN")
+        self.n_log_prob_evals += p.shape[0]
+        return lp
+
+    def run_mcmc(self, initial_state, nsteps, progress=False, skip_initial_state_check=False, log_prob0=None):
+        coords = np.array(initial_state, dtype=np.float64, copy=True)
+        if coords.shape != (self.nwalkers, self.ndim):
+            raise ValueError("incompatible input dimensions")
+        if self.nwalkers < 2 * self.ndim and not self.live_dangerously:
+            raise RuntimeError(
+                "It is unadvisable to use a red-blue move with fewer walkers than twice the number of dimensions."
+            )
+        if not skip_initial_state_check and not walkers_independent(coords):
+            raise ValueError(
+                "Initial state has a large condition number. "
+                "Make sure that your walkers are linearly independent for the best performance"
+            )
+        log_prob = self.compute_log_prob(coords) if log_prob0 is None else np.array(log_prob0, dtype=np.float64)
+        if np.any(np.isnan(log_prob)):
+            raise ValueError("The initial log_prob was NaN")
+
+        nsteps = int(nsteps)
+        chain = np.empty((nsteps, self.nwalkers, self.ndim))
+        lps = np.empty((nsteps, self.nwalkers))
+        rng = self._random
+        all_inds = np.arange(self.nwalkers)
+        a = self.a
+        pbar = _progress(progress, nsteps)
+        for step in range(nsteps):
+            rng.choice(1, p=[1.0])  # move selection among a single StretchMove
+            inds = all_inds % 2
+            rng.shuffle(inds)
+            for split in (0, 1):
+                S1 = inds == split
+                s = coords[S1]
+                c = coords[~S1]
+                Ns, Nc = s.shape[0], c.shape[0]
+                zz = ((a - 1.0) * rng.rand(Ns) + 1.0) ** 2.0 / a
+                factors = (self.ndim - 1.0) * np.log(zz)
+                rint = rng.randint(Nc, size=(Ns,))
+                cr = c[rint]
+                q = cr - (cr - s) * zz[:, None]
+                new_lp = self.compute_log_prob(q)  # <- one batched device call
+                lnpdiff = factors + new_lp - log_prob[S1]
+                with np.errstate(divide="ignore"):
+                    logu = np.log(rng.rand(Ns))  # same stream as Ns scalar draws
+                acc = lnpdiff > logu
+                idx = all_inds[S1][acc]
+                coords[idx] = q[acc]
+                log_prob[idx] = new_lp[acc]
+                self.naccepted[idx] += 1
+            chain[step] = coords
+            lps[step] = log_prob
+            pbar.update(1)
+        pbar.close()
+        self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
+        self._log_prob = lps if self._log_prob is None else np.concatenate([self._log_prob, lps])
+        self.iteration += nsteps
+        return State(coords, log_prob, rng.get_state())
+
+    @property
+    def acceptance_fraction(self):
+        return self.naccepted / max(self.iteration, 1)
+
+    def _slice(self, arr, flat, discard, thin):
+        if arr is None:
+            raise AttributeError("you must run the sampler before accessing the chain")
+        v = arr[discard + thin - 1 : self.iteration : thin]
+        if flat:
+            v = v.reshape((-1,) + v.shape[2:])
+        return v
+
+    def get_chain(self, flat=False, discard=0, thin=1):
+        """(steps, W, ndim), or step-major (steps*W, ndim) when flat -- emcee's layout."""
+        return self._slice(self._chain, flat, int(discard), int(thin))
+
+    def get_log_prob(self, flat=False, discard=0, thin=1):
+        return self._slice(self._log_prob, flat, int(discard), int(thin))
+
+
+class _NoBar:
+    def update(self, n):
+        pass
+
+    def close(self):
+        pass
+
+
+def _progress(progress, total):
+    if progress:
+        try:
+            import tqdm
+
+            return tqdm.tqdm(total=total)
+        except Exception:
+            pass
+    return _NoBar()

@@ -36,6 +36,7 @@ extern "C" {
 #define BGP_ERR_HIP 2      /* a HIP runtime call failed          */
 #define BGP_ERR_NODEVICE 3 /* no usable gfx950 device            */
 #define BGP_ERR_STATE 4    /* call order (e.g. predict before posterior) */
+#define BGP_ERR_NOTPD 5    /* bgp_sample_y: covariance (+jitter) not positive definite */
 
 enum { BGP_FORM_PRODUCT = 0, BGP_FORM_SUM = 1 };
 enum { BGP_RBF = 0, BGP_MATERN12 = 1, BGP_MATERN32 = 2, BGP_MATERN52 = 3 };
@@ -122,9 +123,8 @@ int bgp_predict_batch(bgp_ctx* ctx, int B, const double* h_kernel, int m, const 
                       double* var, double* cov);
 
 /*
- * PVRS inner loop with resident posterior 0 (built WITHOUT the candidate row; alpha_diag as in
- * the context when has_alpha_vec != 0, else the reference adds nothing to the augmented
- * diagonal -- bask/acquisition.py:332-333):  for every candidate i
+ * PVRS inner loop with the resident posterior built by bgp_pvrs_prepare (K without the candidate
+ * row):  for every candidate i
  *   covs[i] = sum_t k_t,aug^T K_aug,i^-1 k_t,aug ,   K_aug,i = kernel([X_train; x_i])
  * computed with the bordered-Cholesky identity instead of m factorizations.
  * Replaces: PVRS.__call__ loop (bask/acquisition.py:328-338); with thompson == candidates it is
@@ -132,12 +132,17 @@ int bgp_predict_batch(bgp_ctx* ctx, int B, const double* h_kernel, int m, const 
  */
 int bgp_pvrs(bgp_ctx* ctx, const double* h_kernel, int m, const double* Xcand, int T, const double* Xthompson,
              double* covs);
+/* Build the resident posterior bgp_pvrs needs: K = kernel_(X_train) (+ alpha_diag only when
+ * has_alpha_vec != 0 -- the reference adds alpha to the augmented diagonal only when it is
+ * iterable, bask/acquisition.py:332-333).  status (1 int, may be NULL) as in bgp_lml_batch. */
+int bgp_pvrs_prepare(bgp_ctx* ctx, const double* h_kernel, int has_alpha_vec, int* status);
 
 /*
  * Draw f ~ N(mean, cov) at m points for resident posterior b using standard normals supplied by
  * the host (z: n_draws*m), via a Cholesky factor of cov (+jitter) instead of numpy's SVD.
  * Replaces: sklearn sample_y (sklearn/_gpr.py:522-526) reached from BayesGPR.sample_y
- * (bask/bayesgpr.py:637-718).  out: n_draws*m.
+ * (bask/bayesgpr.py:637-718).  out: n_draws*m.  Returns BGP_ERR_NOTPD when cov + jitter*I is not
+ * numerically positive definite (the caller retries with a larger jitter).
  */
 int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                  const double* z, double jitter, double* out);

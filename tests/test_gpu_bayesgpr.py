@@ -1,0 +1,135 @@
+"""End-to-end GPU tests of the bask API surface: the reference's own behavioural tests
+(tests/test_bayesgpr.py, tests/test_utils.py of kiudee/bayes-skopt) re-expressed on this build, plus
+LML parity at every theta the sampler visits."""
+import numpy as np
+import pytest
+from scipy.stats import halfnorm, invgamma
+
+from conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bask():
+    import bayes_skopt_amd as bask
+
+    assert bask._lib.device_count() >= 1
+    return bask
+
+
+@pytest.fixture
+def minimal_gp(bask):
+    from bayes_skopt_amd.kernels import RBF, ConstantKernel
+
+    kernel = ConstantKernel(constant_value=1**2, constant_value_bounds=(0.01**2, 1**2)) * RBF(
+        length_scale=1.0, length_scale_bounds=(0.5, 1.5)
+    )
+    return bask.BayesGPR(random_state=1, normalize_y=False, kernel=kernel)
+
+
+@pytest.fixture
+def minimal_priors():
+    return [
+        lambda x: halfnorm(scale=1.0).logpdf(np.sqrt(np.exp(x))) + x / 2.0 - np.log(2.0),
+        lambda x: invgamma(a=5.0, scale=1.0).logpdf(np.exp(x)) + x,
+        lambda x: halfnorm(scale=1.0).logpdf(np.sqrt(np.exp(x))) + x / 2.0 - np.log(2.0),
+    ]
+
+
+def test_noise_vector(minimal_gp, minimal_priors):
+    """reference tests/test_bayesgpr.py:36-51"""
+    X = np.array([[0.0], [0.0]])
+    y = np.array([1.0, 0.0])
+    noise_vector = np.array([1234, 0.0])
+    minimal_gp.fit(X, y, noise_vector=noise_vector, n_burnin=1, progress=False, priors=minimal_priors)
+    prediction = minimal_gp.predict(np.array([[0.0]]))
+    assert prediction < 0.01
+
+
+def test_noise_set_to_zero(minimal_gp, minimal_priors):
+    """reference tests/test_bayesgpr.py:54-62"""
+    X = np.array([[0.1], [0.0], [-0.1]])
+    y = np.array([0.0, 0.0, 0.0])
+    minimal_gp.fit(X, y, n_burnin=1, progress=False, priors=minimal_priors)
+    minimal_gp.theta = np.array([0.0, 0.0, 0.0])
+    assert minimal_gp.predict(np.array([[0.0]]), return_std=True)[1] >= 1.0
+    with minimal_gp.noise_set_to_zero():
+        assert minimal_gp.predict(np.array([[0.0]]), return_std=True)[1] < 1.0
+    assert minimal_gp.predict(np.array([[0.0]]), return_std=True)[1] >= 1.0
+
+
+def test_sample_without_fit(minimal_gp):
+    """reference tests/test_bayesgpr.py:65-68"""
+    with pytest.raises(ValueError):
+        minimal_gp.sample()
+
+
+def test_fit_sample_predict_against_oracle(bask):
+    """fit (MAP + MCMC) on config-A-sized data; every quantity derived from the final theta must
+    match the oracle evaluated at that theta; the chain has the reference's shape."""
+    from oracle import gp_oracle as O
+
+    n, d = 128, 2
+    X, y = synth(n, d, 0)
+    kernel = bask.utils.construct_default_kernel(list(range(d)))
+    gp = bask.BayesGPR(kernel=kernel, random_state=3, normalize_y=False)
+    gp.fit(X, y, n_desired_samples=200, n_burnin=5, n_walkers_per_thread=40, progress=False)
+    assert gp.chain_.shape == (200, d + 2)  # ceil(200/40) kept steps x 40 walkers
+    assert gp.pos_.shape == (40, d + 2)
+    th = gp.theta
+    assert np.all(np.isfinite(th))
+    ad = np.full(n, 1e-10)
+    np.testing.assert_allclose(gp.log_marginal_likelihood_value_, O.lml(X, y, ad, th), rtol=1e-6)
+    Lo, Kio, ao = O.posterior(X, y, ad, th)
+    np.testing.assert_allclose(gp.alpha_, ao, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(gp.L_, Lo, rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gp.K_inv_, Kio, rtol=1e-6, atol=1e-8 * np.abs(Kio).max())
+    Xq = np.random.RandomState(5).uniform(size=(33, d))
+    mean, std = gp.predict(Xq, return_std=True)
+    mo, so = O.predict(X, y, ad, th, Xq)
+    np.testing.assert_allclose(mean, mo, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(std, so, rtol=1e-6, atol=1e-8)
+    with gp.noise_set_to_zero():
+        m0, s0 = gp.predict(Xq, return_std=True)
+    mo0, so0 = O.predict(X, y, ad, th, Xq, noise_zero=True)
+    np.testing.assert_allclose(m0, mo0, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(s0, so0, rtol=1e-5, atol=1e-7)
+    # warm start: a second sample() resumes from pos_ and keeps the walker count
+    gp.sample(n_desired_samples=80, n_burnin=0, n_walkers_per_thread=40)
+    assert gp.chain_.shape == (80, d + 2)
+    # the MAP start lies inside the kernel bounds and the median is a plausible posterior point
+    assert 0.05 < np.exp(th[1]) < 5.0
+
+
+def test_sampler_visits_have_oracle_lml(bask):
+    """LML parity at every theta the device sampler visited (statistical chain parity is unpinned:
+    emcee is absent -- see oracle/gp_oracle.py)."""
+    from oracle import gp_oracle as O
+
+    n, d = 96, 3
+    X, y = synth(n, d, 7)
+    kernel = bask.utils.construct_default_kernel(list(range(d)))
+    gp = bask.BayesGPR(kernel=kernel, random_state=11)
+    gp.fit(X, y, n_desired_samples=60, n_burnin=2, n_walkers_per_thread=20, progress=False)
+    chain = gp._sampler.get_chain(flat=True)
+    lps = gp._sampler.get_log_prob(flat=True)
+    idx = np.random.RandomState(0).choice(len(chain), size=25, replace=False)
+    ad = np.full(n, 1e-10)
+    for i in idx:
+        ref = O.lml(X, y, ad, chain[i]) + float(O.default_log_prior(chain[i][None, :], d)[0])
+        np.testing.assert_allclose(lps[i], ref, rtol=1e-6)
+
+
+def test_normalize_y_and_noise_vector_scaling(bask):
+    """noise_vector is divided by std(y)^2 under normalize_y (bask/bayesgpr.py:480-483,603-605)."""
+    n, d = 40, 2
+    X, y = synth(n, d, 8)
+    y = 5.0 * y + 3.0
+    kernel = bask.utils.construct_default_kernel(list(range(d)))
+    gp = bask.BayesGPR(kernel=kernel, random_state=2, normalize_y=True)
+    nv = np.full(n, 0.5)
+    gp.fit(X, y, noise_vector=nv, n_desired_samples=40, n_burnin=1, n_walkers_per_thread=20, progress=False)
+    np.testing.assert_allclose(gp.alpha, 1e-10 + nv / np.std(y) ** 2)
+    pred = gp.predict(X[:5])
+    assert np.all(np.abs(pred - y[:5]) < 4 * np.std(y))

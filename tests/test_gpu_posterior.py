@@ -1,0 +1,138 @@
+"""GPU parity of posterior build / predict / LML gradient / PVRS / sample_y through the C-ABI against
+the golden vectors (sklearn 1.7.2; reference bask.acquisition via tier-1 import) and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import _lib
+
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+def test_posterior_factors_and_predict(lib):
+    g = load_golden("predict.npz")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        st, form = [str(s) for s in g[pre + "meta"]]
+        X, y, Xq, ad, th = g[pre + "X"], g[pre + "y"], g[pre + "Xq"], g[pre + "alpha_diag"], g[pre + "theta"]
+        ctx = lib.Context(X, y, ad, form=form, stationary=st, max_batch=4)
+        res = ctx.posterior(th, want_L=True, want_alpha=True, want_K_inv=True)
+        assert res["status"][0] == 0
+        np.testing.assert_allclose(res["L"][0], g[pre + "L"], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(res["alpha"][0], g[pre + "alpha_vec"], rtol=1e-6, atol=1e-7)
+        scale = np.abs(g[pre + "K_inv"]).max()
+        np.testing.assert_allclose(res["K_inv"][0], g[pre + "K_inv"], rtol=1e-6, atol=1e-8 * scale)
+        # predict with noise (kernel_ as built) and inside noise_set_to_zero (log s2 = -inf)
+        mean, var, cov = ctx.predict(th, Xq, return_cov=True)
+        np.testing.assert_allclose(mean[0], g[pre + "mean"], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[0]), g[pre + "std"], rtol=RTOL, atol=1e-8)
+        np.testing.assert_allclose(cov[0], g[pre + "cov"], rtol=RTOL, atol=1e-8)
+        th0 = th.copy()
+        th0[-1] = -np.inf
+        mean0, var0, cov0 = ctx.predict(th0, Xq, return_cov=True)
+        np.testing.assert_allclose(mean0[0], g[pre + "mean0"], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var0[0]), g[pre + "std0"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(cov0[0], g[pre + "cov0"], rtol=RTOL, atol=1e-8)
+        ctx.close()
+
+
+def test_posterior_batch_of_hyper_samples(lib):
+    """evaluate_acquisitions rebuilds the posterior once per hyper-posterior sample
+    (bask/acquisition.py:112-121): here as ONE batched build + one batched predict."""
+    from oracle import gp_oracle as O
+
+    n, d, m, B = 150, 3, 70, 6
+    X, y = synth(n, d, 21)
+    Xq = np.random.RandomState(22).uniform(size=(m, d))
+    base = np.array([0.0, -1.2, -1.0, -1.4, -4.0])
+    TH = base + 0.2 * np.random.RandomState(23).randn(B, d + 2)
+    ctx = lib.Context(X, y, 1e-10, max_batch=8)
+    res = ctx.posterior(TH)
+    assert np.all(res["status"] == 0)
+    TH0 = TH.copy()
+    TH0[:, -1] = -np.inf
+    mean, var = ctx.predict(TH0, Xq)
+    for b in range(B):
+        mo, so = O.predict(X, y, np.full(n, 1e-10), TH[b], Xq, noise_zero=True)
+        np.testing.assert_allclose(mean[b], mo, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[b]), so, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(res["lml"][b], O.lml(X, y, np.full(n, 1e-10), TH[b]), rtol=RTOL)
+    ctx.close()
+
+
+def test_lml_gradient(lib):
+    g = load_golden("lml_grad.npz")
+    for c in range(int(g["n_cases"])):
+        pre = f"c{c}_"
+        st, form = [str(s) for s in g[pre + "meta"]]
+        ctx = lib.Context(g[pre + "X"], g[pre + "y"], 1e-10, form=form, stationary=st, max_batch=4)
+        val, grad, status = ctx.lml_grad(g[pre + "theta"])
+        assert np.all(status == 0)
+        np.testing.assert_allclose(val, g[pre + "lml"], rtol=RTOL)
+        np.testing.assert_allclose(grad, g[pre + "grad"], rtol=1e-5, atol=1e-6)
+        ctx.close()
+
+
+def test_lml_gradient_many_dims_and_tiles(lib):
+    """d > 16 (two staging passes) and n > 128 (several tiles, off-diagonal weight 2)."""
+    from oracle import gp_oracle as O
+
+    n, d = 300, 20
+    X, y = synth(n, d, 31)
+    th = np.concatenate([[0.1], np.log(0.5) + 0.1 * np.random.RandomState(1).randn(d), [np.log(0.05)]])
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    val, grad, _ = ctx.lml_grad(th)
+    vo, go = O.lml_and_grad(X, y, np.full(n, 1e-10), th)
+    np.testing.assert_allclose(val[0], vo, rtol=RTOL)
+    np.testing.assert_allclose(grad[0], go, rtol=1e-5, atol=1e-6)
+    ctx.close()
+
+
+def test_pvrs_matches_reference_loop(lib):
+    """bask.acquisition.PVRS per-candidate bordered Cholesky loop (golden: reference tier-1 import)
+    vs the bordered-inverse identity on the device."""
+    g = load_golden("reference_tier1.npz")
+    for c in range(int(g["pvrs_cases"])):
+        pre = f"pvrs{c}_"
+        X, Xc, th = g[pre + "X"], g[pre + "Xc"], g[pre + "theta"]
+        av = g[pre + "alpha_vec"]
+        has_vec = av.size > 0
+        y = np.zeros(len(X))
+        ctx = lib.Context(X, y, av if has_vec else 1e-10, max_batch=4)
+        assert ctx.pvrs_prepare(th, has_vec) == 0
+        tp = Xc[np.argmin(g[pre + "thompson"], axis=0)]
+        covs = ctx.pvrs(th, Xc, tp)
+        np.testing.assert_allclose(covs, g[pre + "covs"], rtol=RTOL)
+        if (pre + "vr") in g.files:  # VarianceReduction == PVRS with thompson points = all candidates
+            vr = ctx.pvrs(th, Xc, Xc)
+            np.testing.assert_allclose(vr, g[pre + "vr"], rtol=RTOL)
+        ctx.close()
+
+
+def test_sample_y_moments(lib):
+    """Draws through the device Cholesky of the predictive covariance: f = mean + L z reproduces
+    mean and cov exactly for the supplied z (checked against the oracle's mean / cov)."""
+    from oracle import gp_oracle as O
+
+    n, d, m = 80, 2, 150
+    X, y = synth(n, d, 41)
+    Xq = np.random.RandomState(42).uniform(size=(m, d))
+    th = np.array([0.0, -1.0, -1.1, -3.0])
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    ctx.posterior(th)
+    z = np.random.RandomState(43).standard_normal((5, m))
+    jit = 1e-8
+    out = ctx.sample_y(0, th, Xq, z, jitter=jit)
+    mean, std, cov = O.predict(X, y, np.full(n, 1e-10), th, Xq, return_cov=True)
+    Lc = np.linalg.cholesky(cov + jit * np.eye(m))
+    np.testing.assert_allclose(out, mean[None, :] + z @ Lc.T, rtol=1e-6, atol=1e-7)
+    ctx.close()
