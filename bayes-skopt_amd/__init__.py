@@ -3,7 +3,20 @@ BayesGPR posterior (kernel-matrix build, jittered fp64 Cholesky, solves, log-mar
 and the ensemble MCMC over kernel hyper-parameters, behind the ``bask`` API surface
 (``bask/__init__.py:19-35`` export list).  Device code: hand-written HIP for gfx950 behind the
 C-ABI of ``include/bgp.h`` (``lib/libbgp.so``), bound with ctypes.  No CPU fallback.
+
+    import bayes_skopt_amd as bask
+    gp = bask.BayesGPR(kernel=...); gp.fit(X, y); gp.predict(Xq, return_std=True)
 """
 __version__ = "0.1.0"
 
-from . import _lib  # noqa: F401
+from . import _lib, distributed, init, kernels, priors, sampler, utils  # noqa: F401
+from .bayesgpr import BayesGPR
+from .utils import construct_default_kernel, geometric_median, guess_priors, r2_sequence  # noqa: F401
+
+__all__ = [
+    "BayesGPR",
+    "geometric_median",
+    "guess_priors",
+    "construct_default_kernel",
+    "r2_sequence",
+]

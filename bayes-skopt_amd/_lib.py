@@ -52,6 +52,7 @@ SIGNATURES = {
     "bgp_pvrs": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]),
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
+    "bgp_device_synchronize": (C.c_int, [C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
@@ -246,6 +247,10 @@ class Context:
         out = {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(names)}
         out["device_total_ms"] = float(ms[4])
         return out
+
+
+def device_synchronize(device=0):
+    _check(load().bgp_device_synchronize(int(device)), "bgp_device_synchronize")
 
 
 def bench_mfma_f64(device=0, iters=20000):

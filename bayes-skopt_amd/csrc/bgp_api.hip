@@ -268,6 +268,12 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
   return BGP_OK;
 }
 
+extern "C" int bgp_device_synchronize(int device) {
+  BGP_HIP(hipSetDevice(device));
+  BGP_HIP(hipDeviceSynchronize());
+  return BGP_OK;
+}
+
 extern "C" int bgp_set_timing(bgp_ctx* c, int enable) {
   if (!c) return BGP_ERR_INVALID;
   c->timing = enable ? 1 : 0;

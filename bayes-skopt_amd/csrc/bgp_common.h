@@ -25,6 +25,7 @@ void bgp_set_error(const char* fmt, ...);
     hipError_t e__ = (call);                                                                 \
     if (e__ != hipSuccess) {                                                                 \
       bgp_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+      (void)hipGetLastError(); /* clear the sticky error so that later calls are not blamed */  \
       return BGP_ERR_HIP;                                                                    \
     }                                                                                        \
   } while (0)

@@ -554,7 +554,7 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   BGP_HIP(hipSetDevice(c->device));
   const int npad = c->npad, n = c->n, d = c->d, mpad = pad128(m), Tpad = pad128(T);
   const size_t p = d + 2;
-  size_t need = (size_t)m * d + (size_t)T * d + p + 16 + (size_t)mpad * npad + 2 * (size_t)Tpad * npad +
+  size_t need = (size_t)m * d + (size_t)T * d + p + 128 + (size_t)mpad * npad + 2 * (size_t)Tpad * npad +
                 2 * (size_t)mpad * Tpad + 2 * (size_t)mpad + 2 * (size_t)Tpad;
   int rc = bgp_ensure_scratch(c, need);
   if (rc) return rc;

@@ -61,13 +61,6 @@ def _stationary_name(k):
     return None
 
 
-class _Leaf:
-    __slots__ = ("kind", "kernel", "theta_index", "n_free")
-
-    def __init__(self, kind, kernel, theta_index, n_free):
-        self.kind, self.kernel, self.theta_index, self.n_free = kind, kernel, theta_index, n_free
-
-
 class KernelPlan:
     """theta (p,) of one kernel expression tree  <->  canonical h (d+2,)."""
 
@@ -146,7 +139,8 @@ def analyse_kernel(kernel):
     is not one of the canonical forms)."""
     if not isinstance(kernel, Kernel):
         raise TypeError(f"expected a scikit-learn kernel object, got {type(kernel)}")
-    leaves, n_theta = _leaves_in_theta_order(kernel)
+    with np.errstate(divide="ignore"):  # a zeroed WhiteKernel has theta = log(0)
+        leaves, n_theta = _leaves_in_theta_order(kernel)
     index_of = {id(k): (i0, nf) for k, i0, nf in leaves}
 
     def slot(k):

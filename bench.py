@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- the BASELINE.json headline metric on MI355X: MCMC LML-evaluations/s of the BayesGPR
+hot path at n=2048 (config C: d=16, Matern-5/2 ARD + White, 256 walkers), plus the roofline of the
+dominant kernel (fp64-MFMA trailing update of the blocked Cholesky) and a CPU baseline.
+
+A "step" is one ensemble-MCMC step = two half-steps, each one batched device call that builds,
+factorises and scores W/2 = 128 kernel matrices; K steps = 256*K LML evaluations.
+Inputs (X, y, walker positions) are resident / tiny; only (128, 18) doubles of proposals go up and
+128 log-likelihoods come back per half-step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU, each rank an independent 256-walker sub-ensemble on its own device
+(weak scaling, no collective in the sampling loop); the posterior samples are all-gathered over
+RCCL at the end (outside the timed region, reported as `gather_ms`).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_POINTS, N_DIMS, N_WALKERS = 2048, 16, 256
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X datasheet fp64 matrix peak (dense); not in MI355X_MICROARCH.md
+NB = 128
+
+
+def synth(n, d, seed):
+    """SURVEY.md 8(d) synthetic design."""
+    rng = np.random.RandomState(seed)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+    return X, (y - y.mean()) / y.std()
+
+
+def trailing_flops_per_launch(n, nb=NB):
+    """F_trail(n, nb) per matrix, split per launch j: nb * m_j * (m_j + 1),
+    m_j = n - j*nb (lower-triangular syrk, 2 flop per MAC)."""
+    return [nb * (n - j * nb) * (n - j * nb + 1) for j in range(1, n // nb)]
+
+
+def cpu_baseline(X, y, thetas, budget_s=20.0):
+    """Oracle (numpy/scipy restatement of sklearn's log_marginal_likelihood) on the host cores,
+    one walker at a time as emcee's map would, bounded sample of the same workload."""
+    from oracle import gp_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ad = np.full(len(y), 1e-10)
+    O.lml(X, y, ad, thetas[0])  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    for th in thetas:
+        O.lml(X, y, ad, th)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": done / dt,
+        "unit": "LML-evals/s",
+        "cores": int(threads),
+        "kind": "port",
+        "sample": f"{done} sequential LML evaluations (n={len(y)}, d={X.shape[1]}) of walker positions from the same "
+        f"start ball, oracle/gp_oracle.py (numpy+scipy LAPACK, {threads} BLAS threads), {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd import _lib, distributed
+    from bayes_skopt_amd.kernels import WhiteKernel
+
+    rank, local_rank, ws = distributed.init_process_group()
+    if ws != args.gpus and ws > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    device = local_rank % ndev
+
+    n, d, W = N_POINTS, N_DIMS, N_WALKERS
+    X, y = synth(n, d, seed=0)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=distributed.rank_seed(0, rank),
+                       device=device, max_batch=W // 2)
+    # state right after the MAP fit of BayesGPR.fit (bask/bayesgpr.py:602-607) without running it:
+    gp.kernel_ = gp.kernel + WhiteKernel(noise_level=0.01)
+    gp.noise_ = 0.01
+    gp.X_train_ = X
+    gp.y_train_ = y
+    gp.y_train_mean_, gp.y_train_std_ = np.zeros(1), 1
+    gp._ensure_context(batch_hint=W // 2)
+    priors = bask.guess_priors(gp.kernel_)
+    theta0 = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+    pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)  # the reference's start ball (:506-509)
+
+    sampler = bask.sampler.EnsembleSampler(W, d + 2, gp._log_prob_batch, kwargs=dict(priors=priors))
+    sampler.random_state = np.random.RandomState(distributed.rank_seed(1, rank)).get_state()
+
+    def sync():
+        _lib.device_synchronize(device)
+        if ws > 1:
+            import torch
+
+            torch.cuda.synchronize()
+
+    state = sampler.run_mcmc(pos, max(args.warmup, 1))  # also evaluates the initial ensemble
+    pos, lp = state.coords, state.log_prob
+
+    distributed.barrier()
+    sync()
+    t0 = time.perf_counter()
+    state = sampler.run_mcmc(pos, args.steps, log_prob0=lp, skip_initial_state_check=True)
+    sync()
+    distributed.barrier()
+    dt = distributed.max_over_ranks(time.perf_counter() - t0)
+    pos, lp = state.coords, state.log_prob
+
+    # final posterior-sample gather (RCCL over xGMI when N > 1)
+    tg = time.perf_counter()
+    chain_all = distributed.gather_chains(sampler.get_chain(flat=True, discard=max(args.warmup, 1)))
+    gather_ms = (time.perf_counter() - tg) * 1e3
+
+    # instrumented pass: HIP events around every launch on the context's stream, same work
+    gp._ctx.set_timing(True)
+    acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk")}
+    dev_total = 0.0
+    n_calls = 0
+    orig = gp._ctx.lml
+
+    def timed_lml(H, return_status=False):
+        nonlocal dev_total, n_calls
+        out = orig(H, return_status)
+        tm = gp._ctx.last_timing()
+        for k in acc:
+            acc[k][0] += tm[k]["ms"]
+            acc[k][1] += tm[k]["launches"]
+        dev_total += tm["device_total_ms"]
+        n_calls += 1
+        return out
+
+    gp._ctx.lml = timed_lml
+    t1 = time.perf_counter()
+    sampler.run_mcmc(pos, args.steps, log_prob0=lp, skip_initial_state_check=True)
+    dt_instr = time.perf_counter() - t1
+    gp._ctx.lml = orig
+    gp._ctx.set_timing(False)
+
+    B = W // 2
+    fl = trailing_flops_per_launch(n)
+    syrk_ms, syrk_launches = acc["syrk"]
+    flops_per_call = float(sum(fl)) * B
+    achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    roofline = {
+        "bound": "mfma",
+        "kernel": "syrk_kernel (blocked-Cholesky trailing update, fp64 v_mfma_f64_16x16x4_f64)",
+        "achieved": achieved,
+        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+        "traffic": None,
+        "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
+        "launches": syrk_launches,
+        "algorithmic_flops_per_factorisation": float(sum(fl)),
+        "note": "algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
+        "peak = datasheet fp64 matrix peak (MI355X_MICROARCH.md has no fp64 row)",
+    }
+
+    evals = W * args.steps * ws
+    value = evals / dt
+    line = {
+        "metric": "mcmc_lml_evals_per_s_n2048",
+        "value": value,
+        "unit": "LML-evals/s",
+        "n_gpus": ws,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config C: BayesGPR hyper-posterior MCMC, n=2048, d=16, c*Matern52(ARD)+White, "
+            "256 walkers per GPU (128 batched kernel-build+Cholesky+LML per half-step), start ball of "
+            "bask/bayesgpr.py:506-509, default priors",
+            "n": n,
+            "d": d,
+            "walkers_per_gpu": W,
+            "parallelism": f"chains{ws}",
+        },
+        "roofline": roofline,
+        "kernel_ms_per_half_step": {k: v[0] / max(n_calls, 1) for k, v in acc.items()},
+        "device_ms_per_half_step": dev_total / max(n_calls, 1),
+        "instrumented_ms_per_step": dt_instr / args.steps * 1e3,
+        "gather_ms": gather_ms,
+        "gathered_chain_rows": int(chain_all.shape[0]),
+        "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
+            line["speedup_vs_cpu_baseline"] = value / ws / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if ws > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,9 @@ int bgp_pvrs_prepare(bgp_ctx* ctx, const double* h_kernel, int has_alpha_vec, in
 int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                  const double* z, double jitter, double* out);
 
+/* hipDeviceSynchronize on `device` (timing brackets in bench.py). */
+int bgp_device_synchronize(int device);
+
 /* ---- measurement hooks (bench.py / profiling; not part of the reference surface) ---- */
 
 /* Average device time (ms, HIP events on the context's stream) of the kernels of the last
