@@ -23,51 +23,176 @@
 #include "bgp_gemm.h"
 
 // ------------------------------------------------------------------------------------------
-// potrf: diagonal block k of every walker.
+// potrf: diagonal block k of every walker, one workgroup (4 waves) per walker, block in LDS.
+//
+// The 128x128 block is processed as 8x8 sub-blocks of 16 (left-looking):
+//   phase 1  block column sb -= L[:, <sb] L[sb, <sb]^T          (fp64 MFMA, operands from LDS)
+//   phase 2  16x16 diagonal sub-block: Cholesky + inverse, register resident, one matrix row per
+//            lane, rows broadcast with v_readlane (compile-time lane ids); every wave does it
+//            redundantly so no hand-off is needed
+//   phase 3  panel below:  X = T M^T  with M = inverse of the 16x16 factor        (fp64 MFMA)
+// and finally W = L^-1 by block columns (register-resident C-layout blocks feed the next MFMA
+// directly as B operands: for v_mfma_f64_16x16x4_f64 the C/D row map (lane>>4)+4*reg coincides
+// with the B operand's k map for k-slice reg), z_k = W y_k, log-det and z^T z.
+// Latency-bound by the 128 sequential pivots; the MFMA pipe is mostly idle here by construction.
 // ------------------------------------------------------------------------------------------
+#define PF_LD 130   // LDS leading dimension of the 128x128 block (== 2 mod 32: conflict-free MFMA operand reads)
+#define PF_MLD 18   // leading dimension of the 16x16 inverse blocks
+
+static __device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Block column J of W = L^-1:  W[J][J] = M_J,  W[I][J] = -M_I * sum_{K=J}^{I-1} L[I][K] W[K][J].
+// Wreg blocks stay in registers in C layout; also accumulates z += W[:, J] y_J into zacc.
+template <int J>
+static __device__ __forceinline__ void potrf_wcol(const double* __restrict__ s, const double* __restrict__ Minv,
+                                                  double* __restrict__ Wg, const double* __restrict__ ylds,
+                                                  double* __restrict__ zacc, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 Wreg[8 - J];
+#pragma unroll
+  for (int r = 0; r < 4; r++) Wreg[0][r] = Minv[J * 16 * PF_MLD + (lk + 4 * r) * PF_MLD + lr];
+#pragma unroll
+  for (int I = J + 1; I < 8; I++) {
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int K = J; K < I; K++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const double av = s[(I * 16 + lr) * PF_LD + K * 16 + kk * 4 + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wreg[K - J][kk], acc, 0, 0, 0);
+      }
+    }
+    d4 wn = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const double av = -Minv[I * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
+      wn = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[kk], wn, 0, 0, 0);
+    }
+    Wreg[I - J] = wn;
+  }
+  const double yv = ylds[J * 16 + lr];
+#pragma unroll
+  for (int I = J; I < 8; I++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = I * 16 + lk + 4 * r;
+      const double w = Wreg[I - J][r];
+      Wg[row * 128 + J * 16 + lr] = w;
+      double part = w * yv;
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      part += __shfl_xor(part, 8);
+      if (lr == 0) atomicAdd(&zacc[row], part);
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                      double* __restrict__ yw, double* __restrict__ accb,
                                                      double* __restrict__ lml, int* __restrict__ status, int n,
                                                      int ld, size_t mstride, int ystride, int nblk, int k) {
   const int b = blockIdx.x;
   if (status[b] != 0) return;
-  __shared__ double s[128 * BGP_TILE_LD];
-  __shared__ double red[256];
-  const int tid = threadIdx.x;
+  __shared__ double s[128 * PF_LD];
+  __shared__ double Minv[8 * 16 * PF_MLD];
+  __shared__ double ylds[128];
+  __shared__ double zacc[128];
+  __shared__ double red[8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lr = lane & 15, lk = lane >> 4;
   double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
+  double* yk = yw + (size_t)b * ystride + k * 128;
 
   for (int idx = tid; idx < 128 * 64; idx += 256) {
     const int row = idx >> 6, seg = idx & 63;
     d2 v = *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2);
-    s[row * BGP_TILE_LD + seg * 2] = v.x;
-    s[row * BGP_TILE_LD + seg * 2 + 1] = v.y;
+    *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v;
+  }
+  if (tid < 128) {
+    ylds[tid] = yk[tid];
+    zacc[tid] = 0.0;
   }
   __syncthreads();
 
-  const int i = tid & 127, hh = tid >> 7;
   int failed = 0;
-  // unblocked right-looking factorisation in LDS (dpotf2 order: sqrt, scale by reciprocal, rank-1)
-  for (int j = 0; j < 128; j++) {
-    const double dj2 = s[j * BGP_TILE_LD + j];
-    if (!(dj2 > 0.0)) {  // also catches NaN; identical for every thread -> uniform exit
-      failed = j + 1;
-      break;
-    }
-    const double dj = sqrt(dj2);
-    const double inv = 1.0 / dj;
-    __syncthreads();
-    if (hh == 0) {
-      if (i == j)
-        s[j * BGP_TILE_LD + j] = dj;
-      else if (i > j)
-        s[i * BGP_TILE_LD + j] *= inv;
-    }
-    __syncthreads();
-    if (i > j) {
-      const double li = s[i * BGP_TILE_LD + j];
-      for (int c = j + 1 + hh; c <= i; c += 2) s[i * BGP_TILE_LD + c] -= li * s[c * BGP_TILE_LD + j];
+  double a[16];  // row (lane & 15) of the current 16x16 diagonal sub-block / its factor
+#pragma unroll 1
+  for (int sb = 0; sb < 8; sb++) {
+    // ---- phase 1: left-looking update of block column sb (rows sb..7 spread over the 4 waves)
+    for (int I = sb + w; I < 8; I += 4) {
+      d4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr];
+      for (int t = 0; t < sb; t++) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double av = -s[(I * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
+          const double bv = s[(sb * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
     }
     __syncthreads();
+
+    // ---- phase 2: 16x16 Cholesky + inverse in registers (every wave, redundantly)
+#pragma unroll
+    for (int c = 0; c < 16; c++) a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
+    double invd[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const double djj = readlane_f64(a[j], j);
+      if (!(djj > 0.0)) {  // NaN-safe; value is wave- and workgroup-uniform
+        if (failed == 0) failed = sb * 16 + j + 1;
+      }
+      const double inv = rsqrt(djj);
+      const double dj = djj * inv;
+      invd[j] = inv;
+      a[j] = (lr == j) ? dj : a[j] * inv;
+#pragma unroll
+      for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_f64(a[j], c);
+    }
+    if (failed) break;  // uniform across the workgroup
+    double m[16];
+#pragma unroll
+    for (int j = 15; j >= 0; j--) {
+      double acc = (lr == j) ? 1.0 : 0.0;
+#pragma unroll
+      for (int c = j + 1; c < 16; c++) acc -= m[c] * readlane_f64(a[j], c);
+      m[j] = acc * invd[j];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) Minv[sb * 16 * PF_MLD + lr * PF_MLD + c] = m[c];  // same values from every wave
+    }
+
+    // ---- phase 3: panel X_I = T_I M^T for the row blocks this wave updated in phase 1
+    for (int I = sb + w; I < 8; I += 4) {
+      if (I == sb) continue;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const double av = s[(I * 16 + lr) * PF_LD + sb * 16 + kk * 4 + lk];
+        const double bv = Minv[sb * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
+    }
+    __syncthreads();
+    // the factor of the diagonal sub-block replaces it only now: until the barrier above the other
+    // waves were still reading the unfactorised block
+    if (w == 0 && lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) s[(sb * 16 + lr) * PF_LD + sb * 16 + c] = (c <= lr) ? a[c] : 0.0;
+    }
   }
   if (failed) {
     if (tid == 0) {
@@ -76,70 +201,61 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     }
     return;
   }
+  __syncthreads();
 
-  // log-det contribution and write-back of L_kk (zeros above the diagonal)
-  red[tid] = (hh == 0) ? log(s[i * BGP_TILE_LD + i]) : 0.0;
+  // ---- L_kk out (zeros above the diagonal), log-det
   for (int idx = tid; idx < 128 * 128; idx += 256) {
     const int row = idx >> 7, col = idx & 127;
-    T[(size_t)row * ld + col] = (col <= row) ? s[row * BGP_TILE_LD + col] : 0.0;
+    T[(size_t)row * ld + col] = (col <= row) ? s[row * PF_LD + col] : 0.0;
   }
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) red[tid] += red[tid + st];
-    __syncthreads();
-  }
-  const double logdet_blk = red[0];
-  __syncthreads();
+  double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
+  for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
+  if (lane == 0) red[w] = ldv;
 
-  // in-place inverse of the lower-triangular block (dtrti2 order, columns right to left):
-  //   M_jj = 1/L_jj ;  M_ij = -M_jj * sum_{c=j+1..i} M_ic L_cj
-  for (int j = 127; j >= 0; j--) {
-    const double ajj = 1.0 / s[j * BGP_TILE_LD + j];
-    double v = 0.0;
-    if (i > j)
-      for (int c = j + 1 + hh; c <= i; c += 2) v += s[i * BGP_TILE_LD + c] * s[c * BGP_TILE_LD + j];
-    if (hh == 1) red[i] = v;
-    __syncthreads();
-    if (hh == 0) {
-      if (i > j)
-        s[i * BGP_TILE_LD + j] = -ajj * (v + red[i]);
-      else if (i == j)
-        s[j * BGP_TILE_LD + j] = ajj;
-    }
-    __syncthreads();
-  }
-
-  // W_kk out (dense 128x128, zeros above the diagonal)
-  double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  for (int idx = tid; idx < 128 * 128; idx += 256) {
+  // ---- W = L^-1 by block columns (wave w: columns w and 7-w), z = W y
+  double* Wg = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
+  for (int idx = tid; idx < 128 * 128; idx += 256) {  // strictly upper 16x16 blocks are zero
     const int row = idx >> 7, col = idx & 127;
-    W[idx] = (col <= row) ? s[row * BGP_TILE_LD + col] : 0.0;
+    if ((col >> 4) > (row >> 4)) Wg[idx] = 0.0;
   }
-  // z_k = W_kk y_k
-  double* yk = yw + (size_t)b * ystride + k * 128;
-  if (hh == 0) red[i] = yk[i];
-  __syncthreads();
-  double z = 0.0;
-  if (hh == 0) {
-    for (int c = 0; c <= i; c++) z += s[i * BGP_TILE_LD + c] * red[c];
+  switch (w) {
+    case 0:
+      potrf_wcol<0>(s, Minv, Wg, ylds, zacc, lane);
+      potrf_wcol<7>(s, Minv, Wg, ylds, zacc, lane);
+      break;
+    case 1:
+      potrf_wcol<1>(s, Minv, Wg, ylds, zacc, lane);
+      potrf_wcol<6>(s, Minv, Wg, ylds, zacc, lane);
+      break;
+    case 2:
+      potrf_wcol<2>(s, Minv, Wg, ylds, zacc, lane);
+      potrf_wcol<5>(s, Minv, Wg, ylds, zacc, lane);
+      break;
+    default:
+      potrf_wcol<3>(s, Minv, Wg, ylds, zacc, lane);
+      potrf_wcol<4>(s, Minv, Wg, ylds, zacc, lane);
+      break;
   }
   __syncthreads();
-  if (hh == 0) yk[i] = z;
-  red[tid] = (hh == 0) ? z * z : 0.0;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st) red[tid] += red[tid + st];
-    __syncthreads();
+  double zv = 0.0;
+  if (tid < 128) {
+    zv = zacc[tid];
+    yk[tid] = zv;
   }
+  double zz = zv * zv;
+  for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
+  if (lane == 0) red[4 + w] = zz;
+  __syncthreads();
   if (tid == 0) {
-    double ld = logdet_blk, zz = red[0];
+    double ldt = red[0] + red[1] + red[2] + red[3];
+    double zzt = red[4] + red[5] + red[6] + red[7];
     if (k > 0) {
-      ld += accb[b * 4 + 0];
-      zz += accb[b * 4 + 1];
+      ldt += accb[b * 4 + 0];
+      zzt += accb[b * 4 + 1];
     }
-    accb[b * 4 + 0] = ld;
-    accb[b * 4 + 1] = zz;
-    if (k == nblk - 1) lml[b] = -0.5 * zz - ld - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    accb[b * 4 + 0] = ldt;
+    accb[b * 4 + 1] = zzt;
+    if (k == nblk - 1) lml[b] = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
   }
 }
 
