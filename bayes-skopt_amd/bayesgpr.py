@@ -482,6 +482,34 @@ class BayesGPR:
         if res is None or res.shape[0] < 1 or not np.array_equal(res[0], H[0]):
             self._ctx.posterior(H, want_alpha=False)
 
+    def _predict_hyper_samples(self, thetas, X, noise_zero=True):
+        """Posterior build + predict for a whole batch of hyper-posterior draws (what
+        ``evaluate_acquisitions`` does one ``gpr.theta = chain_[i]`` at a time,
+        ``bask/acquisition.py:112-125``): ONE batched device build, ONE batched predict."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        H = self._canonical(np.atleast_2d(thetas))
+        res = self._ctx.posterior(H, want_alpha=False)
+        if np.any(res["status"] != 0):
+            b = int(np.flatnonzero(res["status"])[0])
+            raise np.linalg.LinAlgError(
+                _PD_MESSAGE % self.kernel_,
+                "%d-th leading minor of the array is not positive definite" % res["status"][b],
+            )
+        Hk = H.copy()
+        if noise_zero:
+            Hk[:, -1] = -np.inf
+        mean, var = self._ctx.predict(Hk, X)
+        mu = self.y_train_std_ * mean + self.y_train_mean_
+        return mu, np.sqrt(var * self.y_train_std_**2)
+
+    def _pvrs(self, X, thompson_points, has_alpha_vec):
+        """Device side of PVRS / VarianceReduction (``bask/acquisition.py:287-300,328-338``)."""
+        Hk = self._canonical(self._kernel_theta_for_predict())
+        status = self._ctx.pvrs_prepare(Hk, has_alpha_vec)
+        if status != 0:
+            raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % status)
+        return self._ctx.pvrs(Hk, X, np.atleast_2d(thompson_points))
+
     def sample_y(self, X, sample_mean=False, noise=False, n_samples=1, random_state=0):
         """Function realisations of the GP(s) (``bask/bayesgpr.py:637-718``).  The multivariate
         normal draw uses a device Cholesky factor of the predictive covariance instead of numpy's

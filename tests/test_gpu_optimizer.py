@@ -1,0 +1,181 @@
+"""The reference's tests/test_optimizer.py and tests/test_acquisition.py re-expressed on this build
+(GPU: every tell() runs the device MCMC + acquisition kernels)."""
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal, assert_equal
+from scipy.stats import halfnorm, invgamma
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bask():
+    import bayes_skopt_amd as bask
+
+    assert bask._lib.device_count() >= 1
+    return bask
+
+
+def bench1(x):
+    """skopt.benchmarks.bench1: x[0]**2"""
+    return x[0] ** 2
+
+
+def test_multiple_asks(bask):
+    """reference tests/test_optimizer.py:14-26"""
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=1)
+    opt.run(bench1, n_iter=3, gp_burnin=0, n_samples=1)
+    assert_equal(len(opt.Xi), 3)
+    opt.ask()
+    assert_equal(len(opt.Xi), 3)
+    assert_equal(opt.ask(), opt.ask())
+
+
+@pytest.mark.parametrize("init_strategy", ("r2", "sb", "random"))
+def test_initial_points(bask, init_strategy):
+    """reference tests/test_optimizer.py:28-47"""
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=3, init_strategy=init_strategy)
+    x = opt.ask()
+    assert not isinstance(x[0], list)
+    opt.tell([x], [0.0])
+    assert opt._n_initial_points == opt.n_initial_points_ - 1
+    opt.tell([x], [0.0])
+    assert opt._n_initial_points == opt.n_initial_points_ - 2
+    assert opt.gp.chain_ is None
+    opt.tell([[0.1], [0.2], [0.3]], [0.0, 0.1, 0.2], replace=True)
+    assert opt._n_initial_points == opt.n_initial_points_ - 3
+    assert opt.gp.chain_ is not None
+
+
+def test_noise_vector(bask):
+    """reference tests/test_optimizer.py:49-64"""
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=5)
+    opt.tell(
+        [[-2.0], [-1.0], [0.0], [1.0], [2.0]],
+        [0.0, -1.0, 0.0, -1.0, 0.0],
+        noise_vector=[1.0, 1.0, 1.0, 0.0, 1.0],
+    )
+    y_noisy, y = opt.gp.predict(opt.space.transform([[-1.0], [1.0]]))
+    assert y_noisy > y
+    x = opt.ask()
+    opt.tell(x, 0.0, noise_vector=0.5)
+
+
+def test_run_with_noise(bask):
+    """reference tests/test_optimizer.py:66-73"""
+    random_state = np.random.RandomState(123)
+
+    def func(x):
+        return (np.sin(x) + random_state.randn()).item(), 1.0
+
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=1)
+    opt.run(func, n_iter=2, n_samples=1, gp_burnin=0)
+    assert_almost_equal(opt.gp.alpha, np.ones(2))
+
+
+def test_no_error_on_unknown_kwargs(bask):
+    bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=5, unknown_argument=42)
+
+
+def test_error_on_invalid_priors(bask):
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], gp_priors=[], n_initial_points=0)
+    with pytest.raises(ValueError):
+        opt.tell([(0.0,)], 0.0)
+
+
+@pytest.fixture
+def fitted_minimal_gp(bask):
+    from bayes_skopt_amd.kernels import RBF, ConstantKernel
+
+    kernel = ConstantKernel(constant_value=1**2, constant_value_bounds=(0.01**2, 1**2)) * RBF(
+        length_scale=1.0, length_scale_bounds=(0.5, 1.5)
+    )
+    gp = bask.BayesGPR(random_state=1, normalize_y=False, kernel=kernel)
+    priors = [
+        lambda x: halfnorm(scale=1.0).logpdf(np.sqrt(np.exp(x))) + x / 2.0 - np.log(2.0),
+        lambda x: invgamma(a=5.0, scale=1.0).logpdf(np.exp(x)) + x,
+        lambda x: halfnorm(scale=1.0).logpdf(np.sqrt(np.exp(x))) + x / 2.0 - np.log(2.0),
+    ]
+    x = np.array([-2.0, -1.0, 1.0, 2.0])[:, None]
+    y = np.array([0, -1, 1, 2])
+    gp.fit(x, y, priors=priors, progress=False, n_burnin=1)
+    return gp
+
+
+# (acquisition, n_samples, argmax pinned by the reference's tests/test_acquisition.py:42-53, tolerance)
+# The reference's indices run through emcee's exact RNG stream and numpy's SVD-based MVN draw; this
+# build reproduces the ensemble-sampler stream from the published algorithm (emcee is absent) and
+# draws MVN samples through a Cholesky factor, so only the draw-free criteria are compared exactly.
+ACQ_CASES = [
+    ("VarianceReduction", 0, 50, 0),
+    ("LCB", 1, 38, 6),
+    ("ExpectedImprovement", 1, 33, 6),
+    ("Expectation", 1, 30, 6),
+    ("TopTwoEI", 1, 32, 8),
+]
+
+
+@pytest.mark.parametrize("name, n_samples, expected, tol", ACQ_CASES)
+def test_acquisition_argmax(bask, fitted_minimal_gp, name, n_samples, expected, tol):
+    x = np.linspace(-2.0, 2.0, num=101)[:, None]
+    acq = bask.acquisition.evaluate_acquisitions(
+        X=x, gpr=fitted_minimal_gp, acquisition_functions=[getattr(bask.acquisition, name)()], random_state=1,
+        n_samples=n_samples,
+    )
+    got = int(np.argmax(acq))
+    print(f"{name}: argmax {got} (reference pins {expected})")
+    assert abs(got - expected) <= tol
+
+
+@pytest.mark.parametrize("name, n_samples", [("PVRS", 0), ("ThompsonSampling", 1), ("MaxValueSearch", 1)])
+def test_acquisition_sampling_based_runs(bask, fitted_minimal_gp, name, n_samples):
+    x = np.linspace(-2.0, 2.0, num=101)[:, None]
+    acq = bask.acquisition.evaluate_acquisitions(
+        X=x, gpr=fitted_minimal_gp, acquisition_functions=[getattr(bask.acquisition, name)()], random_state=1,
+        n_samples=n_samples,
+    )
+    assert acq.shape == (1, 101) and np.all(np.isfinite(acq))
+    print(f"{name}: argmax {int(np.argmax(acq))}")
+    # the data decrease towards x = -1 (y = -1): every criterion must prefer the left half
+    assert int(np.argmax(acq)) < 60
+
+
+def test_evaluate_acquisitions_batched_equals_per_sample_loop(bask, fitted_minimal_gp):
+    """The batched posterior build + predict must equal the reference's per-draw loop
+    (gpr.theta = chain_[i]; predict inside noise_set_to_zero; bask/acquisition.py:112-141)."""
+    gp = fitted_minimal_gp
+    x = np.linspace(-2.0, 2.0, num=41)[:, None]
+    acqs = [bask.acquisition.ExpectedImprovement(), bask.acquisition.LCB()]
+    out = bask.acquisition.evaluate_acquisitions(X=x, gpr=gp, acquisition_functions=acqs, random_state=3, n_samples=5)
+    rs = np.random.RandomState(3)
+    idx = rs.choice(len(gp.chain_), replace=False, size=5)
+    theta_backup = gp.theta
+    ref = np.zeros((2, 41))
+    for i in idx:
+        gp.theta = gp.chain_[i]
+        with gp.noise_set_to_zero():
+            mu, std = gp.predict(x, return_std=True)
+        for j, a in enumerate(acqs):
+            ref[j] += a(mu, std) / 5
+    gp.theta = theta_backup
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(gp.theta, theta_backup)
+
+
+def test_tell_loop_pvrs_small(bask):
+    """Config-E-shaped loop at small size: several tells with PVRS over a candidate grid."""
+    rng = np.random.RandomState(0)
+    opt = bask.Optimizer(dimensions=[(0.0, 1.0)] * 3, n_points=300, n_initial_points=8, init_strategy="r2",
+                         acq_func="pvrs", random_state=0)
+
+    def f(x):
+        return float(np.sin(3 * np.sum(x)) + 0.05 * rng.randn())
+
+    for _ in range(11):
+        x = opt.ask()
+        res = opt.tell(x, f(x), gp_samples=100, gp_burnin=2, n_samples=0)
+    assert len(opt.Xi) == 11 and opt.gp.chain_.shape == (100, 5)
+    assert opt.gp.pos_.shape == (100, 5)  # 100 walkers through the Optimizer (bask/bayesgpr.py:390)
+    nxt = opt.ask()
+    assert len(nxt) == 3 and all(0.0 <= v <= 1.0 for v in nxt)
+    assert res.fun == min(opt.yi)
