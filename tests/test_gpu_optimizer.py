@@ -102,21 +102,26 @@ def fitted_minimal_gp(bask):
     return gp
 
 
-# (acquisition, n_samples, argmax pinned by the reference's tests/test_acquisition.py:42-53, tolerance)
-# The reference's indices run through emcee's exact RNG stream and numpy's SVD-based MVN draw; this
-# build reproduces the ensemble-sampler stream from the published algorithm (emcee is absent) and
-# draws MVN samples through a Cholesky factor, so only the draw-free criteria are compared exactly.
+# (acquisition, n_samples, argmax pinned by the reference's tests/test_acquisition.py:42-53).
+# These indices run through the MAP fit, emcee's exact RNG stream (fit with random_state=1), the
+# geometric median and the hyper-sample selection: reproducing them EXACTLY pins this build's
+# restatement of the ensemble sampler (emcee itself is absent from the image) against the reference's
+# own test vectors.  ThompsonSampling (reference: 25) is the one criterion not reproduced: its MVN
+# draw goes through a device Cholesky factor instead of numpy's SVD (same distribution, different
+# variates).
 ACQ_CASES = [
-    ("VarianceReduction", 0, 50, 0),
-    ("LCB", 1, 38, 6),
-    ("ExpectedImprovement", 1, 33, 6),
-    ("Expectation", 1, 30, 6),
-    ("TopTwoEI", 1, 32, 8),
+    ("VarianceReduction", 0, 50),
+    ("PVRS", 0, 38),
+    ("LCB", 1, 38),
+    ("ExpectedImprovement", 1, 33),
+    ("Expectation", 1, 30),
+    ("TopTwoEI", 1, 32),
+    ("MaxValueSearch", 1, 37),
 ]
 
 
-@pytest.mark.parametrize("name, n_samples, expected, tol", ACQ_CASES)
-def test_acquisition_argmax(bask, fitted_minimal_gp, name, n_samples, expected, tol):
+@pytest.mark.parametrize("name, n_samples, expected", ACQ_CASES)
+def test_acquisition_argmax_matches_reference_pins(bask, fitted_minimal_gp, name, n_samples, expected):
     x = np.linspace(-2.0, 2.0, num=101)[:, None]
     acq = bask.acquisition.evaluate_acquisitions(
         X=x, gpr=fitted_minimal_gp, acquisition_functions=[getattr(bask.acquisition, name)()], random_state=1,
@@ -124,10 +129,10 @@ def test_acquisition_argmax(bask, fitted_minimal_gp, name, n_samples, expected, 
     )
     got = int(np.argmax(acq))
     print(f"{name}: argmax {got} (reference pins {expected})")
-    assert abs(got - expected) <= tol
+    assert got == expected
 
 
-@pytest.mark.parametrize("name, n_samples", [("PVRS", 0), ("ThompsonSampling", 1), ("MaxValueSearch", 1)])
+@pytest.mark.parametrize("name, n_samples", [("ThompsonSampling", 1)])
 def test_acquisition_sampling_based_runs(bask, fitted_minimal_gp, name, n_samples):
     x = np.linspace(-2.0, 2.0, num=101)[:, None]
     acq = bask.acquisition.evaluate_acquisitions(
