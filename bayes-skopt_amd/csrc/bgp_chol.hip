@@ -279,59 +279,89 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
   bgp_map_block(blockIdx.x, nact, b, t);
   if (b >= B || status[b] != 0) return;
   __shared__ GemmSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  // 4 waves stacked along the rows (32 rows x 128 columns each): every wave sees the same
+  // triangular structure of W_kk, so the k-skip leaves them equally loaded
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r0 = w * 32;
   const int ib = bgp_rowblk(t, k, nblk - k - 1, aug);
   double* Atile = Kbuf + (size_t)b * mstride + (size_t)(ib * 128) * ld + k * 128;
   const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
 
-  d4 acc[4][4];
+  d4 acc[2][8];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (tid < 128) sm.ypart[tid] = 0.0;
+    for (int j = 0; j < 8; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 
   for (int k0 = 0; k0 < 128; k0 += GK_KC) {
     __syncthreads();
     gk_load_chunk(sm.A, Atile + k0, (size_t)ld, tid);
     gk_load_chunk(sm.B, W + k0, (size_t)128, tid);
     __syncthreads();
-    gk_mma_chunk<0, 1>(sm.A, sm.B, acc, wr, wc, lane, k0);
+    gk_mma_block<2, 8, 0, 1, -64>(sm.A, sm.B, acc, r0, 0, lane, k0);
   }
   // In-place overwrite is safe: every global read of this A tile was staged into LDS before the
   // last chunk's barrier, and no other workgroup touches the tile in this launch.
   const double* zk = yw + (size_t)b * ystride + k * 128;
-  double zc[4];
+  double zc[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) zc[j] = zk[GK_COL(wc, j, lane)];
+  for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
+  double* yi = yw + (size_t)b * ystride + ib * 128;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < 2; i++) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const int row = GK_ROW(wr, i, lane, r);
+      const int row = GK_ROWB(r0, i, lane, r);
       double part = 0.0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 8; j++) {
         const double x = acc[i][j][r];
-        Atile[(size_t)row * ld + GK_COL(wc, j, lane)] = x;
+        Atile[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
         part += x * zc[j];
       }
-      // reduce over the 16 lanes that share this row (lane & 15 varies)
+      // reduce over the 16 lanes that share this row (lane & 15 varies); the row belongs to this
+      // wave alone, so the right-hand side is updated directly
       part += __shfl_xor(part, 1);
       part += __shfl_xor(part, 2);
       part += __shfl_xor(part, 4);
       part += __shfl_xor(part, 8);
-      if ((lane & 15) == 0) atomicAdd(&sm.ypart[row], part);
+      if ((lane & 15) == 0) yi[row] -= part;
     }
   }
-  __syncthreads();
-  if (tid < 128) yw[(size_t)b * ystride + ib * 128 + tid] -= sm.ypart[tid];
+}
+
+static __device__ __forceinline__ void syrk_diag_tile(GemmSmem& sm, const double* __restrict__ XI,
+                                                      double* __restrict__ C, int ld, int tid, int lane, int w) {
+  // wave 0 / 1: the two 64x64 triangles on the diagonal (10 MFMA tiles each);
+  // wave 2 / 3: the 64x64 square below the diagonal cut into two 32x64 halves (8 MFMA tiles each).
+  // Barriers and staging are common code; only the register block differs per wave.
+  d4 acc[4][4];
+  d4(&acc2)[2][4] = reinterpret_cast<d4(&)[2][4]>(acc);
+  const int r0 = (w == 0) ? 0 : (w == 1) ? 64 : (w == 2) ? 64 : 96;
+  const int c0 = (w == 1) ? 64 : 0;
+  if (w < 2)
+    gk_load_c<4, 4, 0>(C, (size_t)ld, acc, r0, c0, lane);
+  else
+    gk_load_c<2, 4, -64>(C, (size_t)ld, acc2, r0, c0, lane);
+  for (int k0 = 0; k0 < 128; k0 += GK_KC) {
+    __syncthreads();
+    gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+    __syncthreads();
+    if (w < 2)
+      gk_mma_block<4, 4, 1, 0, 0>(sm.A, sm.A, acc, r0, c0, lane, k0);
+    else
+      gk_mma_block<2, 4, 1, 0, -64>(sm.A, sm.A, acc2, r0, c0, lane, k0);
+  }
+  if (w < 2)
+    gk_store_c<4, 4, 0>(C, (size_t)ld, acc, r0, c0, lane);
+  else
+    gk_store_c<2, 4, -64>(C, (size_t)ld, acc2, r0, c0, lane);
 }
 
 // ------------------------------------------------------------------------------------------
 // syrk: trailing update A_ij -= X_i X_j^T for k < j <= i.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) syrk_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
+__global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
                                                     int ld, size_t mstride, int nblk, int k, int nact, int aug,
                                                     int B) {
   const int ntile = nact * (nact + 1) / 2;
@@ -348,31 +378,25 @@ __global__ void __launch_bounds__(256) syrk_kernel(double* __restrict__ Kbuf, co
   const double* XJ = M + (size_t)(J * 128) * ld + k * 128;
   double* C = M + (size_t)(I * 128) * ld + J * 128;
 
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) acc[i][j][r] = C[(size_t)GK_ROW(wr, i, lane, r) * ld + GK_COL(wc, j, lane)];
-
-  const bool diag = (I == J);
-  for (int k0 = 0; k0 < 128; k0 += GK_KC) {
-    __syncthreads();
-    gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-    if (!diag) gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
-    __syncthreads();
-    gk_mma_chunk<1, 0>(sm.A, diag ? sm.A : sm.B, acc, wr, wc, lane, k0);
+  if (I != J) {
+    d4 acc[4][4];
+    gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
+    for (int k0 = 0; k0 < 128; k0 += GK_KC) {
+      __syncthreads();
+      gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+      gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
+      __syncthreads();
+      gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
+    }
+    gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
+  } else {
+    // Diagonal tile: only its lower triangle (36 of the 64 16x16 MFMA tiles) is ever read again,
+    // split 10 / 10 / 8 / 8 over the waves: two 4x4 triangles and the 4x4 square below the
+    // diagonal cut in two.  X_I is staged once and serves as both operands.
+    syrk_diag_tile(sm, XI, C, ld, tid, lane, w);
   }
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) C[(size_t)GK_ROW(wr, i, lane, r) * ld + GK_COL(wc, j, lane)] = acc[i][j][r];
 }
 
-// ------------------------------------------------------------------------------------------
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).

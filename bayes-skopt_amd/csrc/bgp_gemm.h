@@ -29,34 +29,77 @@ static __device__ __forceinline__ void gk_load_chunk(double* __restrict__ dst, c
   }
 }
 
-// acc[i][j] (+)= sum_k A[64wr+16i+.. ][k] * B[64wc+16j+..][k] over one 32-wide chunk.
+// Generic per-wave MFMA block: acc[i][j] (+)= sum_k A[r0+16i+..][k] * B[c0+16j+..][k] over one 32-wide
+// chunk, for an NR x NC grid of 16x16 MFMA tiles whose top-left corner is (r0, c0) inside the
+// 128x128 workgroup tile.
 // MFMA operand layout (cdna_hip_programming.md section 3): A operand lane l = A[l&15][l>>4],
 // B operand lane l = B[k=l>>4][j=l&15] = Bmat[l&15][l>>4]: both read [row = l&15][k = l>>4].
-// TRI != 0: the B matrix is lower triangular (W_kk): column block j only needs k <= its last column.
-template <int NEG, int TRI>
-static __device__ __forceinline__ void gk_mma_chunk(const double* __restrict__ As, const double* __restrict__ Bs,
-                                                    d4 (&acc)[4][4], int wr, int wc, int lane, int k0) {
+//   NEG   : use -A (trailing update subtracts)
+//   KSKIP : the B matrix is lower triangular (W_kk): column block j only needs k <= its last column
+//   CREL  : tile (i, j) is computed only when j + CREL <= i (lower-triangular part of a diagonal
+//           workgroup tile); CREL = -64 disables the test.
+template <int NR, int NC, int NEG, int KSKIP, int CREL>
+static __device__ __forceinline__ void gk_mma_block(const double* __restrict__ As, const double* __restrict__ Bs,
+                                                    d4 (&acc)[NR][NC], int r0, int c0, int lane, int k0) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int kk = 0; kk < GK_KC / 4; kk++) {
-    double a[4], b[4];
+    double a[NR], b[NC];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      double av = As[(wr * 64 + i * 16 + lr) * GK_LD + kk * 4 + lk];
+    for (int i = 0; i < NR; i++) {
+      const double av = As[(r0 + i * 16 + lr) * GK_LD + kk * 4 + lk];
       a[i] = NEG ? -av : av;
-      b[i] = Bs[(wc * 64 + i * 16 + lr) * GK_LD + kk * 4 + lk];
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (TRI && (k0 + kk * 4 > wc * 64 + j * 16 + 15)) continue;  // wave-uniform
+    for (int j = 0; j < NC; j++) b[j] = Bs[(c0 + j * 16 + lr) * GK_LD + kk * 4 + lk];
 #pragma unroll
-      for (int i = 0; i < 4; i++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < NC; j++) {
+      if (KSKIP && (k0 + kk * 4 > c0 + j * 16 + 15)) continue;  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        if (j + CREL > i) continue;  // compile-time
+        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
     }
   }
+}
+
+// Back-compat wrapper: the 2x2-wave layout (each wave a 64x64 sub-tile).
+template <int NEG, int TRI>
+static __device__ __forceinline__ void gk_mma_chunk(const double* __restrict__ As, const double* __restrict__ Bs,
+                                                    d4 (&acc)[4][4], int wr, int wc, int lane, int k0) {
+  gk_mma_block<4, 4, NEG, TRI, -64>(As, Bs, acc, wr * 64, wc * 64, lane, k0);
 }
 
 // C/D fragment layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 // (cdna_hip_programming.md:247-251; verified at run time by bgp_mfma_f64_layout + tests).
 #define GK_ROW(wr, i, lane, r) ((wr) * 64 + (i) * 16 + ((lane) >> 4) + 4 * (r))
 #define GK_COL(wc, j, lane) ((wc) * 64 + (j) * 16 + ((lane) & 15))
+#define GK_ROWB(r0, i, lane, r) ((r0) + (i) * 16 + ((lane) >> 4) + 4 * (r))
+#define GK_COLB(c0, j, lane) ((c0) + (j) * 16 + ((lane) & 15))
 
+// C tile <-> accumulators for an NR x NC block (same validity rule as gk_mma_block).
+template <int NR, int NC, int CREL>
+static __device__ __forceinline__ void gk_load_c(const double* __restrict__ C, size_t ld, d4 (&acc)[NR][NC], int r0,
+                                                 int c0, int lane) {
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+      if (j + CREL > i) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[i][j][r] = C[(size_t)GK_ROWB(r0, i, lane, r) * ld + GK_COLB(c0, j, lane)];
+    }
+}
+template <int NR, int NC, int CREL>
+static __device__ __forceinline__ void gk_store_c(double* __restrict__ C, size_t ld, const d4 (&acc)[NR][NC], int r0,
+                                                  int c0, int lane) {
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+      if (j + CREL > i) continue;
+#pragma unroll
+      for (int r = 0; r < 4; r++) C[(size_t)GK_ROWB(r0, i, lane, r) * ld + GK_COLB(c0, j, lane)] = acc[i][j][r];
+    }
+}

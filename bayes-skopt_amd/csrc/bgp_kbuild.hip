@@ -14,13 +14,30 @@
 
 #define KB_DK 16  // input dimensions staged per pass
 
+// Compile-time stationary kernel (same operation order as sklearn/kernels.py:1553-1560, 1713-1733;
+// the Matern-5/2 term K**2/3.0 is evaluated as t*t*(1/3): <= 1 ulp from the reference's division).
+template <int STAT>
+static __device__ __forceinline__ double kb_stationary(double r2) {
+  if (STAT == BGP_RBF) return exp(-0.5 * r2);
+  const double dist = sqrt(r2);
+  if (STAT == BGP_MATERN12) return exp(-dist);
+  if (STAT == BGP_MATERN32) {
+    const double t = dist * 1.7320508075688772;  // math.sqrt(3)
+    return (1.0 + t) * exp(-t);
+  }
+  const double t = dist * 2.23606797749979;  // math.sqrt(5)
+  return (1.0 + t + t * t * 0.3333333333333333) * exp(-t);
+}
+
 // Generic tile body: out[(i0+..)][(j0+..)] = k(A_i, B_j); A is (na x d), Bm is (nb x d), row-major.
-// gram != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.
-template <int GRAM>
-__device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na, const double* __restrict__ Bm,
-                                            int nb, int d, const double* __restrict__ h,
-                                            const double* __restrict__ alpha, int form, int stat, int i0, int j0,
-                                            double* __restrict__ out, size_t ldo, int out_rows, int out_cols) {
+// GRAM != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.
+// Tiles that are fully inside the data and off the diagonal take a check-free epilogue.
+template <int GRAM, int STAT, int FORM>
+static __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na,
+                                                   const double* __restrict__ Bm, int nb, int d,
+                                                   const double* __restrict__ h, const double* __restrict__ alpha,
+                                                   int i0, int j0, double* __restrict__ out, size_t ldo, int out_rows,
+                                                   int out_cols) {
   __shared__ double xi[KB_DK][BGP_TILE_LD];
   __shared__ double xj[KB_DK][BGP_TILE_LD];
   __shared__ double ell[KB_DK];
@@ -61,6 +78,20 @@ __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na
     }
   }
   const double cst = exp(h[0]);
+  const bool interior = (i0 + 128 <= na) && (j0 + 128 <= nb) && (i0 + 128 <= out_rows) && (j0 + 128 <= out_cols) &&
+                        !(GRAM && i0 == j0);
+  if (interior) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      double* orow = out + (size_t)(i0 + ty + 16 * r) * ldo + j0 + tx;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const double s = kb_stationary<STAT>(acc[r][c]);
+        orow[16 * c] = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+      }
+    }
+    return;
+  }
   const double s2 = exp(h[d + 1]);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
@@ -75,24 +106,25 @@ __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A, int na
         v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
       } else if (GRAM && gi == gj) {
         // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
-        double base = (form == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
         v = (base + s2);
         if (alpha) v += alpha[gi];
       } else {
-        double s = bgp_stationary(acc[r][c], stat);
-        v = (form == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+        const double s = kb_stationary<STAT>(acc[r][c]);
+        v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
       }
       out[(size_t)gi * ldo + gj] = v;
     }
   }
 }
 
+template <int STAT, int FORM>
 __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restrict__ X,
                                                            const double* __restrict__ alpha,
                                                            const double* __restrict__ H, double* __restrict__ Kbuf,
                                                            const double* __restrict__ y, double* __restrict__ yw,
-                                                           int n, int d, int npad, int nblk, int form, int stat,
-                                                           int B, int full, int ld, int use_alpha) {
+                                                           int n, int d, int npad, int nblk, int B, int full, int ld,
+                                                           int use_alpha) {
   const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
   int b, t;
   bgp_map_block(blockIdx.x, ntiles, b, t);
@@ -109,26 +141,44 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
   double* out = Kbuf + (size_t)b * ld * ld;
   // working right-hand side of walker b (becomes z = L^-1 y during the factorisation)
   if (ti == tj && threadIdx.x < 128) yw[(size_t)b * ld + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
-  kbuild_tile<1>(X, n, X, n, d, h, use_alpha ? alpha : nullptr, form, stat, ti * 128, tj * 128, out, (size_t)ld,
-                 npad, npad);
+  kbuild_tile<1, STAT, FORM>(X, n, X, n, d, h, use_alpha ? alpha : nullptr, ti * 128, tj * 128, out, (size_t)ld, npad,
+                             npad);
 }
 
+template <int STAT, int FORM>
 __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restrict__ Xq, int m,
                                                             const double* __restrict__ Xt, int n, int d,
-                                                            const double* __restrict__ h, int form, int stat,
-                                                            double* __restrict__ out, int ldo, int tiles_j) {
+                                                            const double* __restrict__ h, double* __restrict__ out,
+                                                            int ldo, int tiles_j) {
   const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
-  kbuild_tile<0>(Xq, m, Xt, n, d, h, nullptr, form, stat, ti * 128, tj * 128, out, (size_t)ldo, m, n);
+  kbuild_tile<0, STAT, FORM>(Xq, m, Xt, n, d, h, nullptr, ti * 128, tj * 128, out, (size_t)ldo, m, n);
 }
+
+// (stationary, form) -> instantiation
+#define KB_DISPATCH(STATV, FORMV, CALL)                                      \
+  do {                                                                       \
+    const int key__ = (STATV)*2 + (FORMV);                                   \
+    switch (key__) {                                                         \
+      case 0: { constexpr int S = 0, F = 0; CALL; } break;                   \
+      case 1: { constexpr int S = 0, F = 1; CALL; } break;                   \
+      case 2: { constexpr int S = 1, F = 0; CALL; } break;                   \
+      case 3: { constexpr int S = 1, F = 1; CALL; } break;                   \
+      case 4: { constexpr int S = 2, F = 0; CALL; } break;                   \
+      case 5: { constexpr int S = 2, F = 1; CALL; } break;                   \
+      case 6: { constexpr int S = 3, F = 0; CALL; } break;                   \
+      default: { constexpr int S = 3, F = 1; CALL; } break;                  \
+    }                                                                        \
+  } while (0)
 
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
   const int nblk = ctx->nblk;
   const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
   bgp_tbegin(ctx, 0);
-  hipLaunchKernelGGL(kbuild_gram_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->dX, ctx->dalpha, ctx->dh,
-                     ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, ctx->ks.form, ctx->ks.stationary, B, full_square,
-                     augmented ? 2 * ctx->npad : ctx->npad, use_alpha);
+  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, ctx->stream, ctx->dX, ctx->dalpha,
+                                 ctx->dh, ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, B, full_square,
+                                 augmented ? 2 * ctx->npad : ctx->npad, use_alpha));
   bgp_tend(ctx);
   BGP_HIP(hipGetLastError());
   return BGP_OK;
@@ -137,8 +187,9 @@ int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int u
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int /*unused*/) {
   const int tiles_i = (m + 127) / 128, tiles_j = (nx + 127) / 128;
-  hipLaunchKernelGGL(kbuild_cross_kernel, dim3(tiles_i * tiles_j), dim3(256), 0, ctx->stream, dXq, m, dXt, nx,
-                     ctx->d, dh_b, ctx->ks.form, ctx->ks.stationary, dout, ldo, tiles_j);
+  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+              hipLaunchKernelGGL((kbuild_cross_kernel<S, F>), dim3(tiles_i * tiles_j), dim3(256), 0, ctx->stream, dXq, m,
+                                 dXt, nx, ctx->d, dh_b, dout, ldo, tiles_j));
   BGP_HIP(hipGetLastError());
   return BGP_OK;
 }
