@@ -53,6 +53,7 @@ SIGNATURES = {
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
     "bgp_device_synchronize": (C.c_int, [C.c_int]),
+    "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
@@ -235,6 +236,9 @@ class Context:
             raise NotPositiveDefinite(self._lib.bgp_last_error().decode())
         _check(rc, "bgp_sample_y")
         return out
+
+    def set_streams(self, nstreams):
+        _check(self._lib.bgp_set_streams(self._h, int(nstreams)), "bgp_set_streams")
 
     def set_timing(self, enable):
         _check(self._lib.bgp_set_timing(self._h, int(bool(enable))), "bgp_set_timing")

@@ -1,6 +1,8 @@
 // C-ABI entry points of libbgp.so (see include/bgp.h for the contract and the reference seams).
 #include "bgp_common.h"
 
+#include <cstdlib>
+
 static thread_local std::string g_err;
 
 void bgp_set_error(const char* fmt, ...) {
@@ -142,6 +144,18 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     delete c;
     return BGP_ERR_HIP;
   }
+  {
+    const char* env = getenv("BGP_STREAMS");
+    int ns = env ? atoi(env) : 1;
+    if (ns < 1) ns = 1;
+    if (ns > BGP_MAX_STREAMS) ns = BGP_MAX_STREAMS;
+    c->nstreams = ns;
+    (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
+    for (int g = 0; g < ns; g++) {
+      (void)hipStreamCreate(&c->gstream[g]);
+      (void)hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming);
+    }
+  }
   const size_t mb = max_batch;
   int rc = BGP_OK;
   do {
@@ -189,6 +203,11 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dalpha_sol);
   free_dev(c->dKinv);
   free_dev(c->dscratch);
+  for (int g = 0; g < BGP_MAX_STREAMS; g++) {
+    if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+    if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
+  }
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -232,10 +251,35 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
       (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0, c->stream);
     }
-    int rc = factor_chunk(c, nb, h + (size_t)off * p, 0);
-    if (rc) return rc;
-    rc = bgp_launch_cholesky(c, nb, 0);
-    if (rc) return rc;
+    // walker groups on separate streams (sizes are multiples of 8: one matrix slot per XCD)
+    int ng = c->nstreams;
+    int gsz = ((nb + ng - 1) / ng + 7) / 8 * 8;
+    if (ng == 1 || nb < 16) {
+      ng = 1;
+      gsz = nb;
+    }
+    BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
+    int rc = BGP_OK;
+    if (ng == 1) {
+      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+      if (rc) return rc;
+      rc = bgp_launch_cholesky(c, nb, 0);
+      if (rc) return rc;
+    } else {
+      BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
+      for (int g = 0, o = 0; o < nb; g++, o += gsz) {
+        const int gb = std::min(gsz, nb - o);
+        hipStream_t st = c->gstream[g];
+        BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
+        rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
+        if (rc) return rc;
+        BGP_HIP(hipEventRecord(c->ev_done[g], st));
+        BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));
+      }
+    }
     BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (status) {
       BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -271,6 +315,22 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
 extern "C" int bgp_device_synchronize(int device) {
   BGP_HIP(hipSetDevice(device));
   BGP_HIP(hipDeviceSynchronize());
+  return BGP_OK;
+}
+
+extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
+  if (!c || nstreams < 1 || nstreams > BGP_MAX_STREAMS) {
+    bgp_set_error("bgp_set_streams: nstreams must be in 1..%d", BGP_MAX_STREAMS);
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  for (int g = 0; g < nstreams; g++) {
+    if (!c->gstream[g]) {
+      BGP_HIP(hipStreamCreate(&c->gstream[g]));
+      BGP_HIP(hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming));
+    }
+  }
+  c->nstreams = nstreams;
   return BGP_OK;
 }
 

@@ -398,6 +398,10 @@ __global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf,
 }
 
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
+  return bgp_launch_cholesky_slice(ctx, 0, B, ctx->stream, augmented);
+}
+
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -405,22 +409,28 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   const size_t mstride = (size_t)ld * ld;
   const int ystride = ld;
   const int B8 = 8 * ((B + 7) / 8);
+  double* dK = ctx->dK + (size_t)off * mstride;
+  double* dW = ctx->dW + (size_t)off * nblk * (128 * 128);
+  double* dyw = ctx->dyw + (size_t)off * ystride;
+  double* dacc = ctx->dacc + (size_t)off * 4;
+  double* dlml = ctx->dlml + off;
+  int* dstatus = ctx->dstatus + off;
   for (int k = 0; k < nblk; k++) {
-    bgp_tbegin(ctx, 1);
-    hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, ctx->stream, ctx->dK, ctx->dW, ctx->dyw, ctx->dacc,
-                       ctx->dlml, ctx->dstatus, ctx->n, ld, mstride, ystride, nblk, k);
-    bgp_tend(ctx);
+    bgp_tbegin(ctx, 1, st);
+    hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+                       ystride, nblk, k);
+    bgp_tend(ctx, st);
     const int nlow = nblk - k - 1;
     const int nact = augmented ? nblk : nlow;
     if (nact > 0) {
-      bgp_tbegin(ctx, 2);
-      hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, ctx->stream, ctx->dK, ctx->dW, ctx->dyw,
-                         ctx->dstatus, ld, mstride, ystride, nblk, k, nact, nblk, B);
-      bgp_tend(ctx);
-      bgp_tbegin(ctx, 3);
-      hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, ctx->stream, ctx->dK,
-                         ctx->dstatus, ld, mstride, nblk, k, nact, nblk, B);
-      bgp_tend(ctx);
+      bgp_tbegin(ctx, 2, st);
+      hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride,
+                         nblk, k, nact, nblk, B);
+      bgp_tend(ctx, st);
+      bgp_tbegin(ctx, 3, st);
+      hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                         nblk, k, nact, nblk, B);
+      bgp_tend(ctx, st);
     }
   }
   BGP_HIP(hipGetLastError());

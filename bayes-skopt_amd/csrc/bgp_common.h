@@ -14,6 +14,7 @@
 #define BGP_NB 128          // block size of the right-looking Cholesky == tile edge
 #define BGP_TILE_LD 129     // LDS leading dimension of a 128x128 tile (odd -> conflict-free columns)
 #define BGP_MAX_D 256       // maximum input dimension
+#define BGP_MAX_STREAMS 8
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,12 @@ struct bgp_ctx {
   int max_batch = 0;
   bgp_kernel_spec ks{};
   hipStream_t stream = nullptr;
+  // walker groups: the batch of an LML call is split over nstreams HIP streams so that the
+  // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
+  int nstreams = 1;
+  hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};
+  hipEvent_t ev_ready = nullptr;
+  hipEvent_t ev_done[BGP_MAX_STREAMS] = {nullptr};
   // resident training set
   double* dX = nullptr;      // n*d
   double* dy = nullptr;      // npad (zero padded)
@@ -72,19 +79,19 @@ struct bgp_ctx {
 
 // Per-launch HIP-event timing on the context's stream (only when ctx->timing != 0).
 // Categories: 0 K-build, 1 potrf, 2 trsm, 3 syrk.
-static inline void bgp_tbegin(bgp_ctx* c, int cat) {
+static inline void bgp_tbegin(bgp_ctx* c, int cat, hipStream_t st = nullptr) {
   if (!c->timing) return;
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  (void)hipEventRecord(a, c->stream);
+  (void)hipEventRecord(a, st ? st : c->stream);
   c->ev.push_back(a);
   c->ev.push_back(b);
   c->evcat.push_back(cat);
 }
-static inline void bgp_tend(bgp_ctx* c) {
+static inline void bgp_tend(bgp_ctx* c, hipStream_t st = nullptr) {
   if (!c->timing) return;
-  (void)hipEventRecord(c->ev.back(), c->stream);
+  (void)hipEventRecord(c->ev.back(), st ? st : c->stream);
 }
 static inline void bgp_tcollect(bgp_ctx* c) {
   if (!c->timing) return;
@@ -111,8 +118,12 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
 // ---- kernels launched across translation units ----
 // K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha);
+// same for the slice [off, off+B) of the current batch on an explicit stream
+int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
+                            int use_alpha);
 // Cross kernel matrix k(Xq, X_train) for hyper-vector index b: out is m x ldo row-major (device).
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int symmetric_diag_fix);
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);

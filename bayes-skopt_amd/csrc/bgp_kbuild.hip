@@ -171,15 +171,22 @@ __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restr
   } while (0)
 
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
+  return bgp_launch_kbuild_slice(ctx, 0, B, ctx->stream, full_square, augmented, use_alpha);
+}
+
+int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
+                            int use_alpha) {
   const int nblk = ctx->nblk;
+  const size_t ldm = augmented ? 2 * (size_t)ctx->npad : (size_t)ctx->npad;
   const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
-  bgp_tbegin(ctx, 0);
+  bgp_tbegin(ctx, 0, st);
   KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, ctx->stream, ctx->dX, ctx->dalpha,
-                                 ctx->dh, ctx->dK, ctx->dy, ctx->dyw, ctx->n, ctx->d, ctx->npad, nblk, B, full_square,
-                                 augmented ? 2 * ctx->npad : ctx->npad, use_alpha));
-  bgp_tend(ctx);
+              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, st, ctx->dX, ctx->dalpha,
+                                 ctx->dh + (size_t)off * (ctx->d + 2), ctx->dK + (size_t)off * ldm * ldm, ctx->dy,
+                                 ctx->dyw + (size_t)off * ldm, ctx->n, ctx->d, ctx->npad, nblk, B, full_square,
+                                 (int)ldm, use_alpha));
+  bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
   return BGP_OK;
 }

@@ -147,6 +147,12 @@ int bgp_pvrs_prepare(bgp_ctx* ctx, const double* h_kernel, int has_alpha_vec, in
 int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                  const double* z, double jitter, double* out);
 
+/* Number of walker groups (HIP streams) an LML batch is split over: the latency-bound diagonal-block
+ * factorisations of one group can overlap the MFMA-bound trailing updates of another.  Default 1
+ * (everything on one stream; measured gain of 2 groups on MI355X is only ~3 % because the trailing
+ * updates already fill every CU); environment BGP_STREAMS overrides at context creation. */
+int bgp_set_streams(bgp_ctx* ctx, int nstreams);
+
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */
 int bgp_device_synchronize(int device);
 

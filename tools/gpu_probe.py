@@ -46,11 +46,16 @@ def main():
         ctx = _lib.Context(X, y, 1e-10, max_batch=B)
         H = thetas(d, B, 30)
         ctx.lml(H)  # warm-up
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            v = ctx.lml(H)
-        dt = (time.perf_counter() - t0) / reps
+        for ns in (1, 2, 3, 4, 8):
+            ctx.set_streams(ns)
+            ctx.lml(H)
+            t0 = time.perf_counter()
+            reps = 4
+            for _ in range(reps):
+                v = ctx.lml(H)
+            dt = (time.perf_counter() - t0) / reps
+            print(f"   streams={ns}: wall {dt*1e3:.3f} ms/batch ({B/dt:.1f} evals/s)")
+        ctx.set_streams(1)
         ctx.set_timing(True)
         ctx.lml(H)
         tm = ctx.last_timing()
