@@ -170,6 +170,11 @@ def main():
     syrk_ms, syrk_launches = acc["syrk"]
     flops_per_call = float(sum(fl)) * B
     achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC passes (cannot be collected without rocprofv3)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {
         "bound": "mfma",
         "kernel": "syrk_kernel (blocked-Cholesky trailing update, fp64 v_mfma_f64_16x16x4_f64)",
@@ -177,12 +182,13 @@ def main():
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": traffic,
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
         "note": "algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
-        "peak = datasheet fp64 matrix peak (MI355X_MICROARCH.md has no fp64 row)",
+        "peak = datasheet fp64 matrix peak (MI355X_MICROARCH.md has no fp64 row); traffic = bytes per launch "
+        "from profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
     }
 
     evals = W * args.steps * ws
