@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const double djj = readlane_f64(a[j], j);
-      if (!(djj > 0.0)) {  // NaN-safe; value is wave- and workgroup-uniform
+      if (!(djj > 0.0 && djj < INFINITY)) {  // non-positive, NaN or overflowed pivot; uniform
         if (failed == 0) failed = sb * 16 + j + 1;
       }
       const double inv = rsqrt(djj);
@@ -255,7 +255,14 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     }
     accb[b * 4 + 0] = ldt;
     accb[b * 4 + 1] = zzt;
-    if (k == nblk - 1) lml[b] = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+    if (k == nblk - 1) {
+      double v = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
+      if (!(v > -INFINITY && v < INFINITY)) {  // overflow somewhere on the way: report like a failed factorisation
+        v = -INFINITY;
+        status[b] = n + 1;
+      }
+      lml[b] = v;
+    }
   }
 }
 

@@ -1,0 +1,128 @@
+"""Edge cases and size-independent properties of the device LML path (through the C-ABI)."""
+import numpy as np
+import pytest
+
+from conftest import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import _lib
+
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gp_oracle
+
+    return gp_oracle
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (2, 1), (3, 2), (5, 7), (127, 3), (128, 1), (129, 2), (255, 40), (256, 33), (385, 17)])
+def test_small_and_ragged_shapes(lib, O, n, d):
+    X, y = synth(max(n, 4), d, 100 + n)
+    X, y = X[:n], y[:n]
+    H = np.concatenate([[0.1], np.full(d, np.log(0.6)), [np.log(0.05)]]) + 0.1 * np.random.RandomState(n).randn(3, d + 2)
+    ad = np.full(n, 1e-10)
+    ctx = lib.Context(X, y, ad, max_batch=2)  # B=3 > max_batch: chunked
+    got = ctx.lml(H)
+    ref = O.lml_batch(X, y, ad, H)
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=1e-9)
+    ctx.close()
+
+
+@pytest.mark.parametrize("B", [1, 7, 9, 17])
+def test_batch_sizes_not_multiple_of_eight(lib, O, B):
+    n, d = 200, 3
+    X, y = synth(n, d, 55)
+    H = np.array([0.0, -1.0, -1.2, -0.8, -3.5]) + 0.15 * np.random.RandomState(B).randn(B, d + 2)
+    ctx = lib.Context(X, y, 1e-10, max_batch=32)
+    got = ctx.lml(H)
+    np.testing.assert_allclose(got, O.lml_batch(X, y, np.full(n, 1e-10), H), rtol=RTOL)
+    ctx.close()
+
+
+def test_mixed_failures_across_chunks(lib, O):
+    """Non-PD items anywhere in a batch (and across max_batch chunk boundaries) only affect themselves."""
+    n, d = 140, 2
+    X, y = synth(n, d, 66)
+    X[1] = X[0]  # duplicated point: exactly singular without jitter/noise (second pivot is exactly 0)
+    ad = np.zeros(n)
+    good = np.array([0.0, -1.0, -1.1, -3.0])
+    bad = np.array([0.0, -1.0, -1.1, -np.inf])
+    H = np.array([good, bad, good + 0.1, bad, bad, good - 0.1, good, bad, good + 0.2])
+    ctx = lib.Context(X, y, ad, max_batch=4)
+    got, status = ctx.lml(H, return_status=True)
+    isbad = np.array([0, 1, 0, 1, 1, 0, 0, 1, 0], dtype=bool)
+    assert np.all(got[isbad] == -np.inf) and np.all(status[isbad] == 2)  # pivot of the duplicate (1-based)
+    assert np.all(status[~isbad] == 0)
+    np.testing.assert_allclose(got[~isbad], O.lml_batch(X, y, ad, H[~isbad]), rtol=RTOL)
+    ctx.close()
+
+
+def test_overflowing_hyperparameters_give_minus_inf_not_nan(lib):
+    n, d = 64, 2
+    X, y = synth(n, d, 77)
+    ctx = lib.Context(X, y, 1e-10, max_batch=4)
+    H = np.array([[800.0, -1.0, -1.0, -3.0],     # c = inf
+                  [0.0, -1.0, -1.0, 800.0],      # s2 = inf
+                  [0.0, 800.0, 800.0, -800.0],   # l = inf, s2 = 0 -> rank one + 1e-10
+                  [0.0, -1.0, -1.0, -3.0]])
+    got, status = ctx.lml(H, return_status=True)
+    assert not np.any(np.isnan(got))
+    assert got[0] == -np.inf and got[1] == -np.inf and np.isfinite(got[3])
+    assert status[0] != 0 and status[1] != 0 and status[3] == 0
+    ctx.close()
+
+
+def test_update_data_shrinks_and_grows(lib, O):
+    X, y = synth(300, 2, 88)
+    th = np.array([[0.0, -1.0, -1.2, -3.0]])
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    for n in (300, 40, 260, 129):
+        ctx.update_data(X[:n], y[:n], np.full(n, 1e-10))
+        np.testing.assert_allclose(ctx.lml(th)[0], O.lml(X[:n], y[:n], np.full(n, 1e-10), th[0]), rtol=RTOL)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,d", [(2048, 16), (4096, 32)])
+def test_full_size_properties(lib, n, d):
+    """Size-independent properties at the BASELINE sizes (the oracle is too slow to sweep there):
+    (1) permuting the data rows leaves the LML unchanged; (2) with a dominant noise level the LML
+    approaches the closed form of an isotropic Gaussian; (3) LML(theta) is reproducible bit-for-bit."""
+    X, y = synth(n, d, 0)
+    base = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+    H = base + 0.1 * np.random.RandomState(1).randn(2, d + 2)
+    ctx = lib.Context(X, y, 1e-10, max_batch=4)
+    a = ctx.lml(H)
+    b = ctx.lml(H)
+    np.testing.assert_array_equal(a, b)
+    perm = np.random.RandomState(2).permutation(n)
+    ctx2 = lib.Context(X[perm], y[perm], 1e-10, max_batch=4)
+    np.testing.assert_allclose(ctx2.lml(H), a, rtol=1e-9)
+    big = base.copy()
+    big[-1] = 20.0  # s2 = e^20 >> c
+    s2 = np.exp(20.0)
+    closed = -0.5 * float(y @ y) / s2 - 0.5 * n * 20.0 - 0.5 * n * np.log(2 * np.pi)
+    np.testing.assert_allclose(ctx.lml(big[None, :])[0], closed, rtol=1e-8)
+    ctx.close()
+    ctx2.close()
+
+
+def test_predict_interpolates_smooth_training_points_with_tiny_noise(lib):
+    n, d = 150, 2
+    X, _ = synth(n, d, 99)
+    y = np.sin(3.0 * X.sum(axis=1))  # noise-free targets: a near-interpolating GP must reproduce them
+    th = np.array([0.0, -0.8, -0.8, np.log(1e-8)])
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    ctx.posterior(th)
+    mean, var = ctx.predict(th, X[:50])
+    np.testing.assert_allclose(mean[0], y[:50], atol=2e-4)
+    assert np.all(var[0] < 1e-5)
+    ctx.close()
