@@ -150,6 +150,12 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     if (ns < 1) ns = 1;
     if (ns > BGP_MAX_STREAMS) ns = BGP_MAX_STREAMS;
     c->nstreams = ns;
+    const char* envv = getenv("BGP_LU_VARIANT");
+    c->lu_variant = envv ? atoi(envv) : 0;
+    const char* envl = getenv("BGP_LEFT_LOOKING");
+    c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
+    const char* envt = getenv("BGP_TWO_PANEL");
+    c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
     (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     for (int g = 0; g < ns; g++) {
       (void)hipStreamCreate(&c->gstream[g]);
@@ -262,9 +268,13 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
     BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     int rc = BGP_OK;
     if (ng == 1) {
-      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
-      if (rc) return rc;
-      rc = bgp_launch_cholesky(c, nb, 0);
+      if (c->left_looking) {
+        rc = bgp_launch_cholesky_ll_slice(c, 0, nb, c->stream, 1);
+      } else {
+        rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky(c, nb, 0);
+      }
       if (rc) return rc;
     } else {
       BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
@@ -272,9 +282,13 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
         const int gb = std::min(gsz, nb - o);
         hipStream_t st = c->gstream[g];
         BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
-        rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
-        if (rc) return rc;
-        rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
+        if (c->left_looking) {
+          rc = bgp_launch_cholesky_ll_slice(c, o, gb, st, 1);
+        } else {
+          rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
+          if (rc) return rc;
+          rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
+        }
         if (rc) return rc;
         BGP_HIP(hipEventRecord(c->ev_done[g], st));
         BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));

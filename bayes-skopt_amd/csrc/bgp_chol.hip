@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
 }
 
 static __device__ __forceinline__ void syrk_diag_tile(GemmSmem& sm, const double* __restrict__ XI,
-                                                      double* __restrict__ C, int ld, int tid, int lane, int w) {
+                                                      double* __restrict__ C, int ld, int tid, int lane, int w,
+                                                      int K = 128) {
   // wave 0 / 1: the two 64x64 triangles on the diagonal (10 MFMA tiles each);
   // wave 2 / 3: the 64x64 square below the diagonal cut into two 32x64 halves (8 MFMA tiles each).
   // Barriers and staging are common code; only the register block differs per wave.
@@ -350,7 +351,7 @@ static __device__ __forceinline__ void syrk_diag_tile(GemmSmem& sm, const double
     gk_load_c<4, 4, 0>(C, (size_t)ld, acc, r0, c0, lane);
   else
     gk_load_c<2, 4, -64>(C, (size_t)ld, acc2, r0, c0, lane);
-  for (int k0 = 0; k0 < 128; k0 += GK_KC) {
+  for (int k0 = 0; k0 < K; k0 += GK_KC) {
     __syncthreads();
     gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
     __syncthreads();
@@ -404,6 +405,61 @@ __global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// syrk2: trailing update of the LML path with a panel of width K = 128 or 256 (two factorised block
+// columns at once: halves the C-tile traffic and the per-tile prologue/epilogue per flop).
+//   A_IJ -= X_I X_J^T,  X_I = rows of block I, columns [kp*128, kp*128 + K)
+//   colmode 1: only block column jstart (the look-ahead column the next potrf/trsm need)
+//   colmode 0: every tile with I >= J >= jstart
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
+                                                       int ld, size_t mstride, int nblk, int kp, int K, int jstart,
+                                                       int colmode, int B) {
+  const int nt = nblk - jstart;
+  const int ntile = colmode ? nt : nt * (nt + 1) / 2;
+  int b, t;
+  bgp_map_block(blockIdx.x, ntile, b, t);
+  if (b >= B || status[b] != 0) return;
+  int ti, tj;
+  if (colmode) {
+    ti = t;
+    tj = 0;
+  } else {
+    bgp_tri_decode(t, ti, tj);
+  }
+  const int I = jstart + ti, J = jstart + tj;
+  __shared__ GemmSmem sm;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+  double* M = Kbuf + (size_t)b * mstride;
+  const double* XI = M + (size_t)(I * 128) * ld + kp * 128;
+  const double* XJ = M + (size_t)(J * 128) * ld + kp * 128;
+  double* C = M + (size_t)(I * 128) * ld + J * 128;
+
+  if (I != J) {
+    d4 acc[4][4];
+    gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
+    for (int k0 = 0; k0 < K; k0 += GK_KC) {
+      __syncthreads();
+      gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+      gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
+      __syncthreads();
+      gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
+    }
+    gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
+  } else {
+    syrk_diag_tile(sm, XI, C, ld, tid, lane, w, K);
+  }
+}
+
+void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
+                      int ystride, int nblk, int k);
+
+void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
+                      double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
+  hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+                     ystride, ctx->nblk, k);
+}
+
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   return bgp_launch_cholesky_slice(ctx, 0, B, ctx->stream, augmented);
 }
@@ -422,6 +478,54 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
   double* dacc = ctx->dacc + (size_t)off * 4;
   double* dlml = ctx->dlml + off;
   int* dstatus = ctx->dstatus + off;
+  if (!augmented) {
+    // LML path: panel solve on the 4x4x4 MFMA core (bgp_llchol.hip) and two-panel trailing updates:
+    //   potrf(k) trsm(k) | syrk column k+1 (K=128) | potrf(k+1) trsm(k+1) | syrk rest (K=256, panels k,k+1)
+    int k = 0;
+    while (k < nblk) {
+      const bool pair = (k + 1 < nblk) && ctx->two_panel;
+      bgp_tbegin(ctx, 1, st);
+      hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+                         ystride, nblk, k);
+      bgp_tend(ctx, st);
+      if (k + 1 >= nblk) break;
+      bgp_tbegin(ctx, 2, st);
+      bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k);
+      bgp_tend(ctx, st);
+      if (!pair || k + 2 >= nblk) {
+        // single-panel update of everything below (also the tail when only one block column is left)
+        const int nt = nblk - (k + 1);
+        bgp_tbegin(ctx, 3, st);
+        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk,
+                           k, 128, k + 1, 0, B);
+        bgp_tend(ctx, st);
+        k += 1;
+        continue;
+      }
+      // look-ahead column k+1 with panel k
+      bgp_tbegin(ctx, 3, st);
+      hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nblk - (k + 1))), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, k,
+                         128, k + 1, 1, B);
+      bgp_tend(ctx, st);
+      bgp_tbegin(ctx, 1, st);
+      hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+                         ystride, nblk, k + 1);
+      bgp_tend(ctx, st);
+      bgp_tbegin(ctx, 2, st);
+      bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + 1);
+      bgp_tend(ctx, st);
+      {
+        const int nt = nblk - (k + 2);
+        bgp_tbegin(ctx, 3, st);
+        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk,
+                           k, 256, k + 2, 0, B);
+        bgp_tend(ctx, st);
+      }
+      k += 2;
+    }
+    BGP_HIP(hipGetLastError());
+    return BGP_OK;
+  }
   for (int k = 0; k < nblk; k++) {
     bgp_tbegin(ctx, 1, st);
     hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,

@@ -39,6 +39,9 @@ struct bgp_ctx {
   hipStream_t stream = nullptr;
   // walker groups: the batch of an LML call is split over nstreams HIP streams so that the
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
+  int two_panel = 1;     // right-looking LML path: K = 256 trailing updates (env BGP_TWO_PANEL=0 disables)
+  int lu_variant = 0;    // update-kernel variant (see LuCfg in bgp_llchol.hip); env BGP_LU_VARIANT
+  int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)
   int nstreams = 1;
   hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};
   hipEvent_t ev_ready = nullptr;
@@ -127,3 +130,6 @@ int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);
+// LML path: left-looking update with fused kernel-matrix generation (bgp_llchol.hip); replaces
+// bgp_launch_kbuild_slice + bgp_launch_cholesky_slice(augmented = 0)
+int bgp_launch_cholesky_ll_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha);

@@ -35,3 +35,35 @@ static __device__ __forceinline__ void bgp_tri_decode(int t, int& ti, int& tj) {
   tj = t - r * (r + 1) / 2;
 }
 
+// Compile-time stationary kernel (same operation order as sklearn/kernels.py:1553-1560, 1713-1733;
+// the Matern-5/2 term K**2/3.0 is evaluated as t*t*(1/3): <= 1 ulp from the reference's division).
+template <int STAT>
+static __device__ __forceinline__ double kb_stationary(double r2) {
+  if (STAT == BGP_RBF) return exp(-0.5 * r2);
+  const double dist = sqrt(r2);
+  if (STAT == BGP_MATERN12) return exp(-dist);
+  if (STAT == BGP_MATERN32) {
+    const double t = dist * 1.7320508075688772;  // math.sqrt(3)
+    return (1.0 + t) * exp(-t);
+  }
+  const double t = dist * 2.23606797749979;  // math.sqrt(5)
+  return (1.0 + t + t * t * 0.3333333333333333) * exp(-t);
+}
+
+
+// (stationary, form) -> instantiation
+#define KB_DISPATCH(STATV, FORMV, CALL)                                      \
+  do {                                                                       \
+    const int key__ = (STATV)*2 + (FORMV);                                   \
+    switch (key__) {                                                         \
+      case 0: { constexpr int S = 0, F = 0; CALL; } break;                   \
+      case 1: { constexpr int S = 0, F = 1; CALL; } break;                   \
+      case 2: { constexpr int S = 1, F = 0; CALL; } break;                   \
+      case 3: { constexpr int S = 1, F = 1; CALL; } break;                   \
+      case 4: { constexpr int S = 2, F = 0; CALL; } break;                   \
+      case 5: { constexpr int S = 2, F = 1; CALL; } break;                   \
+      case 6: { constexpr int S = 3, F = 0; CALL; } break;                   \
+      default: { constexpr int S = 3, F = 1; CALL; } break;                  \
+    }                                                                        \
+  } while (0)
+

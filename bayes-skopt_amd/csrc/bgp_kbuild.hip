@@ -14,21 +14,6 @@
 
 #define KB_DK 16  // input dimensions staged per pass
 
-// Compile-time stationary kernel (same operation order as sklearn/kernels.py:1553-1560, 1713-1733;
-// the Matern-5/2 term K**2/3.0 is evaluated as t*t*(1/3): <= 1 ulp from the reference's division).
-template <int STAT>
-static __device__ __forceinline__ double kb_stationary(double r2) {
-  if (STAT == BGP_RBF) return exp(-0.5 * r2);
-  const double dist = sqrt(r2);
-  if (STAT == BGP_MATERN12) return exp(-dist);
-  if (STAT == BGP_MATERN32) {
-    const double t = dist * 1.7320508075688772;  // math.sqrt(3)
-    return (1.0 + t) * exp(-t);
-  }
-  const double t = dist * 2.23606797749979;  // math.sqrt(5)
-  return (1.0 + t + t * t * 0.3333333333333333) * exp(-t);
-}
-
 // Generic tile body: out[(i0+..)][(j0+..)] = k(A_i, B_j); A is (na x d), Bm is (nb x d), row-major.
 // GRAM != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.
 // Tiles that are fully inside the data and off the diagonal take a check-free epilogue.
@@ -153,22 +138,6 @@ __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restr
   const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
   kbuild_tile<0, STAT, FORM>(Xq, m, Xt, n, d, h, nullptr, ti * 128, tj * 128, out, (size_t)ldo, m, n);
 }
-
-// (stationary, form) -> instantiation
-#define KB_DISPATCH(STATV, FORMV, CALL)                                      \
-  do {                                                                       \
-    const int key__ = (STATV)*2 + (FORMV);                                   \
-    switch (key__) {                                                         \
-      case 0: { constexpr int S = 0, F = 0; CALL; } break;                   \
-      case 1: { constexpr int S = 0, F = 1; CALL; } break;                   \
-      case 2: { constexpr int S = 1, F = 0; CALL; } break;                   \
-      case 3: { constexpr int S = 1, F = 1; CALL; } break;                   \
-      case 4: { constexpr int S = 2, F = 0; CALL; } break;                   \
-      case 5: { constexpr int S = 2, F = 1; CALL; } break;                   \
-      case 6: { constexpr int S = 3, F = 0; CALL; } break;                   \
-      default: { constexpr int S = 3, F = 1; CALL; } break;                  \
-    }                                                                        \
-  } while (0)
 
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
   return bgp_launch_kbuild_slice(ctx, 0, B, ctx->stream, full_square, augmented, use_alpha);
