@@ -177,7 +177,7 @@ def main():
         pass
     roofline = {
         "bound": "mfma",
-        "kernel": "syrk_kernel (blocked-Cholesky trailing update, fp64 v_mfma_f64_16x16x4_f64)",
+        "kernel": "syrk2_kernel (blocked-Cholesky trailing update, two-panel K=256, fp64 v_mfma_f64_16x16x4_f64)",
         "achieved": achieved,
         "peak": FP64_MFMA_PEAK_TFLOPS,
         "unit": "TFLOP/s",
