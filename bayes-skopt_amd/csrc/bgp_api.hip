@@ -150,8 +150,6 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     if (ns < 1) ns = 1;
     if (ns > BGP_MAX_STREAMS) ns = BGP_MAX_STREAMS;
     c->nstreams = ns;
-    const char* envv = getenv("BGP_LU_VARIANT");
-    c->lu_variant = envv ? atoi(envv) : 0;
     const char* envl = getenv("BGP_LEFT_LOOKING");
     c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");

@@ -40,7 +40,6 @@ struct bgp_ctx {
   // walker groups: the batch of an LML call is split over nstreams HIP streams so that the
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
   int two_panel = 1;     // right-looking LML path: K = 256 trailing updates (env BGP_TWO_PANEL=0 disables)
-  int lu_variant = 0;    // update-kernel variant (see LuCfg in bgp_llchol.hip); env BGP_LU_VARIANT
   int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)
   int nstreams = 1;
   hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};

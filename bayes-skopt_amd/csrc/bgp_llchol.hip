@@ -1,4 +1,7 @@
+// EXPERIMENTAL (enabled with BGP_LEFT_LOOKING=1; the default LML path is the right-looking two-panel
+// schedule of bgp_chol.hip, which is faster on every measured configuration -- DESIGN.md section 6).
 // Left-looking blocked Cholesky of the LML path on the fast fp64 MFMA form (v_mfma_f64_4x4x4_4b_f64).
+// trsm8_kernel below IS on the default path.
 //
 // Step J (block column J, nb = 128), batched over the B walkers, three launches:
 //   lupdate_kernel  one 512-thread workgroup per tile (I, J), I >= J:
@@ -105,72 +108,40 @@ static __device__ __forceinline__ void lu_generate_tile(GemmSmem& sm, const doub
       }
 }
 
-// Main loop selector: V = 0: 8 waves x (32x64), 4x4x4 MFMA, register prefetch (one workgroup per CU)
-//                     V = 1: 4 waves x (64x64), 4x4x4 MFMA, no prefetch (two workgroups per CU overlap)
-//                     V = 2: 4 waves x (64x64), 16x16x4 MFMA, no prefetch
-template <int V> struct LuCfg;
-template <> struct LuCfg<0> { static constexpr int NR = 2, NC = 4, THREADS = 512, WPE = 1; };
-template <> struct LuCfg<1> { static constexpr int NR = 4, NC = 4, THREADS = 256, WPE = 1; };
-template <> struct LuCfg<2> { static constexpr int NR = 4, NC = 4, THREADS = 256, WPE = 1; };
-
-template <int V, int SAMEB>
-static __device__ __forceinline__ void lu_mainloop(GemmSmem& sm, const double* __restrict__ A,
-                                                   const double* __restrict__ Bm, size_t ld, int K,
-                                                   d4 (&acc)[LuCfg<V>::NR][LuCfg<V>::NC], int r0, int c0, int tid,
-                                                   int lane) {
-  if (V == 0) {
-    g8_mainloop<LuCfg<V>::NR, LuCfg<V>::NC, 1, 0, -64, SAMEB>(sm, A, ld, Bm, ld, K, acc, r0, c0, tid, lane);
-  } else {
-    for (int k0 = 0; k0 < K; k0 += GK_KC) {
-      __syncthreads();
-      gk_load_chunk(sm.A, A + k0, ld, tid);
-      if (!SAMEB) gk_load_chunk(sm.B, Bm + k0, ld, tid);
-      __syncthreads();
-      if (V == 1)
-        g8_mma_block<LuCfg<V>::NR, LuCfg<V>::NC, 1, 0, -64>(sm.A, SAMEB ? sm.A : sm.B, acc, r0, c0, lane, k0);
-      else
-        gk_mma_block<LuCfg<V>::NR, LuCfg<V>::NC, 1, 0, -64>(sm.A, SAMEB ? sm.A : sm.B, acc, r0, c0, lane, k0);
-    }
-  }
-}
-
-// GEN != 0: the K tile is generated in registers (fused K-build); GEN == 0: it was written by
-// kbuild_gram_kernel and is loaded as the initial accumulator (lower register pressure).
-template <int STAT, int FORM, int V, int GEN>
-__global__ void __launch_bounds__(LuCfg<V>::THREADS, LuCfg<V>::WPE) lupdate_kernel(
-    const double* __restrict__ X, const double* __restrict__ alpha, const double* __restrict__ H,
-    double* __restrict__ Kbuf, const double* __restrict__ y, double* __restrict__ yw, const int* __restrict__ status,
-    int n, int d, int ld, size_t mstride, int nblk, int J, int B) {
-  constexpr int NR = LuCfg<V>::NR, NC = LuCfg<V>::NC, THREADS = LuCfg<V>::THREADS;
+template <int STAT, int FORM>
+__global__ void __launch_bounds__(G8_THREADS) lupdate_kernel(const double* __restrict__ X,
+                                                              const double* __restrict__ alpha,
+                                                              const double* __restrict__ H,
+                                                              double* __restrict__ Kbuf,
+                                                              const double* __restrict__ y, double* __restrict__ yw,
+                                                              const int* __restrict__ status, int n, int d, int ld,
+                                                              size_t mstride, int nblk, int J, int B) {
   const int ntile = nblk - J;
   int b, t;
   bgp_map_block(blockIdx.x, ntile, b, t);
   if (b >= B || status[b] != 0) return;
   const int I = J + t;
   __shared__ GemmSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r0 = (V == 0) ? (w >> 1) * 32 : (w >> 1) * 64, c0 = (w & 1) * 64;
+  // 8 waves as 4 (rows) x 2 (cols): wave (wr, wc) owns the 32 x 64 block at (32 wr, 64 wc)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r0 = (w >> 1) * 32, c0 = (w & 1) * 64;
   double* M = Kbuf + (size_t)b * mstride;
   // working right-hand side: every block is initialised at step 0 (the panel solves of the earlier
   // steps already subtract from the blocks below them)
-  if (GEN && J == 0 && tid < 128) yw[(size_t)b * ld + I * 128 + tid] = y[I * 128 + tid];
+  if (J == 0 && tid < 128) yw[(size_t)b * ld + I * 128 + tid] = y[I * 128 + tid];
 
-  d4 acc[NR][NC];
-  if (GEN)
-    lu_generate_tile<STAT, FORM, NR, NC, THREADS>(sm, X, n, d, H + (size_t)b * (d + 2), alpha, I, J, acc, r0, c0, tid,
-                                                  lane);
-  else
-    gk_load_c<NR, NC, -64>(M + (size_t)(I * 128) * ld + J * 128, (size_t)ld, acc, r0, c0, lane);
+  d4 acc[2][4];
+  lu_generate_tile<STAT, FORM, 2, 4, G8_THREADS>(sm, X, n, d, H + (size_t)b * (d + 2), alpha, I, J, acc, r0, c0, tid,
+                                                 lane);
   const int K = J * 128;
   if (K > 0) {
     const double* LI = M + (size_t)(I * 128) * ld;  // row panel L(I, 0 : K)
     const double* LJ = M + (size_t)(J * 128) * ld;  // row panel L(J, 0 : K)
     if (I != J)
-      lu_mainloop<V, 0>(sm, LI, LJ, (size_t)ld, K, acc, r0, c0, tid, lane);
+      g8_mainloop<2, 4, 1, 0, -64, 0>(sm, LI, (size_t)ld, LJ, (size_t)ld, K, acc, r0, c0, tid, lane);
     else
-      lu_mainloop<V, 1>(sm, LI, LI, (size_t)ld, K, acc, r0, c0, tid, lane);
+      g8_mainloop<2, 4, 1, 0, -64, 1>(sm, LI, (size_t)ld, LI, (size_t)ld, K, acc, r0, c0, tid, lane);
   }
-  gk_store_c<NR, NC, -64>(M + (size_t)(I * 128) * ld + J * 128, (size_t)ld, acc, r0, c0, lane);
+  gk_store_c<2, 4, -64>(M + (size_t)(I * 128) * ld + J * 128, (size_t)ld, acc, r0, c0, lane);
 }
 
 // Panel solve on the 8-wave 4x4x4 core: X = T W^T (W lower triangular: k-skip), y_I -= X z_J.
@@ -241,25 +212,11 @@ int bgp_launch_cholesky_ll_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, i
   const double* dH = ctx->dh + (size_t)off * (ctx->d + 2);
   const double* dalpha = ctx->dalpha;  // (use_alpha is always 1 on the LML path)
   (void)use_alpha;
-  if (ctx->lu_variant != 0) {  // separate K-build pass (also initialises the working right-hand sides)
-    int rc = bgp_launch_kbuild_slice(ctx, off, B, st, 0, 0, 1);
-    if (rc) return rc;
-  }
   for (int J = 0; J < nblk; J++) {
     bgp_tbegin(ctx, J == 0 ? 0 : 3, st);  // step 0 is pure kernel-matrix generation
-#define LU_LAUNCH_GEN(VV)                                                                                             \
-  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,                                                                       \
-              hipLaunchKernelGGL((lupdate_kernel<S, F, VV, 1>), dim3(B8 * (nblk - J)), dim3(LuCfg<VV>::THREADS), 0, st, \
-                                 ctx->dX, dalpha, dH, dK, ctx->dy, dyw, dstatus, ctx->n, ctx->d, ld, mstride, nblk, J, B))
-#define LU_LAUNCH_LOAD(VV)                                                                                           \
-  hipLaunchKernelGGL((lupdate_kernel<3, 0, VV, 0>), dim3(B8 * (nblk - J)), dim3(LuCfg<VV>::THREADS), 0, st, ctx->dX,   \
-                     dalpha, dH, dK, ctx->dy, dyw, dstatus, ctx->n, ctx->d, ld, mstride, nblk, J, B)
-    switch (ctx->lu_variant) {
-      case 0: LU_LAUNCH_GEN(0); break;                    // fused K-generation, 8 waves, 4x4x4, prefetch
-      case 1: if (J > 0) LU_LAUNCH_LOAD(1); break;        // kbuild pass + 4 waves 4x4x4, 2 WG/CU
-      case 2: if (J > 0) LU_LAUNCH_LOAD(2); break;        // kbuild pass + 4 waves 16x16x4, 2 WG/CU
-      default: if (J > 0) LU_LAUNCH_LOAD(0); break;       // kbuild pass + 8 waves 4x4x4, prefetch
-    }
+    KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+                hipLaunchKernelGGL((lupdate_kernel<S, F>), dim3(B8 * (nblk - J)), dim3(G8_THREADS), 0, st, ctx->dX,
+                                   dalpha, dH, dK, ctx->dy, dyw, dstatus, ctx->n, ctx->d, ld, mstride, nblk, J, B));
     bgp_tend(ctx, st);
     bgp_tbegin(ctx, 1, st);
     bgp_launch_potrf(ctx, st, B, dK, dW, dyw, dacc, dlml, dstatus, ld, mstride, ld, J);

@@ -36,11 +36,11 @@ def init_process_group(backend=None):
         dist = _dist()
         if not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("BGP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             if backend == "nccl":
-                torch.cuda.set_device(local_rank)
+                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=rank, world_size=ws)
     return rank, local_rank, ws
 

@@ -121,7 +121,8 @@ def main():
         if ws > 1:
             import torch
 
-            torch.cuda.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
 
     state = sampler.run_mcmc(pos, max(args.warmup, 1))  # also evaluates the initial ensemble
     pos, lp = state.coords, state.log_prob

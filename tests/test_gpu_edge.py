@@ -126,3 +126,30 @@ def test_predict_interpolates_smooth_training_points_with_tiny_noise(lib):
     np.testing.assert_allclose(mean[0], y[:50], atol=2e-4)
     assert np.all(var[0] < 1e-5)
     ctx.close()
+
+
+def test_left_looking_and_single_panel_variants_agree(lib, O):
+    """The experimental left-looking update (fused K-generation, 4x4x4 MFMA) and the single-panel
+    right-looking schedule must give the same LML as the default two-panel schedule."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib;"
+        "rng=np.random.RandomState(5); n,d=700,6; X=rng.uniform(size=(n,d)); y=np.sin(3*X.sum(1));"
+        "H=np.concatenate([[0.],np.full(d,np.log(.4)),[np.log(.02)]])+0.1*np.random.RandomState(6).randn(5,d+2);"
+        "c=_lib.Context(X,y,1e-10,max_batch=8); print(repr(c.lml(H).tolist()))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "2"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o, outs[0], rtol=1e-9)
+    rng = np.random.RandomState(5)
+    X = rng.uniform(size=(700, 6))
+    y = np.sin(3 * X.sum(1))
+    H = np.concatenate([[0.0], np.full(6, np.log(0.4)), [np.log(0.02)]]) + 0.1 * np.random.RandomState(6).randn(5, 8)
+    np.testing.assert_allclose(outs[0], O.lml_batch(X, y, np.full(700, 1e-10), H), rtol=RTOL)
