@@ -45,6 +45,9 @@ SIGNATURES = {
     "bgp_ctx_update_data": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "bgp_ctx_destroy": (None, [_vp]),
     "bgp_lml_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _ip]),
+    "bgp_lml_batch_warped": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip]),
+    "bgp_ctx_set_warp": (C.c_int, [_vp, _dp]),
+    "bgp_beta_cdf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "bgp_lml_grad_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip]),
     "bgp_kernel_matrix": (C.c_int, [_vp, _dp, _dp]),
     "bgp_posterior_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
@@ -161,6 +164,34 @@ class Context:
         st = np.zeros(B, dtype=np.int32)
         _check(self._lib.bgp_lml_batch(self._h, B, _p(H), _p(out), _p(st)), "bgp_lml_batch")
         return (out, st) if return_status else out
+
+    def lml_warped(self, H, W, return_status=False):
+        """Per-walker warp: W is (B, 2d) log-space Beta parameters [wa_1..wa_d, wb_1..wb_d]."""
+        H = self._H(H)
+        W = _c(np.atleast_2d(W))
+        B = H.shape[0]
+        if W.shape != (B, 2 * self.d):
+            raise ValueError(f"warp parameters must be (B, 2d) = ({B}, {2 * self.d}), got {W.shape}")
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_lml_batch_warped(self._h, B, _p(H), _p(W), _p(out), _p(st)), "bgp_lml_batch_warped")
+        return (out, st) if return_status else out
+
+    def set_warp(self, w):
+        """Context-level warp (2d log-space parameters) or None to clear."""
+        self.resident_H = None
+        if w is None:
+            _check(self._lib.bgp_ctx_set_warp(self._h, C.cast(None, _dp)), "bgp_ctx_set_warp")
+            return
+        w = _c(w).reshape(2 * self.d)
+        _check(self._lib.bgp_ctx_set_warp(self._h, _p(w)), "bgp_ctx_set_warp")
+
+    def beta_cdf(self, X, w):
+        X = _c(np.atleast_2d(X))
+        w = _c(w).reshape(2 * self.d)
+        out = np.empty_like(X)
+        _check(self._lib.bgp_beta_cdf(self._h, X.shape[0], _p(X), _p(w), _p(out)), "bgp_beta_cdf")
+        return out
 
     def lml_grad(self, H):
         H = self._H(H)

@@ -28,7 +28,7 @@ from . import _lib
 from .kernels import ConstantKernel, WhiteKernel, analyse_kernel, param_for_white_kernel_in_sum
 from .kernels import RBF as _RBF
 from .sampler import EnsembleSampler
-from .utils import geometric_median, guess_priors
+from .utils import geometric_median, guess_priors, validate_zeroone
 
 __all__ = ["BayesGPR"]
 
@@ -67,12 +67,7 @@ class BayesGPR:
         self.optimizer = optimizer
         self.n_restarts_optimizer = n_restarts_optimizer
         self.normalize_y = normalize_y
-        if warp_inputs:
-            raise NotImplementedError(
-                "warp_inputs=True (input warping, bask/bayesgpr.py:219-316) is not available on the "
-                "MI355X path yet (SURVEY.md 8f row f3)"
-            )
-        self.warp_inputs = False
+        self.warp_inputs = bool(warp_inputs)
         self.copy_X_train = copy_X_train
         self.random_state = check_random_state(random_state)
         self.noise = noise
@@ -113,7 +108,22 @@ class BayesGPR:
         self._ctx, self._plan = ctx, plan
         self._post_theta = None
         self._L = self._K_inv = None
+        self._install_warp()
         return ctx
+
+    def _warp_vector(self):
+        """[wa_1..wa_d, wb_1..wb_d] of the current warpers, or None (identity)."""
+        if self.warp_inputs and hasattr(self, "warp_alphas_"):
+            return np.concatenate([self.warp_alphas_, self.warp_betas_])
+        return None
+
+    def _install_warp(self):
+        """Make the device context see the training inputs (and later query points) through the current
+        warpers -- the role of ``rewarp()`` in the reference (``bask/bayesgpr.py:284-295``)."""
+        if self._ctx is not None:
+            self._ctx.set_warp(self._warp_vector())
+            self._post_theta = None
+            self._L = self._K_inv = None
 
     def _canonical(self, theta):
         return self._plan.canonical(theta, self._X_train_.shape[1])
@@ -193,25 +203,57 @@ class BayesGPR:
 
     @property
     def X_train_(self):
-        return getattr(self, "_X_train_", None)
+        """Training inputs; the WARPED ones when ``warp_inputs`` and warpers exist
+        (``bask/bayesgpr.py:219-235``)."""
+        X = getattr(self, "_X_train_", None)
+        if X is not None and self.warp_inputs and hasattr(self, "warp_alphas_") and self._ctx is not None:
+            return self.warp(X)
+        return X
 
     @X_train_.setter
     def X_train_(self, X_train):
         X_train = np.asarray(X_train, dtype=np.float64)
         self._X_train_ = np.copy(X_train) if self.copy_X_train else X_train
 
-    # ------------------------------------------------------------------ warping API (identity)
+    # ------------------------------------------------------------------ input warping
     def warp(self, X):
-        return X
+        """Beta-CDF warp of X with the current warpers, evaluated on the device; identity when
+        ``warp_inputs=False`` or before the first fit (``bask/bayesgpr.py:249-264``)."""
+        w = self._warp_vector()
+        if w is None or self._ctx is None:
+            return X
+        return self._ctx.beta_cdf(np.atleast_2d(np.asarray(X, dtype=np.float64)), w)
 
     def unwarp(self, X):
-        return X
+        """Inverse warp (Beta quantile function per column, ``bask/bayesgpr.py:266-282``).  Only used to
+        GENERATE candidate points (``bask/optimizer.py:353-357``); host-side scipy."""
+        if not (self.warp_inputs and hasattr(self, "warp_alphas_")):
+            return X
+        import scipy.stats as st
+
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        out = np.empty_like(X)
+        for col, (a_log, b_log) in enumerate(zip(self.warp_alphas_, self.warp_betas_)):
+            out[:, col] = st.beta(a=np.exp(a_log), b=np.exp(b_log)).ppf(X[:, col])
+        return out
 
     def rewarp(self):
-        pass
+        """Apply the current warpers to the resident training inputs again."""
+        if self.warp_inputs:
+            self._install_warp()
 
     def create_warpers(self, alphas, betas):
-        pass
+        """Set the Beta-CDF parameters (log space) of every input column
+        (``bask/bayesgpr.py:297-316``).  ``warpers_`` / ``unwarpers_`` are kept as host callables for
+        API compatibility; the device evaluates the warp itself."""
+        if self.warp_inputs:
+            import scipy.stats as st
+
+            self.warp_alphas_ = np.copy(np.asarray(alphas, dtype=np.float64))
+            self.warp_betas_ = np.copy(np.asarray(betas, dtype=np.float64))
+            dists = [st.beta(a=np.exp(a), b=np.exp(b)) for a, b in zip(self.warp_alphas_, self.warp_betas_)]
+            self.warpers_ = [dist.cdf for dist in dists]
+            self.unwarpers_ = [dist.ppf for dist in dists]
 
     @contextmanager
     def noise_set_to_zero(self):
@@ -236,18 +278,26 @@ class BayesGPR:
             self.alpha = alpha
 
     # ------------------------------------------------------------------ log posterior
-    def _log_prob_batch(self, Theta, priors):
+    def _log_prob_batch(self, Theta, priors, warp_priors=None):
         """Vectorised ``_log_prob_fn`` (``bask/bayesgpr.py:351-379``): sum of priors (host) + LML
-        (device) for a (Ns, p) block; non-finite -> -inf."""
+        (device) for a (Ns, p) block; non-finite -> -inf.  With ``warp_inputs`` the last 2d columns are
+        the Beta-CDF parameters of each walker's own input warp (``:353-365``)."""
         Theta = np.atleast_2d(Theta)
-        lp = _eval_priors(priors, Theta)
-        with np.errstate(invalid="ignore"):
-            lp = lp + self._ctx.lml(self._canonical(Theta))
+        if self.warp_inputs:
+            d = self._X_train_.shape[1]
+            Tgp, W = Theta[:, : Theta.shape[1] - 2 * d], Theta[:, Theta.shape[1] - 2 * d :]
+            lp = _eval_priors(priors, Tgp) + _eval_warp_priors(warp_priors, W, d)
+            with np.errstate(invalid="ignore"):
+                lp = lp + self._ctx.lml_warped(self._canonical(Tgp), W)
+        else:
+            lp = _eval_priors(priors, Theta)
+            with np.errstate(invalid="ignore"):
+                lp = lp + self._ctx.lml(self._canonical(Theta))
         lp[~np.isfinite(lp)] = -np.inf
         return lp
 
     def _log_prob_fn(self, x, priors, warp_priors=None):
-        return float(self._log_prob_batch(np.asarray(x, dtype=np.float64)[None, :], priors)[0])
+        return float(self._log_prob_batch(np.asarray(x, dtype=np.float64)[None, :], priors, warp_priors)[0])
 
     # ------------------------------------------------------------------ sample
     def sample(
@@ -276,6 +326,10 @@ class BayesGPR:
             )
         if priors is None:
             priors = guess_priors(self.kernel_)
+        if warp_priors is None:
+            import scipy.stats as st
+
+            warp_priors = (st.norm(loc=0.0, scale=0.3).logpdf, st.norm(loc=0.0, scale=0.3).logpdf)
 
         if X is not None:
             X = np.asarray(X, dtype=np.float64)
@@ -304,9 +358,15 @@ class BayesGPR:
             pos = position
         elif self.pos_ is not None:
             pos = self.pos_
+        n_theta = n_dim
+        if self.warp_inputs:
+            added_dims = self._X_train_.shape[1] * 2
+            n_dim += added_dims
         if pos is None:
             theta = self.theta
             theta[np.isinf(theta)] = np.log(self.noise_)
+            if self.warp_inputs:
+                theta = np.concatenate([theta, np.zeros(added_dims)])
             pos = [theta + 1e-2 * self.random_state.randn(n_dim) for _ in range(n_walkers)]
 
         self._ensure_context(batch_hint=(n_walkers + 1) // 2)
@@ -314,7 +374,7 @@ class BayesGPR:
             nwalkers=n_walkers,
             ndim=n_dim,
             log_prob_fn=self._log_prob_batch,
-            kwargs=dict(priors=priors),
+            kwargs=dict(priors=priors, warp_priors=warp_priors),
             threads=n_threads,
             **kwargs,
         )
@@ -326,7 +386,15 @@ class BayesGPR:
             self.chain_ = np.concatenate([self.chain_, chain])
         else:
             self.chain_ = chain
-        self.theta = geometric_median(self.chain_)
+        if self.warp_inputs:
+            median = geometric_median(self.chain_)
+            d = self._X_train_.shape[1]
+            warp_params = median[n_theta:]
+            self.create_warpers(warp_params[:d], warp_params[d:])
+            self.rewarp()
+            self.theta = median[:n_theta]
+        else:
+            self.theta = geometric_median(self.chain_)
         self.log_marginal_likelihood_value_ = self.log_marginal_likelihood(self.kernel_.theta, clone_kernel=False)
         self.pos_ = pos
 
@@ -461,7 +529,9 @@ class BayesGPR:
         if return_mean_grad or return_std_grad:
             raise NotImplementedError("prediction gradients are not implemented on the MI355X path")
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
-        if self._post_theta is None or self.X_train_ is None:
+        if self.warp_inputs:
+            validate_zeroone(X)  # the device warps the query points with the context-level warp
+        if self._post_theta is None or getattr(self, "_X_train_", None) is None:
             raise RuntimeError("predict before fit is not supported on the MI355X path")
         self._make_resident()
         Hk = self._canonical(self._kernel_theta_for_predict())
@@ -487,6 +557,8 @@ class BayesGPR:
         ``evaluate_acquisitions`` does one ``gpr.theta = chain_[i]`` at a time,
         ``bask/acquisition.py:112-125``): ONE batched device build, ONE batched predict."""
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if self.warp_inputs:
+            return self._predict_hyper_samples_warped(np.atleast_2d(thetas), X, noise_zero)
         H = self._canonical(np.atleast_2d(thetas))
         res = self._ctx.posterior(H, want_alpha=False)
         if np.any(res["status"] != 0):
@@ -501,6 +573,32 @@ class BayesGPR:
         mean, var = self._ctx.predict(Hk, X)
         mu = self.y_train_std_ * mean + self.y_train_mean_
         return mu, np.sqrt(var * self.y_train_std_**2)
+
+    def _predict_hyper_samples_warped(self, rows, X, noise_zero):
+        """With input warping every hyper-posterior draw carries its own warp, i.e. its own training
+        inputs: one posterior build + predict per draw (``bask/acquisition.py:113-119``), all on the
+        device; the warpers are restored afterwards (``:142-145``)."""
+        validate_zeroone(X)
+        n_theta = len(self.kernel_.theta)
+        d = self._X_train_.shape[1]
+        backup = (np.copy(self.warp_alphas_), np.copy(self.warp_betas_))
+        mus, stds = [], []
+        for row in rows:
+            self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
+            self.rewarp()
+            H = self._canonical(row[:n_theta][None, :])
+            res = self._ctx.posterior(H, want_alpha=False)
+            if res["status"][0] != 0:
+                raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % res["status"][0])
+            Hk = H.copy()
+            if noise_zero:
+                Hk[:, -1] = -np.inf
+            mean, var = self._ctx.predict(Hk, X)
+            mus.append(self.y_train_std_ * mean[0] + self.y_train_mean_)
+            stds.append(np.sqrt(var[0] * self.y_train_std_**2))
+        self.create_warpers(*backup)
+        self.rewarp()
+        return np.array(mus), np.array(stds)
 
     def _pvrs(self, X, thompson_points, has_alpha_vec):
         """Device side of PVRS / VarianceReduction (``bask/acquisition.py:287-300,328-338``)."""
@@ -524,12 +622,24 @@ class BayesGPR:
         current_theta = self.theta
         saved = (self._post_theta, self.alpha_, self._L, self._K_inv)
         result = np.empty((X.shape[0], n_samples))
+        n_theta = len(current_theta)
+        if self.warp_inputs:
+            validate_zeroone(X)
+            warp_backup = (np.copy(self.warp_alphas_), np.copy(self.warp_betas_))
+            d = self._X_train_.shape[1]
         for i, j in enumerate(ind):
-            self.theta = self.chain_[j]
+            row = self.chain_[j]
+            if self.warp_inputs:
+                self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
+                self.rewarp()
+            self.theta = row[:n_theta]
             cm = nullcontext(self) if noise else self.noise_set_to_zero()
             with cm:
                 result[:, i] = self._draw(X, 1, rng).flatten()
         self.kernel_.theta = current_theta
+        if self.warp_inputs:  # the reference restores only the parameter arrays (bask/bayesgpr.py:714-716);
+            self.create_warpers(*warp_backup)  # here the warp itself is restored as well
+            self.rewarp()
         self._post_theta, self.alpha_, self._L, self._K_inv = saved
         return result
 
@@ -557,6 +667,32 @@ class BayesGPR:
                 ctx.close()
             except Exception:
                 pass
+
+
+def _eval_warp_priors(warp_priors, W, d):
+    """Log-prior of the warp parameters (``bask/bayesgpr.py:360-365``): a pair of callables applied to
+    every (alpha_k, beta_k), or one callable of both."""
+    lp = np.zeros(W.shape[0])
+    A, Bm = W[:, :d], W[:, d:]
+    if isinstance(warp_priors, (list, tuple)):
+        for k in range(d):
+            lp += _vec_call(warp_priors[0], A[:, k]) + _vec_call(warp_priors[1], Bm[:, k])
+    else:
+        for k in range(d):
+            lp += np.array([float(warp_priors(a, b)) for a, b in zip(A[:, k], Bm[:, k])])
+    return lp
+
+
+def _vec_call(fn, col):
+    try:
+        with np.errstate(all="ignore"):
+            v = np.asarray(fn(col), dtype=np.float64)
+        if v.shape == col.shape:
+            return v
+    except Exception:
+        pass
+    with np.errstate(all="ignore"):
+        return np.array([float(fn(t)) for t in col])
 
 
 def _eval_priors(priors, Theta):

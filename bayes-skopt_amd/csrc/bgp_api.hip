@@ -37,7 +37,10 @@ static int alloc_data(bgp_ctx* c, int n) {
     free_dev(c->dX);
     free_dev(c->dy);
     free_dev(c->dalpha);
-    c->dX = c->dy = c->dalpha = nullptr;
+    free_dev(c->dXw1);
+    free_dev(c->dXwB);
+    c->dX = c->dy = c->dalpha = c->dXw1 = c->dXwB = nullptr;
+    c->cap_xwb = 0;
     BGP_HIP(hipMalloc(&c->dX, npad * c->d * sizeof(double)));
     BGP_HIP(hipMalloc(&c->dy, npad * sizeof(double)));
     BGP_HIP(hipMalloc(&c->dalpha, npad * sizeof(double)));
@@ -106,6 +109,8 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
   BGP_HIP(hipMemcpyAsync(c->dalpha, ap.data(), c->npad * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipStreamSynchronize(c->stream));
   c->post_B = 0;
+  c->has_warp = 0;  // new data: the caller re-installs the warp (bgp_ctx_set_warp)
+  c->dXeff = c->dX;
   return BGP_OK;
 }
 
@@ -206,6 +211,10 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dstatus);
   free_dev(c->dalpha_sol);
   free_dev(c->dKinv);
+  free_dev(c->dXw1);
+  free_dev(c->dXwB);
+  free_dev(c->dwarp);
+  free_dev(c->dwarpB);
   free_dev(c->dscratch);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
@@ -237,13 +246,40 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
   return BGP_OK;
 }
 
+static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status);
+
 extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, int* status) {
   if (!c || !h || !lml || B < 0) {
     bgp_set_error("bgp_lml_batch: bad argument");
     return BGP_ERR_INVALID;
   }
+  return lml_batch_impl(c, B, h, nullptr, lml, status);
+}
+
+extern "C" int bgp_lml_batch_warped(bgp_ctx* c, int B, const double* h, const double* warp, double* lml,
+                                    int* status) {
+  if (!c || !h || !warp || !lml || B < 0) {
+    bgp_set_error("bgp_lml_batch_warped: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  return lml_batch_impl(c, B, h, warp, lml, status);
+}
+
+static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status) {
   if (B == 0) return BGP_OK;
   BGP_HIP(hipSetDevice(c->device));
+  const size_t nd = (size_t)c->n * c->d;
+  if (warp) {
+    const size_t need = (size_t)c->max_batch * nd;
+    if (need > c->cap_xwb) {
+      free_dev(c->dXwB);
+      c->dXwB = nullptr;
+      c->cap_xwb = 0;
+      BGP_HIP(hipMalloc(&c->dXwB, need * sizeof(double)));
+      c->cap_xwb = need;
+    }
+    if (!c->dwarpB) BGP_HIP(hipMalloc(&c->dwarpB, (size_t)c->max_batch * 2 * c->d * sizeof(double)));
+  }
   const size_t p = c->d + 2;
   for (int k = 0; k < 5; k++) c->t_ms[k] = 0.0;
   for (int k = 0; k < 4; k++) c->t_cnt[k] = 0;
@@ -258,14 +294,24 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
     // walker groups on separate streams (sizes are multiples of 8: one matrix slot per XCD)
     int ng = c->nstreams;
     int gsz = ((nb + ng - 1) / ng + 7) / 8 * 8;
-    if (ng == 1 || nb < 16) {
+    if (ng == 1 || nb < 16 || warp) {
       ng = 1;
       gsz = nb;
     }
     BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     int rc = BGP_OK;
-    if (ng == 1) {
+    if (warp) {
+      // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
+      BGP_HIP(hipMemcpyAsync(c->dwarpB, warp + (size_t)off * 2 * c->d, (size_t)nb * 2 * c->d * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+      rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
+      if (rc) return rc;
+      rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
+      if (rc) return rc;
+      rc = bgp_launch_cholesky(c, nb, 0);
+      if (rc) return rc;
+    } else if (ng == 1) {
       if (c->left_looking) {
         rc = bgp_launch_cholesky_ll_slice(c, 0, nb, c->stream, 1);
       } else {

@@ -46,7 +46,14 @@ struct bgp_ctx {
   hipEvent_t ev_ready = nullptr;
   hipEvent_t ev_done[BGP_MAX_STREAMS] = {nullptr};
   // resident training set
-  double* dX = nullptr;      // n*d
+  double* dX = nullptr;      // n*d  (original inputs)
+  double* dXeff = nullptr;   // what the kernels read: dX, or dXw1 when a context-level warp is set
+  double* dXw1 = nullptr;    // training inputs through the context-level Beta-CDF warp
+  double* dXwB = nullptr;    // per-walker warped inputs of a warped LML batch (max_batch * n * d)
+  double* dwarp = nullptr;   // context-level warp parameters (2d, log space)
+  double* dwarpB = nullptr;  // per-walker warp parameters (max_batch * 2d)
+  size_t cap_xwb = 0;
+  int has_warp = 0;
   double* dy = nullptr;      // npad (zero padded)
   double* dalpha = nullptr;  // npad
   size_t cap_n = 0;          // capacity (rows) of the three buffers above
@@ -123,10 +130,16 @@ int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int u
 // same for the slice [off, off+B) of the current batch on an explicit stream
 int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
                             int use_alpha);
+// per-walker inputs: dXb + b * xstride (xstride == 0: shared)
+int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented, int use_alpha,
+                        const double* dXb, size_t xstride);
 // Cross kernel matrix k(Xq, X_train) for hyper-vector index b: out is m x ldo row-major (device).
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int symmetric_diag_fix);
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
+// Beta-CDF warp of n x d inputs for B parameter sets (bgp_warp.hip)
+int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* dW, double* dout, int n, int B,
+                    size_t ostride);
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);
 // LML path: left-looking update with fused kernel-matrix generation (bgp_llchol.hip); replaces

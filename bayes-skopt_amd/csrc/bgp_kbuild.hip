@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
                                                            const double* __restrict__ H, double* __restrict__ Kbuf,
                                                            const double* __restrict__ y, double* __restrict__ yw,
                                                            int n, int d, int npad, int nblk, int B, int full, int ld,
-                                                           int use_alpha) {
+                                                           int use_alpha, size_t xstride) {
   const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
   int b, t;
   bgp_map_block(blockIdx.x, ntiles, b, t);
@@ -126,7 +126,8 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
   double* out = Kbuf + (size_t)b * ld * ld;
   // working right-hand side of walker b (becomes z = L^-1 y during the factorisation)
   if (ti == tj && threadIdx.x < 128) yw[(size_t)b * ld + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
-  kbuild_tile<1, STAT, FORM>(X, n, X, n, d, h, use_alpha ? alpha : nullptr, ti * 128, tj * 128, out, (size_t)ld, npad,
+  const double* Xb = X + (size_t)b * xstride;  // per-walker warped inputs (xstride == 0: shared)
+  kbuild_tile<1, STAT, FORM>(Xb, n, Xb, n, d, h, use_alpha ? alpha : nullptr, ti * 128, tj * 128, out, (size_t)ld, npad,
                              npad);
 }
 
@@ -145,16 +146,21 @@ int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int u
 
 int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
                             int use_alpha) {
+  return bgp_launch_kbuild_x(ctx, off, B, st, full_square, augmented, use_alpha, ctx->dXeff, 0);
+}
+
+int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented, int use_alpha,
+                        const double* dXb, size_t xstride) {
   const int nblk = ctx->nblk;
   const size_t ldm = augmented ? 2 * (size_t)ctx->npad : (size_t)ctx->npad;
   const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
   const int grid = 8 * ((B + 7) / 8) * ntiles;
   bgp_tbegin(ctx, 0, st);
   KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, st, ctx->dX, ctx->dalpha,
+              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, st, dXb, ctx->dalpha,
                                  ctx->dh + (size_t)off * (ctx->d + 2), ctx->dK + (size_t)off * ldm * ldm, ctx->dy,
                                  ctx->dyw + (size_t)off * ldm, ctx->n, ctx->d, ctx->npad, nblk, B, full_square,
-                                 (int)ldm, use_alpha));
+                                 (int)ldm, use_alpha, xstride));
   bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
   return BGP_OK;

@@ -215,7 +215,7 @@ int bgp_launch_cholesky_ll_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, i
   for (int J = 0; J < nblk; J++) {
     bgp_tbegin(ctx, J == 0 ? 0 : 3, st);  // step 0 is pure kernel-matrix generation
     KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-                hipLaunchKernelGGL((lupdate_kernel<S, F>), dim3(B8 * (nblk - J)), dim3(G8_THREADS), 0, st, ctx->dX,
+                hipLaunchKernelGGL((lupdate_kernel<S, F>), dim3(B8 * (nblk - J)), dim3(G8_THREADS), 0, st, ctx->dXeff,
                                    dalpha, dH, dK, ctx->dy, dyw, dstatus, ctx->n, ctx->d, ld, mstride, nblk, J, B));
     bgp_tend(ctx, st);
     bgp_tbegin(ctx, 1, st);

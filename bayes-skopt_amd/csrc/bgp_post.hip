@@ -295,12 +295,16 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
     dCov = s.take((size_t)mpad * mpad);
   }
   BGP_HIP(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->has_warp) {  // BayesGPR.predict warps the query points with the current warpers (bask/bayesgpr.py:630-632)
+    rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0);
+    if (rc) return rc;
+  }
   for (int b = 0; b < B; b++) {
     const double* hk = h_kernel + (size_t)b * p;
     BGP_HIP(hipMemcpyAsync(dhk, hk, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)mpad * npad * sizeof(double), c->stream));
     BGP_HIP(hipMemsetAsync(dq, 0, (size_t)mpad * sizeof(double), c->stream));
-    rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dX, dKs, npad, 0);
+    rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0);
     if (rc) return rc;
     const double* Kinv = c->dKinv + (size_t)b * npad * npad;
     const double* al = c->dalpha_sol + (size_t)b * npad;
@@ -510,7 +514,7 @@ extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lm
   BGP_HIP(hipMemsetAsync(dgrad, 0, (size_t)B * p * sizeof(double), c->stream));
   BGP_HIP(hipMemcpyAsync(dH, h, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   const int ntiles = c->nblk * (c->nblk + 1) / 2;
-  hipLaunchKernelGGL(lml_grad_kernel, dim3(8 * ((B + 7) / 8) * ntiles), dim3(256), 0, c->stream, c->dX, dH, c->dKinv,
+  hipLaunchKernelGGL(lml_grad_kernel, dim3(8 * ((B + 7) / 8) * ntiles), dim3(256), 0, c->stream, c->dXeff, dH, c->dKinv,
                      c->dalpha_sol, dgrad, c->n, c->d, c->npad, c->nblk, c->ks.form, c->ks.stationary, B);
   BGP_HIP(hipGetLastError());
   BGP_HIP(hipMemcpyAsync(grad, dgrad, (size_t)B * p * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -574,11 +578,17 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   BGP_HIP(hipMemcpyAsync(dXc, Xcand, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(dXt, Xthompson, (size_t)T * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->has_warp) {  // candidates and Thompson points are compared in the warped space (bask/acquisition.py:324-327)
+    rc = bgp_launch_warp(c, c->stream, dXc, c->dwarp, dXc, m, 1, 0);
+    if (rc) return rc;
+    rc = bgp_launch_warp(c, c->stream, dXt, c->dwarp, dXt, T, 1, 0);
+    if (rc) return rc;
+  }
   BGP_HIP(hipMemsetAsync(dKc, 0, ((size_t)mpad * npad + 2 * (size_t)Tpad * npad + 2 * (size_t)mpad * Tpad +
                                    2 * (size_t)mpad + 2 * (size_t)Tpad + 16) * sizeof(double), c->stream));
-  rc = bgp_launch_kcross(c, dhk, m, dXc, n, c->dX, dKc, npad, 0);
+  rc = bgp_launch_kcross(c, dhk, m, dXc, n, c->dXeff, dKc, npad, 0);
   if (rc) return rc;
-  rc = bgp_launch_kcross(c, dhk, T, dXt, n, c->dX, dKT, npad, 0);
+  rc = bgp_launch_kcross(c, dhk, T, dXt, n, c->dXeff, dKT, npad, 0);
   if (rc) return rc;
   rc = bgp_launch_kcross(c, dhk, m, dXc, T, dXt, dKti, Tpad, 0);
   if (rc) return rc;
@@ -714,12 +724,13 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   }
     SY(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
     SY(hipMemcpyAsync(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (c->has_warp && (rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0))) break;
     SY(hipMemsetAsync(dKs, 0, (size_t)mpad * npad * sizeof(double), c->stream));
     SY(hipMemsetAsync(dKss, 0, (size_t)mpad * mpad * sizeof(double), c->stream));
     SY(hipMemsetAsync(dZ, 0, (size_t)rpad * mpad * sizeof(double), c->stream));
     SY(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
                         n_draws, hipMemcpyHostToDevice, c->stream));
-    if ((rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dX, dKs, npad, 0))) break;
+    if ((rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0))) break;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4), dim3(256), 0, c->stream, dKs, npad, al, n, m, dmean);
     if ((rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr))) break;
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, dKss, mpad, 0))) break;

@@ -153,7 +153,11 @@ class Optimizer:
                 else:
                     self.gp.sample(self.space.transform(self.Xi), self.yi, **common)
 
-            X = self.space.transform(self.space.rvs(n_samples=self.n_points, random_state=self.rng))
+            if self.gp.warp_inputs:  # uniform in the WARPED space (bask/optimizer.py:353-357)
+                X_warped = self.rng.uniform(size=(self.n_points, self.space.transformed_n_dims))
+                X = self.gp.unwarp(X_warped)
+            else:
+                X = self.space.transform(self.space.rvs(n_samples=self.n_points, random_state=self.rng))
             acq_values = evaluate_acquisitions(
                 X=X,
                 gpr=self.gp,

@@ -85,6 +85,23 @@ void bgp_ctx_destroy(bgp_ctx* ctx);
 int bgp_lml_batch(bgp_ctx* ctx, int B, const double* h, double* lml, int* status);
 
 /*
+ * Input warping (bask/bayesgpr.py:249-316, warp_inputs=True): every input column k is passed through the
+ * CDF of Beta(exp(wa_k), exp(wb_k)) before the kernel is evaluated.  warp vectors are 2*d doubles in log
+ * space, [wa_1..wa_d, wb_1..wb_d] -- the tail the reference appends to theta (bask/bayesgpr.py:355-357).
+ *
+ * bgp_lml_batch_warped: as bgp_lml_batch, but walker b sees the design matrix through its own warp
+ *   warp[b*2d .. (b+1)*2d).  Replaces create_warpers() + rewarp() + log_marginal_likelihood per walker
+ *   (bask/bayesgpr.py:353-374).
+ * bgp_ctx_set_warp: context-level warp (the geometric-median warpers, bask/bayesgpr.py:535-541) seen by
+ *   every later posterior / predict / pvrs / gradient / sample_y / bgp_lml_batch call, including their
+ *   query points (bask/bayesgpr.py:630-632); NULL clears it; bgp_ctx_update_data clears it.
+ * bgp_beta_cdf: warp m points (m*d row-major) on the device -- BayesGPR.warp() (bask/bayesgpr.py:249-264).
+ */
+int bgp_lml_batch_warped(bgp_ctx* ctx, int B, const double* h, const double* warp, double* lml, int* status);
+int bgp_ctx_set_warp(bgp_ctx* ctx, const double* warp);
+int bgp_beta_cdf(bgp_ctx* ctx, int m, const double* X, const double* warp, double* out);
+
+/*
  * LML and its gradient w.r.t. the canonical vector (grad is B*(d+2)):
  *     g_k = 1/2 tr((alpha alpha^T - K^-1) dK/dh_k)
  * Replaces: log_marginal_likelihood(theta, eval_gradient=True) (sklearn/_gpr.py:615-647,

@@ -205,8 +205,8 @@ def test_bayesgpr_host_semantics_without_device(bask):
     np.testing.assert_allclose(gp.alpha, [1.0 + 1e-10, 2.0 + 1e-10, 1e-10])
     gp._apply_noise_vector(3, np.array([0.5, 0.5, 0.5]))  # re-applied on the ORIGINAL scalar alpha
     np.testing.assert_allclose(gp.alpha, 0.5 + 1e-10)
-    with pytest.raises(NotImplementedError):
-        bask.BayesGPR(warp_inputs=True)
+    gw = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1]), warp_inputs=True)
+    assert gw.warp_inputs and gw.warp(np.ones((2, 2))).shape == (2, 2)  # identity before the first fit
     from bayes_skopt_amd.bayesgpr import _eval_priors
 
     Theta = np.random.RandomState(0).randn(5, 2)
