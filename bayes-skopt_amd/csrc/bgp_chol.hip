@@ -109,10 +109,25 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
   double* yk = yw + (size_t)b * ystride + k * 128;
 
-  for (int idx = tid; idx < 128 * 64; idx += 256) {
-    const int row = idx >> 6, seg = idx & 63;
-    d2 v = *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2);
-    *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v;
+  {
+    // lower triangle of the tile -> LDS, 8 independent 16-byte loads in flight per thread (the block is
+    // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
+    // (t >> 6) + 4 i; pairs entirely above the diagonal are never read.
+    const int seg = tid & 63, rbase = tid >> 6;
+#pragma unroll
+    for (int i0 = 0; i0 < 32; i0 += 8) {
+      d2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int row = rbase + 4 * (i0 + u);
+        v[u] = (2 * seg <= row + 15) ? *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2) : (d2){0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int row = rbase + 4 * (i0 + u);
+        *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
+      }
+    }
   }
   if (tid < 128) {
     ylds[tid] = yk[tid];
@@ -203,21 +218,25 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   }
   __syncthreads();
 
-  // ---- L_kk out (zeros above the diagonal), log-det
-  for (int idx = tid; idx < 128 * 128; idx += 256) {
-    const int row = idx >> 7, col = idx & 127;
-    T[(size_t)row * ld + col] = (col <= row) ? s[row * PF_LD + col] : 0.0;
+  // ---- L_kk out, log-det.  Only the lower triangle is written (16-byte stores; the element right of the
+  // diagonal in a straddling pair is junk nobody reads: every consumer of this tile masks j <= i).
+  {
+    const int seg = tid & 63, rbase = tid >> 6;
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+      const int row = rbase + 4 * i;
+      if (2 * seg <= row)
+        *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
+    }
   }
   double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
   for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
   if (lane == 0) red[w] = ldv;
 
   // ---- W = L^-1 by block columns (wave w: columns w and 7-w), z = W y
+  // (the strictly upper 16x16 blocks of W are never multiplied -- the panel solves skip k-steps beyond
+  //  a column block -- so they are left unwritten)
   double* Wg = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  for (int idx = tid; idx < 128 * 128; idx += 256) {  // strictly upper 16x16 blocks are zero
-    const int row = idx >> 7, col = idx & 127;
-    if ((col >> 4) > (row >> 4)) Wg[idx] = 0.0;
-  }
   switch (w) {
     case 0:
       potrf_wcol<0>(s, Minv, Wg, ylds, zacc, lane);
