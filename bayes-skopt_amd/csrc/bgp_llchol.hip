@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(G8_THREADS) lupdate_kernel(const double* __res
 }
 
 // Panel solve on the 8-wave 4x4x4 core: X = T W^T (W lower triangular: k-skip), y_I -= X z_J.
-__global__ void __launch_bounds__(G8_THREADS) trsm8_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf,
+__global__ void __launch_bounds__(G8_THREADS, 4) trsm8_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf,
                                                             double* __restrict__ yw, const int* __restrict__ status,
                                                             int ld, size_t mstride, int ystride, int nblk, int k,
                                                             int B) {
