@@ -470,6 +470,8 @@ __global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf
   }
 }
 
+void bgp_launch_syrk3(hipStream_t st, int grid, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+                      int K, int jstart, int colmode, int B);
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k);
 
@@ -515,16 +517,22 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
         // single-panel update of everything below (also the tail when only one block column is left)
         const int nt = nblk - (k + 1);
         bgp_tbegin(ctx, 3, st);
-        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk,
-                           k, 128, k + 1, 0, B);
+        if (ctx->use_syrk3)
+          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 128, k + 1, 0, B);
+        else
+          hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                             nblk, k, 128, k + 1, 0, B);
         bgp_tend(ctx, st);
         k += 1;
         continue;
       }
       // look-ahead column k+1 with panel k
       bgp_tbegin(ctx, 3, st);
-      hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nblk - (k + 1))), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, k,
-                         128, k + 1, 1, B);
+      if (ctx->use_syrk3)
+        bgp_launch_syrk3(st, B8 * (nblk - (k + 1)), dK, dstatus, ld, mstride, nblk, k, 128, k + 1, 1, B);
+      else
+        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nblk - (k + 1))), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, k,
+                           128, k + 1, 1, B);
       bgp_tend(ctx, st);
       bgp_tbegin(ctx, 1, st);
       hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
@@ -536,8 +544,11 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
       {
         const int nt = nblk - (k + 2);
         bgp_tbegin(ctx, 3, st);
-        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk,
-                           k, 256, k + 2, 0, B);
+        if (ctx->use_syrk3)
+          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 256, k + 2, 0, B);
+        else
+          hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                             nblk, k, 256, k + 2, 0, B);
         bgp_tend(ctx, st);
       }
       k += 2;

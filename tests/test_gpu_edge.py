@@ -142,7 +142,7 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
         "c=_lib.Context(X,y,1e-10,max_batch=8); print(repr(c.lml(H).tolist()))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "2"}):
+    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "2"}, {"BGP_SYRK3": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
