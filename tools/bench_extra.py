@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Extra measurements for DESIGN.md / BASELINE configs B, C (fit+sample wall-clock), D, E.
-Prints one JSON object per section.  GPU box only."""
+Prints one JSON object per section.  GPU box only.  Like bench.py's cpu_baseline leg, the oracle is imported
+here ONLY to time the CPU restatement next to the device path (never as part of what is measured as "GPU")."""
 import json
 import os
 import sys
