@@ -201,6 +201,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  bgp_free_child(c);
   free_dev(c->dX);
   free_dev(c->dy);
   free_dev(c->dalpha);

@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, co
                                                     int ld, size_t mstride, int ystride, int nblk, int k, int nact,
                                                     int aug, int B) {
   int b, t;
-  bgp_map_block(blockIdx.x, nact, b, t);
+  bgp_map_block(blockIdx.x, nact, B, b, t);
   if (b >= B || status[b] != 0) return;
   __shared__ GemmSmem sm;
   // 4 waves stacked along the rows (32 rows x 128 columns each): every wave sees the same
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf,
                                                     int B) {
   const int ntile = nact * (nact + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntile, b, t);
+  bgp_map_block(blockIdx.x, ntile, B, b, t);
   if (b >= B || status[b] != 0) return;
   int ti, tj;
   bgp_tri_decode(t, ti, tj);
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf
   const int nt = nblk - jstart;
   const int ntile = colmode ? nt : nt * (nt + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntile, b, t);
+  bgp_map_block(blockIdx.x, ntile, B, b, t);
   if (b >= B || status[b] != 0) return;
   int ti, tj;
   if (colmode) {

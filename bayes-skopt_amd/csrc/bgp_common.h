@@ -79,6 +79,7 @@ struct bgp_ctx {
   // scratch for predict / pvrs (grown on demand)
   double* dscratch = nullptr;
   size_t cap_scratch = 0;
+  bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
   // timing
   int timing = 0;
   double t_ms[5] = {0, 0, 0, 0, 0};
@@ -119,6 +120,7 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 }
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
+void bgp_free_child(bgp_ctx* ctx);
 // make the matrix workspace at least `doubles` large (and the per-item side buffers consistent)
 int bgp_grow_workspace(bgp_ctx* ctx, size_t doubles);
 // posterior build on the augmented matrices; use_alpha == 0 drops alpha_diag (PVRS quirk)

@@ -19,7 +19,14 @@ static __device__ __forceinline__ double bgp_stationary(double r2, int stat) {
 // (MI355X_MICROARCH.md "Workgroup dispatch"); matrix b is pinned to XCD b % 8 and each XCD walks
 // through its matrices one after another so that the panels a matrix's tiles share stay in that
 // XCD's private 4 MiB L2.  Placement only affects speed, never results.
-static __device__ __forceinline__ void bgp_map_block(int id, int tiles, int& b, int& t) {
+// With fewer than 8 matrices in the batch that pinning would leave XCDs idle, so the tiles of a matrix
+// are spread round-robin over all XCDs instead (grids are sized 8*ceil(B/8)*tiles either way).
+static __device__ __forceinline__ void bgp_map_block(int id, int tiles, int B, int& b, int& t) {
+  if (B < 8) {
+    b = id / tiles;
+    t = id - b * tiles;
+    return;
+  }
   int x = id & 7;
   int q = id >> 3;
   int m = q / tiles;

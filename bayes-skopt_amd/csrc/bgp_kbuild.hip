@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
                                                            int use_alpha, size_t xstride) {
   const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntiles, b, t);
+  bgp_map_block(blockIdx.x, ntiles, B, b, t);
   if (b >= B) return;
   int ti, tj;
   if (full) {

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(G8_THREADS) lupdate_kernel(const double* __res
                                                               size_t mstride, int nblk, int J, int B) {
   const int ntile = nblk - J;
   int b, t;
-  bgp_map_block(blockIdx.x, ntile, b, t);
+  bgp_map_block(blockIdx.x, ntile, B, b, t);
   if (b >= B || status[b] != 0) return;
   const int I = J + t;
   __shared__ GemmSmem sm;
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(G8_THREADS, 4) trsm8_kernel(double* __restrict
                                                             int B) {
   const int nrb = nblk - k - 1;
   int b, t;
-  bgp_map_block(blockIdx.x, nrb, b, t);
+  bgp_map_block(blockIdx.x, nrb, B, b, t);
   if (b >= B || status[b] != 0) return;
   __shared__ GemmSmem sm;
   // 8 waves stacked along the rows (16 rows x 128 columns each): every wave sees the same triangular

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256) lml_grad_kernel(const double* __restrict_
                                                         int form, int stat, int B) {
   const int ntiles = nblk * (nblk + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntiles, b, t);
+  bgp_map_block(blockIdx.x, ntiles, B, b, t);
   if (b >= B) return;
   int ti, tj;
   bgp_tri_decode(t, ti, tj);
@@ -680,26 +680,37 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   BGP_HIP(hipSetDevice(c->device));
   const int npad = c->npad, n = c->n, d = c->d, mpad = pad128(m), rpad = pad128(n_draws);
   const size_t p = d + 2;
-  // child workspace for the m x m Cholesky (shares the stream)
-  bgp_ctx* w = new bgp_ctx();
-  w->device = c->device;
-  w->stream = c->stream;
-  w->n = m;
-  w->npad = mpad;
-  w->nblk = mpad / 128;
-  w->d = d;
-  w->max_batch = 1;
+  // child workspace for the m x m Cholesky (shares the stream); cached on the context and grown on demand
+  // (an m = 10 000 candidate grid needs 0.8 GB: re-allocating it per call costs more than the factorisation)
+  bgp_ctx* w = c->child;
+  if (w && w->cap_n < (size_t)mpad) {
+    free_child(w);
+    w = c->child = nullptr;
+  }
   int rc = BGP_OK;
-  do {
+  if (!w) {
+    w = new bgp_ctx();
+    w->device = c->device;
+    w->stream = c->stream;
+    w->d = d;
+    w->max_batch = 1;
+    w->two_panel = c->two_panel;
     if (hipMalloc(&w->dK, (size_t)mpad * mpad * sizeof(double)) != hipSuccess ||
-        hipMalloc(&w->dW, (size_t)w->nblk * 128 * 128 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&w->dW, (size_t)(mpad / 128) * 128 * 128 * sizeof(double)) != hipSuccess ||
         hipMalloc(&w->dyw, (size_t)mpad * sizeof(double)) != hipSuccess ||
         hipMalloc(&w->dacc, 4 * sizeof(double)) != hipSuccess || hipMalloc(&w->dlml, sizeof(double)) != hipSuccess ||
         hipMalloc(&w->dstatus, sizeof(int)) != hipSuccess) {
       bgp_set_error("bgp_sample_y: hipMalloc of the %d x %d covariance workspace failed", mpad, mpad);
-      rc = BGP_ERR_HIP;
-      break;
+      free_child(w);
+      return BGP_ERR_HIP;
     }
+    w->cap_n = mpad;
+    c->child = w;
+  }
+  w->n = m;
+  w->npad = mpad;
+  w->nblk = mpad / 128;
+  do {
     size_t need = (size_t)m * d + p + 2 * (size_t)mpad * npad + (size_t)mpad * mpad + 2 * (size_t)mpad +
                   2 * (size_t)rpad * mpad + 64;
     rc = bgp_ensure_scratch(c, need);
@@ -762,6 +773,12 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
 #undef SY
   } while (0);
   (void)hipStreamSynchronize(c->stream);
-  free_child(w);
   return rc;
+}
+
+void bgp_free_child(bgp_ctx* c) {
+  if (c && c->child) {
+    free_child(c->child);
+    c->child = nullptr;
+  }
 }

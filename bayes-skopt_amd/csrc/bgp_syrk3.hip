@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256, 2) syrk3_kernel(double* __restrict__ Kbuf
   const int nt = nblk - jstart;
   const int ntile = colmode ? nt : nt * (nt + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntile, b, t);
+  bgp_map_block(blockIdx.x, ntile, B, b, t);
   if (b >= B || status[b] != 0) return;
   int ti, tj;
   if (colmode) {

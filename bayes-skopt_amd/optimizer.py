@@ -157,7 +157,7 @@ class Optimizer:
                 X_warped = self.rng.uniform(size=(self.n_points, self.space.transformed_n_dims))
                 X = self.gp.unwarp(X_warped)
             else:
-                X = self.space.transform(self.space.rvs(n_samples=self.n_points, random_state=self.rng))
+                X = self.space.rvs_transformed(n_samples=self.n_points, random_state=self.rng)
             acq_values = evaluate_acquisitions(
                 X=X,
                 gpr=self.gp,
