@@ -24,7 +24,7 @@ import scipy.optimize
 from sklearn.base import clone
 from sklearn.utils import check_random_state
 
-from . import _lib
+from . import _lib, distributed
 from .kernels import ConstantKernel, WhiteKernel, analyse_kernel, param_for_white_kernel_in_sum
 from .kernels import RBF as _RBF
 from .sampler import EnsembleSampler
@@ -59,6 +59,7 @@ class BayesGPR:
         noise="gaussian",
         device=0,
         max_batch=None,
+        shard_ensemble=False,
     ):
         self._kernel = None if kernel is None else kernel.clone_with_theta(kernel.theta)
         self.kernel = kernel
@@ -73,6 +74,9 @@ class BayesGPR:
         self.noise = noise
         self.device = device
         self.max_batch = max_batch
+        # exact single-ensemble sharding over the ranks of an initialised process group
+        # (distributed.shard_log_prob; every rank must be constructed with the same random_state/data)
+        self.shard_ensemble = bool(shard_ensemble)
         self._sampler = None
         self.chain_ = None
         self.pos_ = None
@@ -369,11 +373,14 @@ class BayesGPR:
                 theta = np.concatenate([theta, np.zeros(added_dims)])
             pos = [theta + 1e-2 * self.random_state.randn(n_dim) for _ in range(n_walkers)]
 
+        if self.shard_ensemble:  # every rank must propose the same blocks: pin the start ensemble to rank 0's
+            pos = distributed.broadcast_array(np.asarray(pos, dtype=np.float64))
         self._ensure_context(batch_hint=(n_walkers + 1) // 2)
         self._sampler = EnsembleSampler(
             nwalkers=n_walkers,
             ndim=n_dim,
-            log_prob_fn=self._log_prob_batch,
+            log_prob_fn=distributed.shard_log_prob(self._log_prob_batch) if self.shard_ensemble
+            else self._log_prob_batch,
             kwargs=dict(priors=priors, warp_priors=warp_priors),
             threads=n_threads,
             **kwargs,

@@ -219,6 +219,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dwarp);
   free_dev(c->dwarpB);
   free_dev(c->dscratch);
+  free_dev(c->drowpart);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);

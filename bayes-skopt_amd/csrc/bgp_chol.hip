@@ -47,7 +47,8 @@ static __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // Block column J of W = L^-1:  W[J][J] = M_J,  W[I][J] = -M_I * sum_{K=J}^{I-1} L[I][K] W[K][J].
-// Wreg blocks stay in registers in C layout; also accumulates z += W[:, J] y_J into zacc.
+// Wreg blocks stay in registers in C layout; also stores the partial z_J = W[:, J] y_J into zacc[J][.]
+// (summed over J in a fixed order by the caller: bitwise reproducible, no floating-point atomics).
 template <int J>
 static __device__ __forceinline__ void potrf_wcol(const double* __restrict__ s, const double* __restrict__ Minv,
                                                   double* __restrict__ Wg, const double* __restrict__ ylds,
@@ -88,7 +89,7 @@ static __device__ __forceinline__ void potrf_wcol(const double* __restrict__ s, 
       part += __shfl_xor(part, 2);
       part += __shfl_xor(part, 4);
       part += __shfl_xor(part, 8);
-      if (lr == 0) atomicAdd(&zacc[row], part);
+      if (lr == 0) zacc[J * 128 + row] = part;  // one slot per (column block, row): fixed-order sum later
     }
   }
 }
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   __shared__ double s[128 * PF_LD];
   __shared__ double Minv[8 * 16 * PF_MLD];
   __shared__ double ylds[128];
-  __shared__ double zacc[128];
+  __shared__ double zacc[8 * 128];
   __shared__ double red[8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -131,7 +132,6 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   }
   if (tid < 128) {
     ylds[tid] = yk[tid];
-    zacc[tid] = 0.0;
   }
   __syncthreads();
 
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   __syncthreads();
   double zv = 0.0;
   if (tid < 128) {
-    zv = zacc[tid];
+    for (int J = 0; J <= (tid >> 4); J++) zv += zacc[J * 128 + tid];
     yk[tid] = zv;
   }
   double zz = zv * zv;

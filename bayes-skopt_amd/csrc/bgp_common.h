@@ -78,6 +78,8 @@ struct bgp_ctx {
   std::vector<double> post_h;
   // scratch for predict / pvrs (grown on demand)
   double* dscratch = nullptr;
+  double* drowpart = nullptr;  // column-tile partials of the predictive-variance row dots
+  size_t cap_rowpart = 0;
   size_t cap_scratch = 0;
   bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
   // timing

@@ -85,7 +85,8 @@ __global__ void finish_var_kernel(const double* __restrict__ q, double diag, int
 // General NT tile GEMM: C (M x N) = A (M x K) * B (N x K)^T, all row-major, M, N multiples of 128,
 // K a multiple of 32 (buffers are zero padded).  Epilogues:
 //   EPI 0: C = acc                         (ldc)
-//   EPI 1: rowdot[i] += sum_j acc[i][j] * E[i][j]        (E: M x N, lde)  -- predictive variance
+//   EPI 1: rowdot[tj][i] = sum_{j in column tile tj} acc[i][j] * E[i][j]  (E: M x N, lde) -- predictive
+//          variance; the launcher then sums the column tiles in a fixed order (no fp atomics to global)
 //   EPI 2: C = E - acc                                    -- predictive covariance
 // ------------------------------------------------------------------------------------------
 template <int EPI>
@@ -138,17 +139,47 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__
   }
   if (EPI == 1) {
     __syncthreads();
-    if (tid < 128) atomicAdd(&rowdot[ti * 128 + tid], sm.ypart[tid]);
+    if (tid < 128) rowdot[(size_t)tj * ((size_t)gridDim.x / tiles_n * 128) + ti * 128 + tid] = sm.ypart[tid];
   }
+}
+
+__global__ void rowdot_reduce_kernel(const double* __restrict__ part, int tn, int M, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  double s = 0.0;
+  for (int t = 0; t < tn; t++) s += part[(size_t)t * M + i];
+  out[i] = s;
+}
+
+// column-tile partials of the EPI-1 row dots (own buffer: the callers' scratch layouts stay as they are)
+static int ensure_rowpart(bgp_ctx* c, size_t doubles) {
+  if (doubles > c->cap_rowpart) {
+    if (c->drowpart) (void)hipFree(c->drowpart);
+    c->drowpart = nullptr;
+    c->cap_rowpart = 0;
+    BGP_HIP(hipMalloc(&c->drowpart, doubles * sizeof(double)));
+    c->cap_rowpart = doubles;
+  }
+  return BGP_OK;
 }
 
 template <int EPI>
 static int launch_gemm_nt(bgp_ctx* c, const double* A, int lda, const double* Bm, int ldb, int M, int N, int K,
                           double* C, int ldc, const double* E, int lde, double* rowdot) {
   const int tm = M / 128, tn = N / 128;
+  double* rd = rowdot;
+  if (EPI == 1) {
+    int rc = ensure_rowpart(c, (size_t)tn * M);
+    if (rc) return rc;
+    rd = c->drowpart;
+  }
   hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, c->stream, A, lda, Bm, ldb, K, C, ldc, E, lde,
-                     rowdot, tn);
+                     rd, tn);
   BGP_HIP(hipGetLastError());
+  if (EPI == 1) {
+    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, c->stream, rd, tn, M, rowdot);
+    BGP_HIP(hipGetLastError());
+  }
   return BGP_OK;
 }
 
@@ -342,19 +373,21 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
 // ------------------------------------------------------------------------------------------
 // LML gradient:  g_k = 1/2 sum_ij (alpha_i alpha_j - Kinv_ij) dK_ij/dh_k   (sklearn/_gpr.py:615-647)
 // One workgroup per lower-triangular 128x128 tile (off-diagonal tiles count twice); per-dimension
-// sums are reduced in the workgroup and added atomically to grad[b][k].
+// sums are reduced in the workgroup and stored to gpart[b][tile][k]; grad_reduce_kernel adds the tiles in a
+// fixed order (bitwise reproducible gradients: no floating-point atomics).
 // ------------------------------------------------------------------------------------------
 #define GR_DK 16
 __global__ void __launch_bounds__(256) lml_grad_kernel(const double* __restrict__ X,
                                                         const double* __restrict__ H,
                                                         const double* __restrict__ Kinv,
                                                         const double* __restrict__ alpha_sol,
-                                                        double* __restrict__ grad, int n, int d, int npad, int nblk,
+                                                        double* __restrict__ gpart, int n, int d, int npad, int nblk,
                                                         int form, int stat, int B) {
   const int ntiles = nblk * (nblk + 1) / 2;
   int b, t;
   bgp_map_block(blockIdx.x, ntiles, B, b, t);
   if (b >= B) return;
+  double* gp = gpart + ((size_t)b * ntiles + t) * (d + 2);
   int ti, tj;
   bgp_tri_decode(t, ti, tj);
   __shared__ double xi[GR_DK][BGP_TILE_LD];
@@ -477,7 +510,7 @@ __global__ void __launch_bounds__(256) lml_grad_kernel(const double* __restrict_
       if (lane == 0) red[w][k] = sk;
     }
     __syncthreads();
-    if (tid < kc) atomicAdd(&grad[(size_t)b * (d + 2) + 1 + k0 + tid], 0.5 * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]));
+    if (tid < kc) gp[1 + k0 + tid] = 0.5 * (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     g_const += __shfl_xor(g_const, o);
@@ -490,9 +523,17 @@ __global__ void __launch_bounds__(256) lml_grad_kernel(const double* __restrict_
   }
   __syncthreads();
   if (tid == 0) {
-    atomicAdd(&grad[(size_t)b * (d + 2)], 0.5 * (red[0][0] + red[1][0] + red[2][0] + red[3][0]));
-    atomicAdd(&grad[(size_t)b * (d + 2) + d + 1], 0.5 * (red[0][1] + red[1][1] + red[2][1] + red[3][1]));
+    gp[0] = 0.5 * (red[0][0] + red[1][0] + red[2][0] + red[3][0]);
+    gp[d + 1] = 0.5 * (red[0][1] + red[1][1] + red[2][1] + red[3][1]);
   }
+}
+
+__global__ void grad_reduce_kernel(const double* __restrict__ gpart, double* __restrict__ grad, int ntiles, int p) {
+  const int b = blockIdx.x, k = threadIdx.x;
+  if (k >= p) return;
+  double s = 0.0;
+  for (int t = 0; t < ntiles; t++) s += gpart[((size_t)b * ntiles + t) * p + k];
+  grad[(size_t)b * p + k] = s;
 }
 
 extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lml, double* grad, int* status) {
@@ -507,15 +548,19 @@ extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lm
   int rc = bgp_posterior_build(c, B, h, 1, nullptr, nullptr, nullptr, lml, st.data());
   if (rc) return rc;
   c->post_B = 0;  // the resident K^-1 belong to a gradient evaluation, not to a posterior
-  rc = bgp_ensure_scratch(c, (size_t)B * p * 2);
+  const int ntiles = c->nblk * (c->nblk + 1) / 2;
+  rc = bgp_ensure_scratch(c, (size_t)B * p * (2 + ntiles));
   if (rc) return rc;
   double* dgrad = c->dscratch;
   double* dH = c->dscratch + (size_t)B * p;
-  BGP_HIP(hipMemsetAsync(dgrad, 0, (size_t)B * p * sizeof(double), c->stream));
+  double* dgpart = c->dscratch + (size_t)B * p * 2;
+  BGP_HIP(hipMemsetAsync(dgpart, 0, (size_t)B * p * ntiles * sizeof(double), c->stream));
   BGP_HIP(hipMemcpyAsync(dH, h, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  const int ntiles = c->nblk * (c->nblk + 1) / 2;
   hipLaunchKernelGGL(lml_grad_kernel, dim3(8 * ((B + 7) / 8) * ntiles), dim3(256), 0, c->stream, c->dXeff, dH, c->dKinv,
-                     c->dalpha_sol, dgrad, c->n, c->d, c->npad, c->nblk, c->ks.form, c->ks.stationary, B);
+                     c->dalpha_sol, dgpart, c->n, c->d, c->npad, c->nblk, c->ks.form, c->ks.stationary, B);
+  BGP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(B), dim3(((int)p + 63) / 64 * 64), 0, c->stream, dgpart, dgrad, ntiles,
+                     (int)p);
   BGP_HIP(hipGetLastError());
   BGP_HIP(hipMemcpyAsync(grad, dgrad, (size_t)B * p * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(hipStreamSynchronize(c->stream));

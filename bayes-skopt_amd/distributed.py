@@ -1,8 +1,15 @@
-"""Multi-GPU sharding of the MCMC chains: one process per GPU (``torch.distributed.run``), each rank
-runs an independent sub-ensemble on its own device with NO collective in the sampling loop; the only
-exchange is the final gather of the posterior samples (RCCL all-gather over xGMI on GPUs, gloo in the
-CPU tests).  SURVEY.md 8(e) option 2 / BASELINE.json north_star: "chains shard naturally ... RCCL over
-xGMI only for the final posterior-sample gather".
+"""Multi-GPU sharding of the MCMC chains: one process per GPU (``torch.distributed.run``).
+
+Default (SURVEY.md 8(e) option 2 / BASELINE.json north_star: "chains shard naturally ... RCCL over xGMI
+only for the final posterior-sample gather"): each rank runs an independent sub-ensemble on its own
+device with NO collective in the sampling loop; the only exchange is the final gather of the posterior
+samples (``gather_chains``: RCCL all-gather over xGMI on GPUs, gloo in the CPU tests).
+
+Option (SURVEY.md 8(e) option 1, exact single-ensemble semantics): every rank holds the same data and
+the same sampler RNG, so all ranks propose the same (B, p) block each half-step; ``shard_log_prob``
+makes rank r evaluate rows [r*B/G, (r+1)*B/G) on its device and all-gathers the B log-probabilities
+(one latency-bound collective of B doubles per half-step).  Accept/reject then runs identically on
+every rank and the chain equals the single-GPU chain bit for bit.
 
 torch is used here for process-group plumbing only (rendezvous, RCCL); nothing in the numerical path
 touches it.
@@ -11,7 +18,8 @@ import os
 
 import numpy as np
 
-__all__ = ["world", "init_process_group", "gather_chains", "barrier", "max_over_ranks", "rank_seed"]
+__all__ = ["world", "init_process_group", "gather_chains", "barrier", "max_over_ranks", "rank_seed", "shard_rows",
+           "shard_log_prob", "broadcast_array"]
 
 
 def world():
@@ -98,3 +106,55 @@ def max_over_ranks(value):
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device_for_backend())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shard_rows(B, rank, ws):
+    """Row range [lo, hi) of a B-row proposal block owned by `rank` (contiguous, sizes differ by <= 1)."""
+    return (B * rank) // ws, (B * (rank + 1)) // ws
+
+
+def shard_log_prob(fn):
+    """Wrap a vectorised log-probability ``fn(Theta (B,p), **kw) -> (B,)`` so that each rank evaluates only
+    its own rows and the full vector is re-assembled with one all-gather (exact single-ensemble sharding).
+    Every rank must call it with the same Theta (same sampler RNG on every rank).  Outside a process
+    group it is ``fn`` itself."""
+
+    def wrapped(Theta, *args, **kwargs):
+        Theta = np.atleast_2d(np.asarray(Theta, dtype=np.float64))
+        if not _is_dist():
+            return fn(Theta, *args, **kwargs)
+        import torch
+
+        dist = _dist()
+        ws, rank = dist.get_world_size(), dist.get_rank()
+        B = Theta.shape[0]
+        lo, hi = shard_rows(B, rank, ws)
+        chunk = -(-B // ws)
+        local = np.zeros(chunk)
+        if hi > lo:
+            local[: hi - lo] = fn(Theta[lo:hi], *args, **kwargs)
+        dev = _device_for_backend()
+        t = torch.from_numpy(local).to(dev)
+        out = [torch.empty_like(t) for _ in range(ws)]
+        dist.all_gather(out, t)
+        full = np.empty(B)
+        for r in range(ws):
+            rlo, rhi = shard_rows(B, r, ws)
+            if rhi > rlo:
+                full[rlo:rhi] = out[r][: rhi - rlo].cpu().numpy()
+        return full
+
+    return wrapped
+
+
+def broadcast_array(arr, src=0):
+    """Broadcast a float64 array from rank `src` (identity outside a process group).  Used to pin the
+    start ensemble of the sharded sampler to one rank's copy."""
+    arr = np.ascontiguousarray(arr, dtype=np.float64)
+    if not _is_dist():
+        return arr
+    import torch
+
+    t = torch.from_numpy(arr.copy()).to(_device_for_backend())
+    _dist().broadcast(t, src=src)
+    return t.cpu().numpy()

@@ -84,6 +84,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=("chains", "ensemble"), default="chains",
+                    help="chains (default): independent 256-walker sub-ensemble per GPU, weak scaling, no collective in "
+                    "the loop; ensemble: ONE 256-walker ensemble, each half-step's 128 proposals split over the GPUs + "
+                    "an all-gather of 128 doubles (exact reference semantics, strong scaling; SURVEY 8e option 1)")
     args = ap.parse_args()
 
     import bayes_skopt_amd as bask
@@ -100,8 +104,10 @@ def main():
 
     n, d, W = N_POINTS, N_DIMS, N_WALKERS
     X, y = synth(n, d, seed=0)
-    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=distributed.rank_seed(0, rank),
-                       device=device, max_batch=W // 2)
+    ensemble = args.shard == "ensemble" and ws > 1
+    seed_rank = 0 if ensemble else rank  # one shared ensemble needs the same RNG streams on every rank
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))),
+                       random_state=distributed.rank_seed(0, seed_rank), device=device, max_batch=W // 2)
     # state right after the MAP fit of BayesGPR.fit (bask/bayesgpr.py:602-607) without running it:
     gp.kernel_ = gp.kernel + WhiteKernel(noise_level=0.01)
     gp.noise_ = 0.01
@@ -113,8 +119,9 @@ def main():
     theta0 = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
     pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)  # the reference's start ball (:506-509)
 
-    sampler = bask.sampler.EnsembleSampler(W, d + 2, gp._log_prob_batch, kwargs=dict(priors=priors))
-    sampler.random_state = np.random.RandomState(distributed.rank_seed(1, rank)).get_state()
+    log_prob = distributed.shard_log_prob(gp._log_prob_batch) if ensemble else gp._log_prob_batch
+    sampler = bask.sampler.EnsembleSampler(W, d + 2, log_prob, kwargs=dict(priors=priors))
+    sampler.random_state = np.random.RandomState(distributed.rank_seed(1, seed_rank)).get_state()
 
     def sync():
         _lib.device_synchronize(device)
@@ -138,7 +145,8 @@ def main():
 
     # final posterior-sample gather (RCCL over xGMI when N > 1)
     tg = time.perf_counter()
-    chain_all = distributed.gather_chains(sampler.get_chain(flat=True, discard=max(args.warmup, 1)))
+    chain_local = sampler.get_chain(flat=True, discard=max(args.warmup, 1))
+    chain_all = chain_local if ensemble else distributed.gather_chains(chain_local)
     gather_ms = (time.perf_counter() - tg) * 1e3
 
     # instrumented pass: HIP events around every launch on the context's stream, same work
@@ -167,6 +175,9 @@ def main():
     gp._ctx.set_timing(False)
 
     B = W // 2
+    if ensemble:  # this rank's share of every proposal block
+        lo, hi = distributed.shard_rows(B, rank, ws)
+        B = hi - lo
     fl = trailing_flops_per_launch(n)
     syrk_ms, syrk_launches = acc["syrk"]
     flops_per_call = float(sum(fl)) * B
@@ -192,7 +203,7 @@ def main():
         "from profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
     }
 
-    evals = W * args.steps * ws
+    evals = W * args.steps * (1 if ensemble else ws)
     value = evals / dt
     line = {
         "metric": "mcmc_lml_evals_per_s_n2048",
@@ -203,18 +214,19 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if ensemble else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": "BASELINE config C: BayesGPR hyper-posterior MCMC, n=2048, d=16, c*Matern52(ARD)+White, "
-            "256 walkers per GPU (128 batched kernel-build+Cholesky+LML per half-step), start ball of "
-            "bask/bayesgpr.py:506-509, default priors",
+            + ("ONE 256-walker ensemble, the 128 proposals of each half-step split over the GPUs, " if ensemble else
+               "256 walkers per GPU (128 batched kernel-build+Cholesky+LML per half-step), ")
+            + "start ball of bask/bayesgpr.py:506-509, default priors",
             "n": n,
             "d": d,
-            "walkers_per_gpu": W,
-            "parallelism": f"chains{ws}",
+            "walkers_per_gpu": W / ws if ensemble else W,
+            "parallelism": f"ensemble_sharded{ws}" if ensemble else f"chains{ws}",
         },
         "roofline": roofline,
         "kernel_ms_per_half_step": {k: v[0] / max(n_calls, 1) for k, v in acc.items()},
@@ -227,7 +239,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
-            line["speedup_vs_cpu_baseline"] = value / ws / line["cpu_baseline"]["value"]
+            line["speedup_vs_cpu_baseline"] = value / (1 if ensemble else ws) / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if ws > 1:
         import torch.distributed as dist

@@ -1,0 +1,59 @@
+"""Worker for the exact single-ensemble sharding test (SURVEY.md 8(e) option 1): every rank drives the
+same sampler RNG, evaluates only its rows of each proposal block and all-gathers the log-probabilities.
+argv: out_dir mode   (mode "toy": CPU toy target; mode "gpu": the device LML, ranks share GPU 0)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bayes_skopt_amd as bask  # noqa: E402
+from bayes_skopt_amd import distributed  # noqa: E402
+
+
+def main():
+    out_dir, mode = sys.argv[1], sys.argv[2]
+    rank, local_rank, ws = distributed.init_process_group(backend="gloo")
+    calls = []
+    if mode == "toy":
+        p, W, steps = 3, 14, 25   # W/2 = 7 rows per half-step: uneven split 3/4 over two ranks
+        mu = np.array([1.0, -2.0, 0.5])
+
+        def log_prob(Xb):
+            calls.append(len(Xb))
+            lp = -0.5 * ((Xb - mu) ** 2).sum(axis=1)
+            lp[Xb[:, 0] > 1.5] = -np.inf  # hard wall: -inf must survive the gather
+            return lp
+
+        sampler = bask.sampler.EnsembleSampler(W, p, distributed.shard_log_prob(log_prob))
+        sampler.random_state = np.random.RandomState(5).get_state()
+        sampler.run_mcmc(mu + 1e-2 * np.random.RandomState(4).randn(W, p), steps)
+        chain = sampler.get_chain(flat=True)
+        lp = sampler.get_log_prob(flat=True)
+    else:
+        rng = np.random.RandomState(0)
+        X = rng.uniform(size=(96, 2))
+        y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(96)
+        gp = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1]), random_state=3, device=0, normalize_y=True,
+                           shard_ensemble=True)
+        gp.fit(X, y, n_desired_samples=60, n_burnin=4, n_walkers_per_thread=20, progress=False)
+        chain = gp.chain_
+        lp = np.array([gp.log_marginal_likelihood_value_])
+        # the same fit without sharding, in this very process (same libraries / thread settings)
+        gp1 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1]), random_state=3, device=0, normalize_y=True)
+        gp1.fit(X, y, n_desired_samples=60, n_burnin=4, n_walkers_per_thread=20, progress=False)
+        np.save(os.path.join(out_dir, f"chain_unsharded{rank}.npy"), gp1.chain_)
+    np.save(os.path.join(out_dir, f"chain{rank}.npy"), chain)
+    json.dump({"rank": rank, "ws": ws, "calls": calls, "lp_sum": float(np.sum(lp[np.isfinite(lp)]))},
+              open(os.path.join(out_dir, f"shard{rank}.json"), "w"))
+    import torch.distributed as dist
+
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

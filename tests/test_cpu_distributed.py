@@ -38,6 +38,52 @@ def test_two_rank_gloo_chain_gather(tmp_path):
     assert r[0]["checksum_local"] != r[1]["checksum_local"]  # independent sub-ensembles (rank seeds differ)
 
 
+def _run_two_ranks(worker, args, timeout=600):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BGP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", worker)] + list(args)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+
+
+def test_two_rank_exact_ensemble_sharding_equals_single_process(tmp_path):
+    """SURVEY 8(e) option 1: rows of every proposal block split over the ranks + all-gather of the
+    log-probabilities == the single-process chain, bit for bit, on every rank."""
+    import bayes_skopt_amd as bask
+
+    _run_two_ranks("_dist_shard_worker.py", [str(tmp_path), "toy"])
+    p, W, steps = 3, 14, 25
+    mu = np.array([1.0, -2.0, 0.5])
+
+    def log_prob(Xb):
+        lp = -0.5 * ((Xb - mu) ** 2).sum(axis=1)
+        lp[Xb[:, 0] > 1.5] = -np.inf
+        return lp
+
+    sampler = bask.sampler.EnsembleSampler(W, p, log_prob)
+    sampler.random_state = np.random.RandomState(5).get_state()
+    sampler.run_mcmc(mu + 1e-2 * np.random.RandomState(4).randn(W, p), steps)
+    ref = sampler.get_chain(flat=True)
+    for k in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"chain{k}.npy"), ref)
+    r = [json.load(open(tmp_path / f"shard{k}.json")) for k in range(2)]
+    # initial ensemble 14 rows -> 7/7; each half-step 7 rows -> 3 on rank 0, 4 on rank 1
+    assert r[0]["calls"][0] == 7 and r[1]["calls"][0] == 7
+    assert set(r[0]["calls"][1:]) == {3} and set(r[1]["calls"][1:]) == {4}
+    assert len(r[0]["calls"]) == 1 + 2 * steps
+
+
+def test_shard_rows_cover_block():
+    import bayes_skopt_amd as bask
+
+    for B in (1, 2, 7, 128, 129):
+        for ws in (1, 2, 3, 8):
+            spans = [bask.distributed.shard_rows(B, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
 def test_single_process_helpers():
     import bayes_skopt_amd as bask
 
