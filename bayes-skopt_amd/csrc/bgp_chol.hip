@@ -36,6 +36,15 @@
 // with the B operand's k map for k-slice reg), z_k = W y_k, log-det and z^T z.
 // Latency-bound by the 128 sequential pivots; the MFMA pipe is mostly idle here by construction.
 // ------------------------------------------------------------------------------------------
+#ifdef PF_TRACE  // phase timestamps of workgroup 0 (tools/potrf_bench.hip); compiled out of the product library
+__device__ unsigned long long pf_trace[32];
+#define PF_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) pf_trace[i] = wall_clock64(); } while (0)
+extern "C" int bgp_debug_potrf_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_trace), sizeof(pf_trace)) == hipSuccess ? 0 : 1;
+}
+#else
+#define PF_T(i)
+#endif
 #define PF_LD 130   // LDS leading dimension of the 128x128 block (== 2 mod 32: conflict-free MFMA operand reads)
 #define PF_MLD 18   // leading dimension of the 16x16 inverse blocks
 
@@ -44,6 +53,42 @@ static __device__ __forceinline__ double readlane_f64(double v, int lane) {
   lo = __builtin_amdgcn_readlane(lo, lane);
   hi = __builtin_amdgcn_readlane(hi, lane);
   return __hiloint2double(hi, lo);
+}
+
+// 16x16 micro-Cholesky fused with the inverse of its factor, one matrix row per lane (lane & 15), all
+// 16 pivots unrolled at compile time.  Pivot J broadcasts L[c][J] (lane c of register a[J]) to the whole
+// 16-lane row with ONE 64-bit DPP move (row_newbcast) and uses it twice:
+//   a[c]    -= L[lane][J] * L[c][J]          right-looking update of the block (lane = row)
+//   macc[c] += L[c][J] * M[J][lane]          forward substitution for M = L^-1 (lane = column of M)
+// so no SGPR round trip (v_readlane pairs) and the two dependency chains interleave.
+template <int C>
+static __device__ __forceinline__ double bc16(double v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xF, 0xF, false);  // row_newbcast:C (all lanes written)
+}
+
+template <int J, int C>
+static __device__ __forceinline__ void micro_cols(double (&a)[16], double (&macc)[16], double mj) {
+  if constexpr (C < 16) {
+    const double l = bc16<C>(a[J]);
+    a[C] = fma(-a[J], l, a[C]);
+    macc[C] = fma(l, mj, macc[C]);
+    micro_cols<J, C + 1>(a, macc, mj);
+  }
+}
+
+template <int J>
+static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr,
+                                                      int& bad) {
+  if constexpr (J < 16) {
+    const double djj = bc16<J>(a[J]);
+    bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
+    const double inv = rsqrt(djj);
+    a[J] = (lr == J) ? djj * inv : a[J] * inv;
+    const double mj = (((lr == J) ? 1.0 : 0.0) - macc[J]) * inv;  // M[J][lane]
+    mrow[J] = mj;
+    micro_cols<J, J + 1>(a, macc, mj);
+    micro_chol_inv<J + 1>(a, macc, mrow, lr, bad);
+  }
 }
 
 // Block column J of W = L^-1:  W[J][J] = M_J,  W[I][J] = -M_I * sum_{K=J}^{I-1} L[I][K] W[K][J].
@@ -109,6 +154,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   const int lr = lane & 15, lk = lane >> 4;
   double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
   double* yk = yw + (size_t)b * ystride + k * 128;
+  PF_T(0);
 
   {
     // lower triangle of the tile -> LDS, 8 independent 16-byte loads in flight per thread (the block is
@@ -134,6 +180,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     ylds[tid] = yk[tid];
   }
   __syncthreads();
+  PF_T(1);
 
   int failed = 0;
   double a[16];  // row (lane & 15) of the current 16x16 diagonal sub-block / its factor
@@ -156,38 +203,29 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
       for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
     }
     __syncthreads();
+    PF_T(2 + sb * 3);
 
     // ---- phase 2: 16x16 Cholesky + inverse in registers (every wave, redundantly)
 #pragma unroll
     for (int c = 0; c < 16; c++) a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
-    double invd[16];
+    double mrow[16];
+    {
+      double macc[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const double djj = readlane_f64(a[j], j);
-      if (!(djj > 0.0 && djj < INFINITY)) {  // non-positive, NaN or overflowed pivot; uniform
-        if (failed == 0) failed = sb * 16 + j + 1;
-      }
-      const double inv = rsqrt(djj);
-      const double dj = djj * inv;
-      invd[j] = inv;
-      a[j] = (lr == j) ? dj : a[j] * inv;
-#pragma unroll
-      for (int c = j + 1; c < 16; c++) a[c] -= a[j] * readlane_f64(a[j], c);
+      for (int c = 0; c < 16; c++) macc[c] = 0.0;
+      int bad = 0;
+      micro_chol_inv<0>(a, macc, mrow, lr, bad);
+      // `bad` is the same in every lane (all rows of 16 lanes hold the same block); make it scalar
+      const int bad_u = __builtin_amdgcn_readfirstlane(bad);
+      if (bad_u && failed == 0) failed = sb * 16 + bad_u;
     }
     if (failed) break;  // uniform across the workgroup
-    double m[16];
-#pragma unroll
-    for (int j = 15; j >= 0; j--) {
-      double acc = (lr == j) ? 1.0 : 0.0;
-#pragma unroll
-      for (int c = j + 1; c < 16; c++) acc -= m[c] * readlane_f64(a[j], c);
-      m[j] = acc * invd[j];
-    }
     if (lane < 16) {
 #pragma unroll
-      for (int c = 0; c < 16; c++) Minv[sb * 16 * PF_MLD + lr * PF_MLD + c] = m[c];  // same values from every wave
+      for (int j = 0; j < 16; j++) Minv[sb * 16 * PF_MLD + j * PF_MLD + lr] = mrow[j];  // same values from every wave
     }
 
+    PF_T(3 + sb * 3);
     // ---- phase 3: panel X_I = T_I M^T for the row blocks this wave updated in phase 1
     for (int I = sb + w; I < 8; I += 4) {
       if (I == sb) continue;
@@ -202,6 +240,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
       for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
     }
     __syncthreads();
+    PF_T(4 + sb * 3);
     // the factor of the diagonal sub-block replaces it only now: until the barrier above the other
     // waves were still reading the unfactorised block
     if (w == 0 && lane < 16) {
@@ -232,6 +271,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
   for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
   if (lane == 0) red[w] = ldv;
+  PF_T(26);
 
   // ---- W = L^-1 by block columns (wave w: columns w and 7-w), z = W y
   // (the strictly upper 16x16 blocks of W are never multiplied -- the panel solves skip k-steps beyond
@@ -256,6 +296,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
       break;
   }
   __syncthreads();
+  PF_T(27);
   double zv = 0.0;
   if (tid < 128) {
     for (int J = 0; J <= (tid >> 4); J++) zv += zacc[J * 128 + tid];
@@ -283,6 +324,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
       lml[b] = v;
     }
   }
+  PF_T(28);
 }
 
 // ------------------------------------------------------------------------------------------
