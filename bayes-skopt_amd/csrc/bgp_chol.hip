@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   __shared__ double ylds[128];
   __shared__ double zacc[8 * 128];
   __shared__ double red[8];
+  __shared__ int fail_lds;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
@@ -182,70 +183,134 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   __syncthreads();
   PF_T(1);
 
+  // ---- factorisation of the 128x128 block as a two-stage software pipeline over its eight 16-wide block
+  // columns.  Wave 0 is the PANEL wave: per step sb it completes row block sb (panel product with the previous
+  // 16x16 inverse, last two rank-16 terms of the diagonal block), factorises the diagonal block in registers
+  // and publishes its inverse M_sb.  Waves 1-3 are UPDATE waves running one phase behind: phase p (after M_p
+  // is published) forms the panel blocks X_{I,p} of their rows I >= p+2 and applies
+  //     column p+1: terms t = p-1, p          column p+2: terms t <= p-1
+  // so every block column c is complete (terms t <= c-3 in phase c-2, t = c-2, c-1 in phase c-1) when the
+  // panel wave needs it, and the only thing on the critical path is the 16-pivot chain.  Panel products are
+  // formed transposed (X^T = M T^T): their C-layout registers are directly the A and the B operand of the
+  // following rank-16 updates (see potrf_wcol), so nothing round-trips through LDS.  One barrier per step.
   int failed = 0;
-  double a[16];  // row (lane & 15) of the current 16x16 diagonal sub-block / its factor
+  if (tid == 0) fail_lds = 0;
+  d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written to LDS one step later (the update waves
+                                        // still read the unscaled block T_{sb,sb-1} during this step)
 #pragma unroll 1
   for (int sb = 0; sb < 8; sb++) {
-    // ---- phase 1: left-looking update of block column sb (rows sb..7 spread over the 4 waves)
-    for (int I = sb + w; I < 8; I += 4) {
-      d4 acc;
+    if (w == 0) {
+      if (sb > 1) {  // pending panel block of the previous row
 #pragma unroll
-      for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr];
-      for (int t = 0; t < sb; t++) {
+        for (int r = 0; r < 4; r++) s[((sb - 1) * 16 + lr) * PF_LD + (sb - 2) * 16 + lk + 4 * r] = xpend[r];
+      }
+      d4 dg;
+#pragma unroll
+      for (int r = 0; r < 4; r++) dg[r] = s[(sb * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr];
+      if (sb > 0) {
+        d4 xt = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
-          const double av = -s[(I * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
-          const double bv = s[(sb * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          const double av = Minv[(sb - 1) * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
+          const double bv = s[(sb * 16 + lr) * PF_LD + (sb - 1) * 16 + kk * 4 + lk];
+          xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
+        }
+        if (sb > 1) {
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const double xv = s[(sb * 16 + lr) * PF_LD + (sb - 2) * 16 + kk * 4 + lk];
+            dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv, xv, dg, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[kk], xt[kk], dg, 0, 0, 0);
+        xpend = xt;
+      }
+      // C layout -> one matrix row per lane through the block's own LDS slot (nobody else touches it)
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[(sb * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = dg[r];
+      double a[16], mrow[16], macc[16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
+        macc[c] = 0.0;
+      }
+      int bad = 0;
+      micro_chol_inv<0>(a, macc, mrow, lr, bad);
+      const int bad_u = __builtin_amdgcn_readfirstlane(bad);
+      if (bad_u) {
+        if (lane == 0) fail_lds = sb * 16 + bad_u;
+      } else if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) Minv[sb * 16 * PF_MLD + j * PF_MLD + lr] = mrow[j];
+#pragma unroll
+        for (int c = 0; c < 16; c++) s[(sb * 16 + lr) * PF_LD + sb * 16 + c] = (c <= lr) ? a[c] : 0.0;
+      }
+    } else if (sb > 0) {
+      const int p = sb - 1;  // phase: M_p was published at the previous barrier
+      d4 xt = (d4){0.0, 0.0, 0.0, 0.0};  // X_{p+1,p}^T (every update wave forms its own copy)
+      if (p + 2 < 8) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const double av = Minv[p * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
+          const double bv = s[((p + 1) * 16 + lr) * PF_LD + p * 16 + kk * 4 + lk];
+          xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
         }
       }
+      for (int I = p + 2; I < 8; I++) {
+        if (I % 3 + 1 != w) continue;  // static row ownership
+        d4 xi = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
+        for (int kk = 0; kk < 4; kk++) {
+          const double av = Minv[p * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
+          const double bv = s[(I * 16 + lr) * PF_LD + p * 16 + kk * 4 + lk];
+          xi = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xi, 0, 0, 0);
+        }
+        // column p+1: terms p-1 (operands from LDS) and p (registers)
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 1) * 16 + lr];
+        if (p > 0) {
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const double av = -s[(I * 16 + lr) * PF_LD + (p - 1) * 16 + kk * 4 + lk];
+            const double bv = s[((p + 1) * 16 + lr) * PF_LD + (p - 1) * 16 + kk * 4 + lk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[kk], xt[kk], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + (p + 1) * 16 + lr] = acc[r];
+        // the row's own panel block (its unscaled values were last read just above)
+#pragma unroll
+        for (int r = 0; r < 4; r++) s[(I * 16 + lr) * PF_LD + p * 16 + lk + 4 * r] = xi[r];
+        // column p+2: terms t <= p-1
+        if (p > 0) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr];
+          for (int t = 0; t < p; t++) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+              const double av = -s[(I * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
+              const double bv = s[((p + 2) * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr] = acc[r];
+        }
+      }
     }
     __syncthreads();
     PF_T(2 + sb * 3);
-
-    // ---- phase 2: 16x16 Cholesky + inverse in registers (every wave, redundantly)
-#pragma unroll
-    for (int c = 0; c < 16; c++) a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
-    double mrow[16];
-    {
-      double macc[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) macc[c] = 0.0;
-      int bad = 0;
-      micro_chol_inv<0>(a, macc, mrow, lr, bad);
-      // `bad` is the same in every lane (all rows of 16 lanes hold the same block); make it scalar
-      const int bad_u = __builtin_amdgcn_readfirstlane(bad);
-      if (bad_u && failed == 0) failed = sb * 16 + bad_u;
-    }
+    failed = fail_lds;
     if (failed) break;  // uniform across the workgroup
-    if (lane < 16) {
+  }
+  if (!failed) {
+    if (w == 0) {  // last pending panel block (row 7)
 #pragma unroll
-      for (int j = 0; j < 16; j++) Minv[sb * 16 * PF_MLD + j * PF_MLD + lr] = mrow[j];  // same values from every wave
-    }
-
-    PF_T(3 + sb * 3);
-    // ---- phase 3: panel X_I = T_I M^T for the row blocks this wave updated in phase 1
-    for (int I = sb + w; I < 8; I += 4) {
-      if (I == sb) continue;
-      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const double av = s[(I * 16 + lr) * PF_LD + sb * 16 + kk * 4 + lk];
-        const double bv = Minv[sb * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = acc[r];
-    }
-    __syncthreads();
-    PF_T(4 + sb * 3);
-    // the factor of the diagonal sub-block replaces it only now: until the barrier above the other
-    // waves were still reading the unfactorised block
-    if (w == 0 && lane < 16) {
-#pragma unroll
-      for (int c = 0; c < 16; c++) s[(sb * 16 + lr) * PF_LD + sb * 16 + c] = (c <= lr) ? a[c] : 0.0;
+      for (int r = 0; r < 4; r++) s[(7 * 16 + lr) * PF_LD + 6 * 16 + lk + 4 * r] = xpend[r];
     }
   }
   if (failed) {

@@ -76,20 +76,10 @@ int main(int argc, char** argv) {
   unsigned long long tr[32];
   if (bgp_debug_potrf_trace(tr) == 0) {
     auto us = [&](int a, int b) { return (double)(tr[b] - tr[a]) * 0.01; };
-    double p1 = 0, p2 = 0, p3 = 0;
-    for (int sb = 0; sb < 8; sb++) {
-      p1 += us(sb == 0 ? 1 : 4 + (sb - 1) * 3, 2 + sb * 3);
-      p2 += us(2 + sb * 3, 3 + sb * 3);
-      p3 += us(3 + sb * 3, 4 + sb * 3);
-    }
-    printf("trace (us): load %.2f | phase1 %.2f | factor+inverse %.2f | phase3 %.2f | Lstore+logdet %.2f | W %.2f | tail %.2f | total %.2f\n",
-           us(0, 1), p1, p2, p3, us(25, 26), us(26, 27), us(27, 28), us(0, 28));
-    printf("per-sb factor+inverse:");
-    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(2 + sb * 3, 3 + sb * 3));
-    printf("\nper-sb phase1:");
-    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(sb == 0 ? 1 : 4 + (sb - 1) * 3, 2 + sb * 3));
-    printf("\nper-sb phase3:");
-    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(3 + sb * 3, 4 + sb * 3));
+    printf("trace (us): load %.2f | loop %.2f | Lstore+logdet %.2f | W %.2f | tail %.2f | total %.2f\n", us(0, 1),
+           us(1, 23), us(23, 26), us(26, 27), us(27, 28), us(0, 28));
+    printf("per-step:");
+    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(sb == 0 ? 1 : 2 + (sb - 1) * 3, 2 + sb * 3));
     printf("\n");
   }
   return 0;
