@@ -25,16 +25,22 @@
 // ------------------------------------------------------------------------------------------
 // potrf: diagonal block k of every walker, one workgroup (4 waves) per walker, block in LDS.
 //
-// The 128x128 block is processed as 8x8 sub-blocks of 16 (left-looking):
-//   phase 1  block column sb -= L[:, <sb] L[sb, <sb]^T          (fp64 MFMA, operands from LDS)
-//   phase 2  16x16 diagonal sub-block: Cholesky + inverse, register resident, one matrix row per
-//            lane, rows broadcast with v_readlane (compile-time lane ids); every wave does it
-//            redundantly so no hand-off is needed
-//   phase 3  panel below:  X = T M^T  with M = inverse of the 16x16 factor        (fp64 MFMA)
-// and finally W = L^-1 by block columns (register-resident C-layout blocks feed the next MFMA
-// directly as B operands: for v_mfma_f64_16x16x4_f64 the C/D row map (lane>>4)+4*reg coincides
-// with the B operand's k map for k-slice reg), z_k = W y_k, log-det and z^T z.
-// Latency-bound by the 128 sequential pivots; the MFMA pipe is mostly idle here by construction.
+// The 128x128 block is processed as 8x8 sub-blocks of 16 by a two-stage software pipeline inside the
+// workgroup.  Wave 0 is the PANEL wave: per step sb it completes row block sb (panel product with the
+// previous 16x16 inverse, last rank-16 term of the diagonal block), factorises the diagonal block in
+// registers (one matrix row per lane, 64-bit DPP row broadcasts) and publishes its inverse M_sb.  Waves 1-3
+// are UPDATE waves running one phase behind: phase p (after M_p is published) forms the panel blocks X_{I,p}
+// of the rows I >= p+2 and applies
+//     column p+1: terms t = p-1, p        column p+2: terms t <= p-1  (and t = p on its diagonal block)
+// so every block column c is complete (terms t <= c-3 in phase c-2, t = c-2, c-1 in phase c-1) when the
+// panel wave needs it; they also form row sb-1 of W = L^-1 while the panel wave factorises block sb.  The
+// only thing on the critical path is the 16-pivot chain (8 x ~2 us); one barrier per step.
+// Panel products are formed transposed (X^T = M T^T): their C-layout registers are directly the A and
+// the B operand of the following rank-16 updates (for v_mfma_f64_16x16x4_f64 the C/D row map
+// (lane>>4)+4*reg coincides with the A and the B operand's k map for k-slice reg), so nothing
+// round-trips through LDS.  W is kept TRANSPOSED in the otherwise unused upper triangle of the LDS
+// tile, where later rows read it with the ordinary row-major operand pattern; z_k = W y_k, log-det and
+// z^T z finish the launch.
 // ------------------------------------------------------------------------------------------
 #ifdef PF_TRACE  // phase timestamps of workgroup 0 (tools/potrf_bench.hip); compiled out of the product library
 __device__ unsigned long long pf_trace[32];
@@ -47,13 +53,6 @@ extern "C" int bgp_debug_potrf_trace(unsigned long long* out) {
 #endif
 #define PF_LD 130   // LDS leading dimension of the 128x128 block (== 2 mod 32: conflict-free MFMA operand reads)
 #define PF_MLD 18   // leading dimension of the 16x16 inverse blocks
-
-static __device__ __forceinline__ double readlane_f64(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
 
 // 16x16 micro-Cholesky fused with the inverse of its factor, one matrix row per lane (lane & 15), all
 // 16 pivots unrolled at compile time.  Pivot J broadcasts L[c][J] (lane c of register a[J]) to the whole
@@ -82,8 +81,15 @@ static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&
   if constexpr (J < 16) {
     const double djj = bc16<J>(a[J]);
     bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
-    const double inv = rsqrt(djj);
-    a[J] = (lr == J) ? djj * inv : a[J] * inv;
+    // sqrt and 1/sqrt together from the hardware seed by one coupled (Goldschmidt) step: three dependent
+    // operations on the pivot chain instead of the library rsqrt's six
+    const double y0 = __builtin_amdgcn_rsq(djj);
+    const double g = djj * y0, h = 0.5 * y0;
+    const double r = fma(-g, h, 0.5);
+    const double dj = fma(g, r, g);        // sqrt(djj)
+    const double hh = fma(h, r, h);
+    const double inv = hh + hh;            // 1 / sqrt(djj)
+    a[J] = (lr == J) ? dj : a[J] * inv;
     const double mj = (((lr == J) ? 1.0 : 0.0) - macc[J]) * inv;  // M[J][lane]
     mrow[J] = mj;
     micro_cols<J, J + 1>(a, macc, mj);
@@ -91,52 +97,92 @@ static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&
   }
 }
 
-// Block column J of W = L^-1:  W[J][J] = M_J,  W[I][J] = -M_I * sum_{K=J}^{I-1} L[I][K] W[K][J].
-// Wreg blocks stay in registers in C layout; also stores the partial z_J = W[:, J] y_J into zacc[J][.]
-// (summed over J in a fixed order by the caller: bitwise reproducible, no floating-point atomics).
-template <int J>
-static __device__ __forceinline__ void potrf_wcol(const double* __restrict__ s, const double* __restrict__ Minv,
-                                                  double* __restrict__ Wg, const double* __restrict__ ylds,
-                                                  double* __restrict__ zacc, int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  d4 Wreg[8 - J];
+// acc (+/-)= sum_{t < nt} A_t B_t^T for 16x16 blocks whose operands sit in LDS rows `pa` / `pb` (pointers
+// already offset to the lane's row and k-group) and advance by one 16-wide block column per term.  The
+// next term's eight operand reads are issued before the current term's four MFMAs (one wave per SIMD
+// here: nothing else hides the LDS latency).
+template <int NEG>
+static __device__ __forceinline__ d4 mma_run(d4 acc, const double* __restrict__ pa, const double* __restrict__ pb,
+                                             int nt) {
+  if (nt <= 0) return acc;
+  double a0[4], b0[4];
 #pragma unroll
-  for (int r = 0; r < 4; r++) Wreg[0][r] = Minv[J * 16 * PF_MLD + (lk + 4 * r) * PF_MLD + lr];
+  for (int kk = 0; kk < 4; kk++) {
+    a0[kk] = pa[kk * 4];
+    b0[kk] = pb[kk * 4];
+  }
+  for (int t = 0; t < nt; t++) {
+    double a1[4], b1[4];
+    const int tn = (t + 1 < nt) ? t + 1 : t;
 #pragma unroll
-  for (int I = J + 1; I < 8; I++) {
-    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int K = J; K < I; K++) {
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const double av = s[(I * 16 + lr) * PF_LD + K * 16 + kk * 4 + lk];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Wreg[K - J][kk], acc, 0, 0, 0);
-      }
+    for (int kk = 0; kk < 4; kk++) {
+      a1[kk] = pa[tn * 16 + kk * 4];
+      b1[kk] = pb[tn * 16 + kk * 4];
     }
-    d4 wn = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a0[kk] : a0[kk], b0[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      a0[kk] = a1[kk];
+      b0[kk] = b1[kk];
+    }
+  }
+  return acc;
+}
+
+// Row I of W = L^-1, block J <= I:  W[I][I] = M_I,  W[I][J] = -M_I * S,  S = sum_{K=J}^{I-1} L[I][K] W[K][J].
+// pf_wsum forms the terms K = J .. Kend-1 of S (L[I][I-1] comes from `xrow` while the panel wave's in-place
+// write of that block is still pending); pf_wfinish multiplies by -M_I (the C-layout sum is directly the B
+// operand), writes the block to global memory (row-major W, lower blocks only: the panel solves skip k-steps
+// beyond a column block) and transposed into LDS block (J, I).
+static __device__ __forceinline__ d4 pf_wsum(d4 acc, const double* __restrict__ s, const double* __restrict__ Minv,
+                                             const double* __restrict__ xrow, int I, int J, int Kbeg, int Kend,
+                                             int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  if (Kbeg == J && Kbeg < Kend) {  // W[J][J] = M_J
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const double av = (J == I - 1 && xrow) ? xrow[lr * PF_MLD + kk * 4 + lk] : s[(I * 16 + lr) * PF_LD + J * 16 + kk * 4 + lk];
+      const double bv = Minv[J * 16 * PF_MLD + (kk * 4 + lk) * PF_MLD + lr];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    Kbeg++;
+  }
+  int Kmid = Kend;
+  if (xrow && Kend == I) Kmid = I - 1;  // the last term's A operand lives in xrow
+  if (Kmid > Kbeg)
+    acc = mma_run<0>(acc, &s[(I * 16 + lr) * PF_LD + Kbeg * 16 + lk], &s[(J * 16 + lr) * PF_LD + Kbeg * 16 + lk],
+                     Kmid - Kbeg);
+  if (Kmid < Kend && Kmid >= Kbeg) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const double av = xrow[lr * PF_MLD + kk * 4 + lk];
+      const double bv = s[(J * 16 + lr) * PF_LD + Kmid * 16 + kk * 4 + lk];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+  }
+  return acc;
+}
+
+static __device__ __forceinline__ void pf_wfinish(d4 acc, double* __restrict__ s, const double* __restrict__ Minv,
+                                                  double* __restrict__ Wg, int I, int J, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  d4 wn;
+  if (J == I) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) wn[r] = Minv[I * 16 * PF_MLD + (lk + 4 * r) * PF_MLD + lr];
+  } else {
+    wn = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       const double av = -Minv[I * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
       wn = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[kk], wn, 0, 0, 0);
     }
-    Wreg[I - J] = wn;
-  }
-  const double yv = ylds[J * 16 + lr];
 #pragma unroll
-  for (int I = J; I < 8; I++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = I * 16 + lk + 4 * r;
-      const double w = Wreg[I - J][r];
-      Wg[row * 128 + J * 16 + lr] = w;
-      double part = w * yv;
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
-      if (lr == 0) zacc[J * 128 + row] = part;  // one slot per (column block, row): fixed-order sum later
-    }
+    for (int r = 0; r < 4; r++) s[(J * 16 + lr) * PF_LD + I * 16 + lk + 4 * r] = wn[r];
   }
+#pragma unroll
+  for (int r = 0; r < 4; r++) Wg[(I * 16 + lk + 4 * r) * 128 + J * 16 + lr] = wn[r];
 }
 
 __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
@@ -147,8 +193,9 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   if (status[b] != 0) return;
   __shared__ double s[128 * PF_LD];
   __shared__ double Minv[8 * 16 * PF_MLD];
+  __shared__ double xrow[2][16 * PF_MLD];  // X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
   __shared__ double ylds[128];
-  __shared__ double zacc[8 * 128];
+  __shared__ double zpart[2 * 128];
   __shared__ double red[8];
   __shared__ int fail_lds;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -158,45 +205,40 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   PF_T(0);
 
   {
-    // lower triangle of the tile -> LDS, 8 independent 16-byte loads in flight per thread (the block is
+    // lower triangle of the tile -> LDS, all 32 16-byte loads of a thread in flight at once (the block is
     // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
     // (t >> 6) + 4 i; pairs entirely above the diagonal are never read.
     const int seg = tid & 63, rbase = tid >> 6;
+    d2 v[32];
 #pragma unroll
-    for (int i0 = 0; i0 < 32; i0 += 8) {
-      d2 v[8];
+    for (int u = 0; u < 32; u++) {
+      const int row = rbase + 4 * u;
+      v[u] = (2 * seg <= row + 15) ? *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2) : (d2){0.0, 0.0};
+    }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int row = rbase + 4 * (i0 + u);
-        v[u] = (2 * seg <= row + 15) ? *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2) : (d2){0.0, 0.0};
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int row = rbase + 4 * (i0 + u);
-        *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
-      }
+    for (int u = 0; u < 32; u++) {
+      const int row = rbase + 4 * u;
+      *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
     }
   }
-  if (tid < 128) {
-    ylds[tid] = yk[tid];
+  if (tid < 128) ylds[tid] = yk[tid];
+  double ld_prev = 0.0, zz_prev = 0.0;  // running log-det and z^T z of the earlier diagonal blocks
+  if (tid == 0) {
+    fail_lds = 0;
+    if (k > 0) {
+      ld_prev = accb[b * 4 + 0];
+      zz_prev = accb[b * 4 + 1];
+    }
   }
   __syncthreads();
   PF_T(1);
 
-  // ---- factorisation of the 128x128 block as a two-stage software pipeline over its eight 16-wide block
-  // columns.  Wave 0 is the PANEL wave: per step sb it completes row block sb (panel product with the previous
-  // 16x16 inverse, last two rank-16 terms of the diagonal block), factorises the diagonal block in registers
-  // and publishes its inverse M_sb.  Waves 1-3 are UPDATE waves running one phase behind: phase p (after M_p
-  // is published) forms the panel blocks X_{I,p} of their rows I >= p+2 and applies
-  //     column p+1: terms t = p-1, p          column p+2: terms t <= p-1
-  // so every block column c is complete (terms t <= c-3 in phase c-2, t = c-2, c-1 in phase c-1) when the
-  // panel wave needs it, and the only thing on the critical path is the 16-pivot chain.  Panel products are
-  // formed transposed (X^T = M T^T): their C-layout registers are directly the A and the B operand of the
-  // following rank-16 updates (see potrf_wcol), so nothing round-trips through LDS.  One barrier per step.
+  double* Wg = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
   int failed = 0;
-  if (tid == 0) fail_lds = 0;
-  d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written to LDS one step later (the update waves
-                                        // still read the unscaled block T_{sb,sb-1} during this step)
+  d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written in place one step later (the update
+                                        // waves still read the unscaled block T_{sb,sb-1} during this step)
+  d4 w7[2];                             // update waves: partial sums of row 7 of W, finished after the loop
+  w7[0] = w7[1] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll 1
   for (int sb = 0; sb < 8; sb++) {
     if (w == 0) {
@@ -215,16 +257,11 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
           const double bv = s[(sb * 16 + lr) * PF_LD + (sb - 1) * 16 + kk * 4 + lk];
           xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
         }
-        if (sb > 1) {
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
-            const double xv = s[(sb * 16 + lr) * PF_LD + (sb - 2) * 16 + kk * 4 + lk];
-            dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xv, xv, dg, 0, 0, 0);
-          }
-        }
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[kk], xt[kk], dg, 0, 0, 0);
         xpend = xt;
+#pragma unroll
+        for (int r = 0; r < 4; r++) xrow[sb & 1][lr * PF_MLD + lk + 4 * r] = xt[r];
       }
       // C layout -> one matrix row per lane through the block's own LDS slot (nobody else touches it)
 #pragma unroll
@@ -236,7 +273,15 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
         macc[c] = 0.0;
       }
       int bad = 0;
+#ifdef PF_TRACE
+      asm volatile("s_nop 0" ::"v"(a[0]), "v"(a[15]));
+#endif
+      PF_T(3 + sb * 3);
       micro_chol_inv<0>(a, macc, mrow, lr, bad);
+#ifdef PF_TRACE
+      asm volatile("s_nop 0" ::"v"(a[15]), "v"(mrow[15]), "v"(mrow[14]));
+#endif
+      PF_T(4 + sb * 3);
       const int bad_u = __builtin_amdgcn_readfirstlane(bad);
       if (bad_u) {
         if (lane == 0) fail_lds = sb * 16 + bad_u;
@@ -258,7 +303,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
         }
       }
       for (int I = p + 2; I < 8; I++) {
-        if (I % 3 + 1 != w) continue;  // static row ownership
+        if (I % 3 + 1 != w) continue;  // row ownership
         d4 xi = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
@@ -270,14 +315,9 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
         d4 acc;
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 1) * 16 + lr];
-        if (p > 0) {
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
-            const double av = -s[(I * 16 + lr) * PF_LD + (p - 1) * 16 + kk * 4 + lk];
-            const double bv = s[((p + 1) * 16 + lr) * PF_LD + (p - 1) * 16 + kk * 4 + lk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-          }
-        }
+        if (p > 0)
+          acc = mma_run<1>(acc, &s[(I * 16 + lr) * PF_LD + (p - 1) * 16 + lk],
+                           &s[((p + 1) * 16 + lr) * PF_LD + (p - 1) * 16 + lk], 1);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[kk], xt[kk], acc, 0, 0, 0);
 #pragma unroll
@@ -285,20 +325,44 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
         // the row's own panel block (its unscaled values were last read just above)
 #pragma unroll
         for (int r = 0; r < 4; r++) s[(I * 16 + lr) * PF_LD + p * 16 + lk + 4 * r] = xi[r];
-        // column p+2: terms t <= p-1
-        if (p > 0) {
+        // column p+2: terms t <= p-1, and on the row's own diagonal block (I == p+2) also term p, so the
+        // panel wave is left with a single rank-16 term
+        if (p > 0 || I == p + 2) {
 #pragma unroll
           for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr];
-          for (int t = 0; t < p; t++) {
+          acc = mma_run<1>(acc, &s[(I * 16 + lr) * PF_LD + lk], &s[((p + 2) * 16 + lr) * PF_LD + lk], p);
+          if (I == p + 2) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-              const double av = -s[(I * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
-              const double bv = s[((p + 2) * 16 + lr) * PF_LD + t * 16 + kk * 4 + lk];
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[kk], xi[kk], acc, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr] = acc[r];
+        }
+      }
+      // row p of W = L^-1: M_p, its panel blocks (the last one via xrow) and rows < p of W are visible
+      // (blocks dealt to the three waves so that phase rows + W blocks balance: 4 bits per J, greedy by cost)
+      const unsigned wown = (p == 0) ? 0x1u : (p == 1) ? 0x33u : (p == 2) ? 0x331u : (p == 3) ? 0x2321u
+                          : (p == 4) ? 0x31233u : (p == 5) ? 0x311331u : 0x1321321u;
+      for (int J = 0; J <= p; J++) {
+        if ((int)((wown >> (4 * J)) & 15u) != w) continue;
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+        if (J < p) acc = pf_wsum(acc, s, Minv, xrow[p & 1], p, J, J, p, lane);
+        pf_wfinish(acc, s, Minv, Wg, p, J, lane);
+      }
+      // row block sb-2 of L is final and visible: stream it out now (lower triangle, 16-byte pairs)
+      if (sb >= 2 && sb <= 6) {  // (the last step is the update waves' busiest: blocks 5..7 go out after the loop)
+        const int R = sb - 2, ut = tid - 64;  // 192 update threads: 12 per row
+        const int rr = ut / 12, c0 = ut - 12 * rr, row = R * 16 + rr;
+        for (int seg = c0; seg < 8 * R + 8; seg += 12) {
+          if (2 * seg <= row)
+            *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
+        }
+      }
+      // last step: rows <= 5 of W are complete -> the terms K <= 5 of row 7 (two blocks per wave)
+      if (sb == 7) {
+        for (int q = 0; q < 2; q++) {
+          const int J = (3 - w) + 3 * q;  // J = 0..5, heavy blocks to the wave with the lightest row-6 share
+          w7[q] = pf_wsum(w7[q], s, Minv, nullptr, 7, J, J, 6, lane);
         }
       }
     }
@@ -307,12 +371,6 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     failed = fail_lds;
     if (failed) break;  // uniform across the workgroup
   }
-  if (!failed) {
-    if (w == 0) {  // last pending panel block (row 7)
-#pragma unroll
-      for (int r = 0; r < 4; r++) s[(7 * 16 + lr) * PF_LD + 6 * 16 + lk + 4 * r] = xpend[r];
-    }
-  }
   if (failed) {
     if (tid == 0) {
       status[b] = k * 128 + failed;  // 1-based index of the failing pivot
@@ -320,51 +378,58 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     }
     return;
   }
-  __syncthreads();
-
-  // ---- L_kk out, log-det.  Only the lower triangle is written (16-byte stores; the element right of the
-  // diagonal in a straddling pair is junk nobody reads: every consumer of this tile masks j <= i).
+  PF_T(26);
+  // ---- L_kk out.  Only the lower triangle is written (16-byte stores; the element right of the diagonal in
+  // a straddling pair is junk nobody reads: every consumer of this tile masks j <= i).  Block (7, 6) is still
+  // in the panel wave's registers and goes out from there.  The stores drain while row 7 of W is formed.
   {
     const int seg = tid & 63, rbase = tid >> 6;
 #pragma unroll 8
-    for (int i = 0; i < 32; i++) {
+    for (int i = 20; i < 32; i++) {  // row blocks 5, 6 and 7 (0..4 went out inside the loop)
       const int row = rbase + 4 * i;
-      if (2 * seg <= row)
+      if (2 * seg <= row && !(row >= 112 && seg >= 48 && seg < 56))
         *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
+    }
+  }
+  // ---- row 7 of W: last term (K = 6) and the multiplication by -M_7
+  if (w == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) T[(size_t)(7 * 16 + lr) * ld + 6 * 16 + lk + 4 * r] = xpend[r];
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+    acc = pf_wsum(acc, s, Minv, xrow[1], 7, 6, 6, 7, lane);
+    pf_wfinish(acc, s, Minv, Wg, 7, 6, lane);
+    pf_wfinish(acc, s, Minv, Wg, 7, 7, lane);
+  } else {
+    for (int q = 0; q < 2; q++) {
+      const int J = (3 - w) + 3 * q;
+      w7[q] = pf_wsum(w7[q], s, Minv, xrow[1], 7, J, 6, 7, lane);
+      pf_wfinish(w7[q], s, Minv, Wg, 7, J, lane);
     }
   }
   double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
   for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
   if (lane == 0) red[w] = ldv;
-  PF_T(26);
-
-  // ---- W = L^-1 by block columns (wave w: columns w and 7-w), z = W y
-  // (the strictly upper 16x16 blocks of W are never multiplied -- the panel solves skip k-steps beyond
-  //  a column block -- so they are left unwritten)
-  double* Wg = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  switch (w) {
-    case 0:
-      potrf_wcol<0>(s, Minv, Wg, ylds, zacc, lane);
-      potrf_wcol<7>(s, Minv, Wg, ylds, zacc, lane);
-      break;
-    case 1:
-      potrf_wcol<1>(s, Minv, Wg, ylds, zacc, lane);
-      potrf_wcol<6>(s, Minv, Wg, ylds, zacc, lane);
-      break;
-    case 2:
-      potrf_wcol<2>(s, Minv, Wg, ylds, zacc, lane);
-      potrf_wcol<5>(s, Minv, Wg, ylds, zacc, lane);
-      break;
-    default:
-      potrf_wcol<3>(s, Minv, Wg, ylds, zacc, lane);
-      potrf_wcol<4>(s, Minv, Wg, ylds, zacc, lane);
-      break;
-  }
   __syncthreads();
   PF_T(27);
+  // ---- z = W y from the LDS copy of W (transposed in the upper triangle, diagonal blocks in Minv); two
+  // threads per row, fixed summation order (bitwise reproducible)
+  {
+    const int row = tid & 127, h = tid >> 7, Ib = row >> 4, ri = row & 15;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;  // four chains (16 Ib is a multiple of 8), fixed order
+    for (int j = h; j < 16 * Ib; j += 8) {
+      z0 = fma(s[j * PF_LD + row], ylds[j], z0);
+      z1 = fma(s[(j + 2) * PF_LD + row], ylds[j + 2], z1);
+      z2 = fma(s[(j + 4) * PF_LD + row], ylds[j + 4], z2);
+      z3 = fma(s[(j + 6) * PF_LD + row], ylds[j + 6], z3);
+    }
+    double zs = (z0 + z1) + (z2 + z3);
+    for (int jj = h; jj <= ri; jj += 2) zs = fma(Minv[Ib * 16 * PF_MLD + ri * PF_MLD + jj], ylds[16 * Ib + jj], zs);
+    zpart[h * 128 + row] = zs;
+  }
+  __syncthreads();
   double zv = 0.0;
   if (tid < 128) {
-    for (int J = 0; J <= (tid >> 4); J++) zv += zacc[J * 128 + tid];
+    zv = zpart[tid] + zpart[128 + tid];
     yk[tid] = zv;
   }
   double zz = zv * zv;
@@ -374,10 +439,8 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   if (tid == 0) {
     double ldt = red[0] + red[1] + red[2] + red[3];
     double zzt = red[4] + red[5] + red[6] + red[7];
-    if (k > 0) {
-      ldt += accb[b * 4 + 0];
-      zzt += accb[b * 4 + 1];
-    }
+    ldt += ld_prev;
+    zzt += zz_prev;
     accb[b * 4 + 0] = ldt;
     accb[b * 4 + 1] = zzt;
     if (k == nblk - 1) {

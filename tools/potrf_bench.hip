@@ -80,6 +80,12 @@ int main(int argc, char** argv) {
            us(1, 23), us(23, 26), us(26, 27), us(27, 28), us(0, 28));
     printf("per-step:");
     for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(sb == 0 ? 1 : 2 + (sb - 1) * 3, 2 + sb * 3));
+    printf("\n  pre-factor:");
+    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(sb == 0 ? 1 : 2 + (sb - 1) * 3, 3 + sb * 3));
+    printf("\n  factor:");
+    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(3 + sb * 3, 4 + sb * 3));
+    printf("\n  post-factor+barrier:");
+    for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(4 + sb * 3, 2 + sb * 3));
     printf("\n");
   }
   return 0;
