@@ -161,6 +161,9 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->use_syrk3 = (envs && atoi(envs) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");
     c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
+    c->panels = c->two_panel ? 2 : 1;
+    const char* envp = getenv("BGP_PANELS");
+    if (envp && atoi(envp) >= 1 && atoi(envp) <= 8) c->panels = atoi(envp);
     (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     for (int g = 0; g < ns; g++) {
       (void)hipStreamCreate(&c->gstream[g]);

@@ -601,14 +601,18 @@ __global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf,
 //   colmode 1: only block column jstart (the look-ahead column the next potrf/trsm need)
 //   colmode 0: every tile with I >= J >= jstart
 // ------------------------------------------------------------------------------------------
+template <int SPLIT>
 __global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
                                                        int ld, size_t mstride, int nblk, int kp, int K, int jstart,
                                                        int colmode, int B) {
   const int nt = nblk - jstart;
   const int ntile = colmode ? nt : nt * (nt + 1) / 2;
   int b, t;
-  bgp_map_block(blockIdx.x, ntile, B, b, t);
+  bgp_map_block(blockIdx.x, SPLIT * ntile, B, b, t);
   if (b >= B || status[b] != 0) return;
+  // SPLIT == 2 (small launches that would leave the GPU under-filled): two workgroups per tile, 64 rows each
+  const int half = (SPLIT == 2) ? (t & 1) : 0;
+  if (SPLIT == 2) t >>= 1;
   int ti, tj;
   if (colmode) {
     ti = t;
@@ -625,19 +629,46 @@ __global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf
   double* C = M + (size_t)(I * 128) * ld + J * 128;
 
   if (I != J) {
-    d4 acc[4][4];
-    gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
-    for (int k0 = 0; k0 < K; k0 += GK_KC) {
-      __syncthreads();
-      gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-      gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
-      __syncthreads();
-      gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
+    if (SPLIT == 2) {
+      d4 acc[2][4];
+      const int r0 = half * 64 + wr * 32;
+      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
+      for (int k0 = 0; k0 < K; k0 += GK_KC) {
+        __syncthreads();
+        gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+        gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
+        __syncthreads();
+        gk_mma_block<2, 4, 1, 0, -64>(sm.A, sm.B, acc, r0, wc * 64, lane, k0);
+      }
+      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
+    } else {
+      d4 acc[4][4];
+      gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
+      for (int k0 = 0; k0 < K; k0 += GK_KC) {
+        __syncthreads();
+        gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
+        gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
+        __syncthreads();
+        gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
+      }
+      gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
     }
-    gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
   } else {
+    if (half) return;  // diagonal tiles (half the work of a full tile already) stay on one workgroup
     syrk_diag_tile(sm, XI, C, ld, tid, lane, w, K);
   }
+}
+
+// tiles x walkers below this many workgroups: split the off-diagonal tiles over two workgroups each
+#define SYRK_SPLIT_BELOW 1024
+static void launch_syrk2(hipStream_t st, int B8, int ntile, double* dK, const int* dstatus, int ld, size_t mstride,
+                         int nblk, int kp, int K, int jstart, int colmode, int B) {
+  if (B8 * ntile < SYRK_SPLIT_BELOW)
+    hipLaunchKernelGGL(syrk2_kernel<2>, dim3(B8 * ntile * 2), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,
+                       jstart, colmode, B);
+  else
+    hipLaunchKernelGGL(syrk2_kernel<1>, dim3(B8 * ntile), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,
+                       jstart, colmode, B);
 }
 
 void bgp_launch_syrk3(hipStream_t st, int grid, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
@@ -670,58 +701,43 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
   double* dlml = ctx->dlml + off;
   int* dstatus = ctx->dstatus + off;
   if (!augmented) {
-    // LML path: panel solve on the 4x4x4 MFMA core (bgp_llchol.hip) and two-panel trailing updates:
-    //   potrf(k) trsm(k) | syrk column k+1 (K=128) | potrf(k+1) trsm(k+1) | syrk rest (K=256, panels k,k+1)
+    // LML path: panel solve on the 4x4x4 MFMA core (bgp_llchol.hip) and multi-panel trailing updates.  A group
+    // of P block columns is factorised with look-ahead column updates only, then everything to its right is
+    // updated ONCE with the whole K = 128 P panel (P times fewer passes over the trailing matrix):
+    //   potrf(k) trsm(k) | col k+1 (K=128) | potrf(k+1) trsm(k+1) | col k+2 (K=256) | ... | rest (K = 128 P)
+    const int P = ctx->panels;
     int k = 0;
     while (k < nblk) {
-      const bool pair = (k + 1 < nblk) && ctx->two_panel;
-      bgp_tbegin(ctx, 1, st);
-      hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
-                         ystride, nblk, k);
-      bgp_tend(ctx, st);
-      if (k + 1 >= nblk) break;
-      bgp_tbegin(ctx, 2, st);
-      bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k);
-      bgp_tend(ctx, st);
-      if (!pair || k + 2 >= nblk) {
-        // single-panel update of everything below (also the tail when only one block column is left)
-        const int nt = nblk - (k + 1);
+      const int np = std::min(P, nblk - k);
+      for (int j = 0; j < np; j++) {
+        bgp_tbegin(ctx, 1, st);
+        hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld,
+                           mstride, ystride, nblk, k + j);
+        bgp_tend(ctx, st);
+        if (k + j + 1 >= nblk) break;
+        bgp_tbegin(ctx, 2, st);
+        bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
+        bgp_tend(ctx, st);
+        if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
+          bgp_tbegin(ctx, 3, st);
+          if (ctx->use_syrk3)
+            bgp_launch_syrk3(st, B8 * (nblk - (k + j + 1)), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1,
+                             B);
+          else
+            launch_syrk2(st, B8, nblk - (k + j + 1), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
+          bgp_tend(ctx, st);
+        }
+      }
+      const int nt = nblk - (k + np);
+      if (nt > 0) {
         bgp_tbegin(ctx, 3, st);
         if (ctx->use_syrk3)
-          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 128, k + 1, 0, B);
+          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         else
-          hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
-                             nblk, k, 128, k + 1, 0, B);
-        bgp_tend(ctx, st);
-        k += 1;
-        continue;
-      }
-      // look-ahead column k+1 with panel k
-      bgp_tbegin(ctx, 3, st);
-      if (ctx->use_syrk3)
-        bgp_launch_syrk3(st, B8 * (nblk - (k + 1)), dK, dstatus, ld, mstride, nblk, k, 128, k + 1, 1, B);
-      else
-        hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nblk - (k + 1))), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, k,
-                           128, k + 1, 1, B);
-      bgp_tend(ctx, st);
-      bgp_tbegin(ctx, 1, st);
-      hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
-                         ystride, nblk, k + 1);
-      bgp_tend(ctx, st);
-      bgp_tbegin(ctx, 2, st);
-      bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + 1);
-      bgp_tend(ctx, st);
-      {
-        const int nt = nblk - (k + 2);
-        bgp_tbegin(ctx, 3, st);
-        if (ctx->use_syrk3)
-          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 256, k + 2, 0, B);
-        else
-          hipLaunchKernelGGL(syrk2_kernel, dim3(B8 * (nt * (nt + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
-                             nblk, k, 256, k + 2, 0, B);
+          launch_syrk2(st, B8, nt * (nt + 1) / 2, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         bgp_tend(ctx, st);
       }
-      k += 2;
+      k += np;
     }
     BGP_HIP(hipGetLastError());
     return BGP_OK;

@@ -740,6 +740,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     w->d = d;
     w->max_batch = 1;
     w->two_panel = c->two_panel;
+    w->panels = c->panels;
     if (hipMalloc(&w->dK, (size_t)mpad * mpad * sizeof(double)) != hipSuccess ||
         hipMalloc(&w->dW, (size_t)(mpad / 128) * 128 * 128 * sizeof(double)) != hipSuccess ||
         hipMalloc(&w->dyw, (size_t)mpad * sizeof(double)) != hipSuccess ||
