@@ -671,6 +671,13 @@ static void launch_syrk2(hipStream_t st, int B8, int ntile, double* dK, const in
                        jstart, colmode, B);
 }
 
+#ifdef PF_TRACE
+extern "C" void bgp_debug_launch_syrk2(hipStream_t st, int B8, int ntile, double* dK, const int* dstatus, int ld,
+                                       size_t mstride, int nblk, int kp, int K, int jstart, int colmode, int B) {
+  launch_syrk2(st, B8, ntile, dK, dstatus, ld, mstride, nblk, kp, K, jstart, colmode, B);
+}
+#endif
+
 void bgp_launch_syrk3(hipStream_t st, int grid, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
                       int K, int jstart, int colmode, int B);
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
