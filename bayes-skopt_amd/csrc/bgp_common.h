@@ -44,6 +44,7 @@ struct bgp_ctx {
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
   int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)
   int nstreams = 1;
+  int streams_auto = 1;  // choose the group count per call from the batch size (see bgp_ctx_create)
   hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};
   hipEvent_t ev_ready = nullptr;
   hipEvent_t ev_done[BGP_MAX_STREAMS] = {nullptr};

@@ -149,7 +149,11 @@ def main():
     chain_all = chain_local if ensemble else distributed.gather_chains(chain_local)
     gather_ms = (time.perf_counter() - tg) * 1e3
 
-    # instrumented pass: HIP events around every launch on the context's stream, same work
+    # instrumented pass: HIP events around every launch, same work.  The timed pass above runs the two
+    # walker-group streams of the product default (the groups' launches overlap, so per-launch durations
+    # there are not those of a kernel running alone); for the per-kernel numbers and the roofline every
+    # launch goes to ONE stream, like the rocprofv3 runs under profiles/ (BGP_STREAMS=1).
+    gp._ctx.set_streams(1)
     gp._ctx.set_timing(True)
     acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk")}
     dev_total = 0.0
@@ -198,7 +202,8 @@ def main():
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
-        "note": "algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
+        "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
+        "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
         "peak = datasheet fp64 matrix peak (MI355X_MICROARCH.md has no fp64 row); traffic = bytes per launch "
         "from profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
     }

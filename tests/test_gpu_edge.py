@@ -142,7 +142,8 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
         "c=_lib.Context(X,y,1e-10,max_batch=8); print(repr(c.lml(H).tolist()))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "2"}, {"BGP_SYRK3": "1"}):
+    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
+                {"BGP_PANELS": "4"}, {"BGP_SYRK3": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
@@ -184,3 +185,22 @@ def test_bitwise_reproducible_and_batch_split_invariant():
             np.testing.assert_array_equal(m1, m0)
             np.testing.assert_array_equal(v1, v0)
         ctx.close()
+
+
+def test_walker_group_streams_bit_identical():
+    """Batches of >= 64 proposals are split over two walker-group streams by default (their launches overlap
+    on the GPU); the result must not depend on the grouping."""
+    from bayes_skopt_amd import _lib
+
+    rng = np.random.RandomState(11)
+    n, d, B = 260, 3, 80
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+    H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.2 * rng.randn(B, d + 2)
+    H[7, -1] = np.log(1e-300)  # one proposal that may fail must not disturb its group
+    ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
+    auto = ctx.lml(H)
+    for ns in (1, 2, 3):
+        ctx.set_streams(ns)
+        np.testing.assert_array_equal(ctx.lml(H), auto)
+    ctx.close()
