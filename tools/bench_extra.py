@@ -66,11 +66,14 @@ def config_d():
     for B in (1, 8):
         ctx = _lib.Context(X, y, 1e-10, max_batch=B)
         H = base + 0.2 * np.random.RandomState(30).randn(B, d + 2)
-        ctx.lml(H)
-        t0 = time.perf_counter()
         for _ in range(3):
+            ctx.lml(H)
+        ts = []
+        for _ in range(8):
+            t0 = time.perf_counter()
             v = ctx.lml(H)
-        dt = (time.perf_counter() - t0) / 3
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
         ctx.set_timing(True)
         ctx.lml(H)
         tm = ctx.last_timing()
