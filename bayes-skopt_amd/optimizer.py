@@ -3,8 +3,8 @@
 (re)fits / resumes the BayesGPR hyper-posterior MCMC on the device and evaluates the acquisition
 function over ``n_points`` random candidates with the device predict / PVRS kernels.
 
-Out of scope in this build: the arviz-based diagnostics
-``probability_of_optimality`` / ``expected_optimality_gap`` / ``optimum_intervals``.
+The post-hoc diagnostics ``probability_of_optimality`` / ``expected_optimality_gap`` /
+``optimum_intervals`` (``bask/optimizer.py:447-689``) run on the device ``sample_y``.
 """
 import warnings
 
@@ -16,7 +16,7 @@ from .acquisition import evaluate_acquisitions
 from .bayesgpr import BayesGPR
 from .init import r2_sequence, sb_sequence
 from .space import create_result, is_2Dlistlike, is_listlike, normalize_dimensions
-from .utils import construct_default_kernel
+from .utils import construct_default_kernel, expected_minimum, hdi
 
 __all__ = ["Optimizer"]
 
@@ -186,11 +186,73 @@ class Optimizer:
             replace = False
         return create_result(self.Xi, self.yi, self.space, self.rng, models=[self.gp])
 
-    def probability_of_optimality(self, *args, **kwargs):
-        raise NotImplementedError("post-hoc diagnostics (bask/optimizer.py:447-525) are outside the accelerated hot path")
+    def probability_of_optimality(self, threshold, n_space_samples=500, n_gp_samples=200, n_random_starts=100,
+                                  use_mean_gp=True, normalized_scores=True, random_state=None):
+        """Probability that the current expected optimum cannot be improved by more than ``threshold``
+        (``bask/optimizer.py:447-525``, same arguments): the expected optimum and ``n_space_samples`` random
+        points are scored under ``n_gp_samples`` function draws of the GP (device ``sample_y``: median GP, or
+        one posterior build per hyper-posterior sample when ``use_mean_gp=False``)."""
+        result = create_result(self.Xi, self.yi, self.space, self.rng, models=[self.gp])
+        X_orig = [expected_minimum(result, random_state=random_state, n_random_starts=n_random_starts)[0]]
+        X_orig.extend(self.space.rvs(n_samples=n_space_samples, random_state=random_state))
+        X_trans = self.space.transform(X_orig)
+        score_samples = self.gp.sample_y(X_trans, n_samples=n_gp_samples, sample_mean=use_mean_gp,
+                                         random_state=random_state)
+        if normalized_scores:
+            std = np.std(score_samples, axis=0)
+        thresholds = threshold if is_listlike(threshold) else [threshold]
+        probabilities = []
+        for eps in thresholds:
+            diff = score_samples[0][None, :] - score_samples
+            if normalized_scores:
+                diff = diff / std
+            probabilities.append(float(((diff - eps).max(axis=0) < 0.0).mean()))
+        return probabilities[0] if len(probabilities) == 1 else probabilities
 
-    def expected_optimality_gap(self, *args, **kwargs):
-        raise NotImplementedError("post-hoc diagnostics (bask/optimizer.py:527-620) are outside the accelerated hot path")
+    def expected_optimality_gap(self, max_tries=3, n_probabilities=50, n_space_samples=500, n_gp_samples=200,
+                                n_random_starts=100, tol=0.01, use_mean_gp=True, normalized_scores=True,
+                                random_state=None):
+        """Expected optimality gap of the current global optimum (``bask/optimizer.py:527-620``): the
+        cumulative distribution of the gap is traced with ``probability_of_optimality`` on a threshold grid
+        whose upper end is found by bounded scalar minimisation."""
+        from scipy.optimize import minimize_scalar
 
-    def optimum_intervals(self, *args, **kwargs):
-        raise NotImplementedError("arviz-based HDI diagnostics (bask/optimizer.py:622-689) are outside the accelerated hot path")
+        random_state = check_random_state(random_state)
+        seed = random_state.randint(0, 2**32 - 1, dtype=np.int64)
+        common = dict(n_random_starts=n_random_starts, n_gp_samples=n_gp_samples, n_space_samples=n_space_samples,
+                      use_mean_gp=use_mean_gp, normalized_scores=normalized_scores, random_state=seed)
+
+        def func(threshold):
+            prob = self.probability_of_optimality(threshold=threshold, **common)
+            return (prob - 1.0) ** 2 + threshold**2 * 1e-3
+
+        max_observed_gap = np.max(self.yi) - np.min(self.yi)
+        for _ in range(max_tries):
+            try:
+                upper_threshold = minimize_scalar(func, bounds=(0.0, max_observed_gap), tol=tol).x
+                break
+            except ValueError:
+                pass
+        else:
+            raise ValueError("Determining the upper threshold was not possible.")
+        thresholds = list(np.linspace(0, upper_threshold, num=n_probabilities))
+        probabilities = self.probability_of_optimality(thresholds, **common)
+        expected_gap = 0.0
+        for i in range(len(probabilities) - 1):
+            expected_gap += (probabilities[i + 1] - probabilities[i]) * thresholds[i + 1]
+        return expected_gap
+
+    def optimum_intervals(self, hdi_prob=0.95, multimodal=True, opt_samples=200, space_samples=500, only_mean=True,
+                          random_state=None):
+        """Highest density intervals of the optimum's location per dimension by Thompson sampling
+        (``bask/optimizer.py:622-689``); ``utils.hdi`` restates the two arviz estimators."""
+        if self.space.is_partly_categorical:
+            raise NotImplementedError("Highest density interval not implemented for categorical parameters.")
+        X = self.space.transform(self.space.rvs(n_samples=space_samples, random_state=random_state))
+        optimum_samples = self.gp.sample_y(X, sample_mean=only_mean, n_samples=opt_samples, random_state=random_state)
+        X_opt = X[np.argmin(optimum_samples, axis=0)]
+        intervals = []
+        for i, col in enumerate(X_opt.T):
+            raw_interval = hdi(col, hdi_prob=hdi_prob, multimodal=multimodal)
+            intervals.append(self.space.dimensions[i].inverse_transform(raw_interval))
+        return intervals

@@ -128,6 +128,10 @@ class Space:
     def bounds(self):
         return [d.bounds for d in self.dimensions]
 
+    @property
+    def is_partly_categorical(self):
+        return any(isinstance(d, Categorical) for d in self.dimensions)
+
     def _columns(self, X):
         if len(X) == 0:
             return [[] for _ in self.dimensions]

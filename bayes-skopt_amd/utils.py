@@ -8,7 +8,7 @@ from .init import r2_sequence  # noqa: F401  (re-exported like bask/utils.py:8-9
 from .kernels import ConstantKernel, Matern
 from .priors import halfnorm_logpdf_logspace, make_roundflat
 
-__all__ = ["geometric_median", "guess_priors", "construct_default_kernel", "validate_zeroone", "r2_sequence"]
+__all__ = ["expected_minimum", "hdi", "geometric_median", "guess_priors", "construct_default_kernel", "validate_zeroone", "r2_sequence"]
 
 
 def geometric_median(X, eps=1e-5):
@@ -102,3 +102,79 @@ def validate_zeroone(arr):
     arr = np.asarray(arr)
     if np.any(arr < 0) or np.any(arr > 1):
         raise ValueError("Not all values of the array are between 0 and 1.")
+
+
+def expected_minimum(res, n_random_starts=20, random_state=None):
+    """Minimum of the surrogate's predictive mean: L-BFGS-B from the best observed point and
+    ``n_random_starts`` random points of the space (restatement of ``skopt.utils.expected_minimum``, the
+    routine ``bask/optimizer.py:497-503`` calls).  Returns (x in the original space, predicted value).
+
+    skopt lets scipy difference the objective one point at a time; here every iterate and its 2-point
+    difference stencil go to the device as ONE predict batch (d + 1 rows), forward differences switching
+    to backward ones at the upper bound like scipy's ``approx_derivative``."""
+    from scipy.optimize import minimize
+    from sklearn.utils import check_random_state
+
+    space = res.space
+    if space.is_partly_categorical:
+        raise ValueError("expected_minimum does not support any categorical values")
+    reg = res.models[-1]
+    bounds = np.asarray(space.bounds, dtype=np.float64)
+    d = len(bounds)
+    eps = np.sqrt(np.finfo(np.float64).eps)
+
+    def fun_and_grad(x):
+        h = eps * np.maximum(1.0, np.abs(x))
+        sign = np.where(x + h > bounds[:, 1], -1.0, 1.0)
+        pts = np.tile(x, (d + 1, 1))
+        pts[1:, :][np.arange(d), np.arange(d)] += sign * h
+        vals = np.asarray(reg.predict(space.transform(pts.tolist())), dtype=np.float64)
+        return float(vals[0]), (vals[1:] - vals[0]) / (sign * h)
+
+    rng = check_random_state(random_state)
+    xs = [res.x]
+    if n_random_starts > 0:
+        xs.extend(space.rvs(n_random_starts, random_state=rng))
+    best_x, best_fun = None, np.inf
+    for x0 in xs:
+        r = minimize(fun_and_grad, x0=np.asarray(x0, dtype=np.float64), jac=True, bounds=space.bounds, method="L-BFGS-B")
+        if r.fun < best_fun:
+            best_x, best_fun = r.x, r.fun
+    return [float(v) for v in best_x], float(best_fun)
+
+
+def hdi(samples, hdi_prob=0.95, multimodal=False, max_modes=10, grid=512):
+    """Highest density interval(s) of a 1-d sample (the quantity ``bask/optimizer.py:684`` takes from
+    ``arviz.hdi``; arviz is not part of this image, so its two estimators are restated):
+
+    * ``multimodal=False``: the narrowest interval containing ``hdi_prob`` of the sorted sample -> (2,);
+    * ``multimodal=True``: density estimate on a regular grid (Gaussian KDE, Silverman bandwidth), grid cells
+      taken in order of decreasing density until they hold ``hdi_prob`` of the mass, contiguous runs of
+      cells reported as separate intervals -> (n_modes, 2)."""
+    x = np.sort(np.asarray(samples, dtype=np.float64).ravel())
+    x = x[np.isfinite(x)]
+    n = len(x)
+    if n == 0:
+        raise ValueError("hdi needs at least one finite sample")
+    if not multimodal:
+        inc = min(int(np.floor(hdi_prob * n)), n - 1)
+        widths = x[inc:] - x[: n - inc]
+        i = int(np.argmin(widths))
+        return np.array([x[i], x[i + inc]])
+    lower, upper = x[0], x[-1]
+    if upper <= lower:
+        return np.array([[lower, upper]])
+    from scipy.stats import gaussian_kde
+
+    bins = np.linspace(lower, upper, grid)
+    density = gaussian_kde(x, bw_method="silverman")(bins)
+    dx = (upper - lower) / grid
+    density = density * dx
+    density = density / density.sum()
+    order = np.argsort(-density)
+    keep = np.sort(bins[order][np.cumsum(density[order]) <= hdi_prob])
+    if keep.size == 0:
+        return np.array([[lower, upper]])
+    step = bins[1] - bins[0]
+    runs = np.split(keep, np.where(np.diff(keep) >= step * 1.1)[0] + 1)
+    return np.array([[r[0], r[-1]] for r in runs[:max_modes]])

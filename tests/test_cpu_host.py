@@ -215,3 +215,56 @@ def test_bayesgpr_host_semantics_without_device(bask):
     np.testing.assert_allclose(_eval_priors(lambda row: row.sum(), Theta), Theta.sum(axis=1))
     with pytest.raises(ValueError):
         _eval_priors(vec[:1], Theta)
+
+
+def test_hdi_unimodal_is_narrowest_interval_and_multimodal_splits():
+    """utils.hdi restates arviz.hdi (bask/optimizer.py:684): the unimodal estimator is the narrowest interval
+    holding hdi_prob of the sorted sample (checked against brute force), the multimodal one returns one interval
+    per mode."""
+    from bayes_skopt_amd.utils import hdi
+
+    rng = np.random.RandomState(3)
+    x = rng.gamma(2.0, size=501)
+    lo, hi = hdi(x, 0.9)
+    xs = np.sort(x)
+    k = int(np.floor(0.9 * len(xs)))
+    best = min((xs[i + k] - xs[i], xs[i], xs[i + k]) for i in range(len(xs) - k))
+    assert (lo, hi) == (best[1], best[2])
+    assert np.mean((x >= lo) & (x <= hi)) >= 0.9
+    two = np.concatenate([0.25 + 0.03 * rng.randn(600), 0.75 + 0.03 * rng.randn(600)])
+    iv = hdi(two, 0.9, multimodal=True)
+    assert iv.shape == (2, 2)
+    assert iv[0, 0] < 0.25 < iv[0, 1] < 0.5 < iv[1, 0] < 0.75 < iv[1, 1]
+    assert hdi(two, 0.9, multimodal=False).shape == (2,)
+    assert hdi(np.full(10, 0.3), 0.9, multimodal=True).tolist() == [[0.3, 0.3]]
+
+
+def test_expected_minimum_on_a_known_surrogate():
+    """utils.expected_minimum (skopt.utils.expected_minimum, called at bask/optimizer.py:497): bounded L-BFGS-B on
+    the surrogate mean from the incumbent + random starts, in the ORIGINAL space."""
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd.space import Space, create_result
+    from bayes_skopt_amd.utils import expected_minimum
+
+    space = Space([(-2.0, 2.0), (0.0, 10.0)])
+
+    class Model:  # mean over the unit cube with a unique minimum at the image of (0.5, 7.0), a local one elsewhere
+        calls = 0
+
+        def predict(self, Xt):
+            Model.calls += 1
+            Xt = np.asarray(Xt)
+            assert Xt.min() >= -1e-6 and Xt.max() <= 1 + 1e-6  # transformed coordinates, inside the bounds
+            a, b = Xt[:, 0] - 0.625, Xt[:, 1] - 0.7
+            return 3.0 * a * a + b * b - 0.3 * np.exp(-200.0 * ((Xt[:, 0] - 0.1) ** 2 + (Xt[:, 1] - 0.1) ** 2))
+
+    res = create_result([[-1.6, 1.0]], [0.0], space, models=[Model()])
+    x, f = expected_minimum(res, n_random_starts=15, random_state=0)
+    np.testing.assert_allclose(x, [0.5, 7.0], atol=1e-4)
+    assert abs(f) < 1e-8
+    # a start on the upper bound must difference backwards (never leaves the box)
+    res2 = create_result([[2.0, 10.0]], [0.0], space, models=[Model()])
+    x2, _ = expected_minimum(res2, n_random_starts=0)
+    np.testing.assert_allclose(x2, [0.5, 7.0], atol=1e-4)
+    with pytest.raises(ValueError):
+        expected_minimum(create_result([["a"]], [0.0], Space([["a", "b"]]), models=[Model()]))

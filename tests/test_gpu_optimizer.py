@@ -184,3 +184,74 @@ def test_tell_loop_pvrs_small(bask):
     nxt = opt.ask()
     assert len(nxt) == 3 and all(0.0 <= v <= 1.0 for v in nxt)
     assert res.fun == min(opt.yi)
+
+
+# ---- post-hoc diagnostics (tests/test_optimizer.py:85-175 of the reference).  The reference pins its numbers to
+# two decimals through emcee's stream and numpy's SVD-based MVN draws; the function draws here come from a device
+# Cholesky factor (same distribution, different variates), so the same quantities are checked within their Monte
+# Carlo error (200 draws: +-0.03 on a probability of 0.86) instead of to two decimals.
+def _five_point_optimizer(bask, seed):
+    opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=0, random_state=np.random.RandomState(seed))
+    opt.tell([[-2.0], [-1.0], [0.0], [1.0], [2.0]], [2.0, 0.0, -2.0, 0.0, 2.0], gp_burnin=10)
+    return opt
+
+
+@pytest.mark.parametrize(
+    "kw,expected",
+    [
+        (dict(normalized_scores=False, threshold=1.0), 0.99),
+        (dict(normalized_scores=False, threshold=(0.9, 0.5)), (0.98, 0.86)),
+        (dict(normalized_scores=True, threshold=1.0), 0.99),
+    ],
+)
+def test_probability_of_optimality(bask, kw, expected):
+    opt = _five_point_optimizer(bask, 0)
+    prob = opt.probability_of_optimality(threshold=kw["threshold"], n_random_starts=100,
+                                         random_state=np.random.RandomState(0),
+                                         normalized_scores=kw["normalized_scores"])
+    np.testing.assert_allclose(prob, expected, atol=0.08)
+    assert np.all(np.asarray(prob) <= 1.0) and np.all(np.asarray(prob) >= 0.0)
+
+
+def test_probability_of_optimality_is_monotone_in_the_threshold(bask):
+    opt = _five_point_optimizer(bask, 1)
+    p = opt.probability_of_optimality(threshold=[0.0, 0.25, 0.5, 1.0, 2.0], n_random_starts=20, random_state=3,
+                                      normalized_scores=False)
+    assert all(b >= a for a, b in zip(p, p[1:]))
+    assert p[-1] > 0.97
+
+
+@pytest.mark.parametrize(
+    "kw,expected",
+    [
+        (dict(normalized_scores=False, use_mean_gp=True), 0.3),
+        (dict(normalized_scores=True, use_mean_gp=True), 0.25),
+        (dict(normalized_scores=True, use_mean_gp=False), 0.29),
+    ],
+)
+def test_expected_optimality_gap(bask, kw, expected):
+    opt = _five_point_optimizer(bask, 0)
+    gap = opt.expected_optimality_gap(random_state=np.random.RandomState(0), n_probabilities=10, n_space_samples=100,
+                                      n_gp_samples=100, n_random_starts=10, tol=0.1, use_mean_gp=kw["use_mean_gp"],
+                                      normalized_scores=kw["normalized_scores"])
+    assert 0.0 < gap < 1.0
+    np.testing.assert_allclose(gap, expected, atol=0.15)
+
+
+def test_optimum_intervals(bask):
+    opt = bask.Optimizer(dimensions=[(0.0, 1.0)], random_state=0, acq_func="mean", n_points=100)
+    x = np.linspace(0, 1, num=20)[:, None]
+    y = np.cos(np.pi * 4 * x).flatten() + opt.rng.randn(20) * 0.1
+    opt.tell(x.tolist(), y.tolist(), gp_burnin=20, progress=False, n_samples=1)
+    intervals = opt.optimum_intervals(random_state=0, space_samples=100)
+    assert len(intervals) == 1
+    assert len(intervals[0]) >= 2          # cos(4 pi x) has two minima on [0, 1]
+    assert len(intervals[0][0]) == 2
+    centres = sorted(np.mean(iv) for iv in intervals[0])
+    assert abs(centres[0] - 0.25) < 0.1 and abs(centres[-1] - 0.75) < 0.1
+    intervals = opt.optimum_intervals(random_state=0, space_samples=100, multimodal=False)
+    assert len(intervals) == 1
+    assert len(intervals[0]) == 2
+    opt_cat = bask.Optimizer(dimensions=[(0.0, 1.0), ["a", "b"]], n_initial_points=2)
+    with pytest.raises(NotImplementedError):
+        opt_cat.optimum_intervals()
