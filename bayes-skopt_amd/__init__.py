@@ -9,13 +9,15 @@ C-ABI of ``include/bgp.h`` (``lib/libbgp.so``), bound with ctypes.  No CPU fallb
 """
 __version__ = "0.1.0"
 
-from . import _lib, acquisition, distributed, init, kernels, priors, sampler, space, utils  # noqa: F401
+from . import _lib, acquisition, distributed, init, kernels, priors, sampler, searchcv, space, utils  # noqa: F401
 from .bayesgpr import BayesGPR
 from .optimizer import Optimizer
+from .searchcv import BayesSearchCV
 from .utils import construct_default_kernel, geometric_median, guess_priors, r2_sequence  # noqa: F401
 
 __all__ = [
     "BayesGPR",
+    "BayesSearchCV",
     "Optimizer",
     "acquisition",
     "geometric_median",

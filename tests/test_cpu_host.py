@@ -268,3 +268,43 @@ def test_expected_minimum_on_a_known_surrogate():
     np.testing.assert_allclose(x2, [0.5, 7.0], atol=1e-4)
     with pytest.raises(ValueError):
         expected_minimum(create_result([["a"]], [0.0], Space([["a", "b"]]), models=[Model()]))
+
+
+def test_searchcv_initial_design_only_runs_on_cpu():
+    """BayesSearchCV (bask/searchcv.py) with fewer iterations than initial points never fits the GP, so the
+    scikit-learn plumbing (clone, cv_results_, refit, point <-> dict mapping in sorted key order) is testable
+    without a device."""
+    from sklearn.base import clone
+    from sklearn.datasets import load_iris
+    from sklearn.model_selection import train_test_split
+    from sklearn.svm import SVC
+
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd.space import Categorical, Integer, Real
+
+    X, y = load_iris(return_X_y=True)
+    Xtr, Xte, ytr, yte = train_test_split(X, y, train_size=0.75, random_state=0)
+    spaces = {
+        "C": Real(1e-6, 1e6, prior="log-uniform"),
+        "gamma": Real(1e-6, 1e1, prior="log-uniform"),
+        "degree": Integer(1, 8),
+        "kernel": Categorical(["linear", "poly", "rbf"]),
+    }
+    opt = bask.BayesSearchCV(SVC(), spaces, n_iter=6, cv=3, random_state=0)
+    assert clone(opt).get_params()["n_iter"] == 6 and opt.total_iterations == 6
+    opt.fit(Xtr, ytr)
+    assert len(opt.cv_results_["params"]) == 6
+    assert set(opt.best_params_) == set(spaces)
+    assert opt.best_params_["kernel"] in ("linear", "poly", "rbf") and 1 <= opt.best_params_["degree"] <= 8
+    assert opt.best_score_ == max(opt.cv_results_["mean_test_score"])
+    assert opt.score(Xte, yte) > 0.6
+    assert len(opt.optimizer_results_) == 1 and len(opt.optimizer_results_[0].x_iters) == 6
+    assert opt.optimizer_kwargs_["acq_func"] == "pvrs"  # bask/searchcv.py:289-290
+    # list-of-(dict, n_iter) form
+    two = bask.BayesSearchCV(SVC(), [({"C": Real(1e-3, 1e3, prior="log-uniform")}, 2), ({"gamma": Real(1e-4, 1.0)}, 3)],
+                             cv=3, random_state=1)
+    assert two.total_iterations == 5
+    two.fit(Xtr, ytr)
+    assert len(two.cv_results_["params"]) == 5 and len(two.optimizer_results_) == 2
+    with pytest.raises(ValueError):
+        bask.BayesSearchCV(SVC(), [({"C": Real(1e-3, 1e3)}, 0)]).fit(Xtr, ytr)
