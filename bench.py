@@ -78,6 +78,30 @@ def cpu_baseline(X, y, thetas, budget_s=20.0):
     }
 
 
+def cpu_baseline_sklearn(X, y, thetas, budget_s=10.0):
+    """The call the reference itself makes per walker (bask/bayesgpr.py:374): scikit-learn's
+    GaussianProcessRegressor.log_marginal_likelihood(theta) -- third-party code present in the image on both
+    sides, timed on the same bounded sample next to the oracle restatement (they agree to 1e-12)."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import ConstantKernel, Matern, WhiteKernel
+
+    d = X.shape[1]
+    k = ConstantKernel(1.0, (0.1, 2.0)) * Matern(length_scale=[0.3] * d, length_scale_bounds=(0.2, 0.5), nu=2.5) \
+        + WhiteKernel(0.01)
+    gpr = GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
+    vals = [gpr.log_marginal_likelihood(thetas[0])]  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    for th in thetas:
+        vals.append(gpr.log_marginal_likelihood(th))
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "LML-evals/s", "kind": "sklearn 1.7 GaussianProcessRegressor.log_marginal_likelihood",
+            "sample": f"{done} sequential evaluations, {dt:.1f} s"}, vals[1:]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +269,13 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
             line["speedup_vs_cpu_baseline"] = value / (1 if ensemble else ws) / line["cpu_baseline"]["value"]
+            try:  # the reference's own per-walker call, and a live parity check of the device path against it
+                sk, sk_vals = cpu_baseline_sklearn(X, y, pos[:32])
+                dev_vals = gp._ctx.lml(gp._canonical(pos[: len(sk_vals)]))
+                sk["max_rel_diff_device_vs_sklearn"] = float(np.max(np.abs(dev_vals - np.array(sk_vals)) / np.abs(sk_vals)))
+                line["cpu_baseline_sklearn"] = sk
+            except Exception as exc:  # reported, never fatal for the bench line
+                line["cpu_baseline_sklearn"] = {"error": repr(exc)}
         print(json.dumps(line))
     if ws > 1:
         import torch.distributed as dist
