@@ -533,9 +533,13 @@ class BayesGPR:
         """Predictive mean [, std | cov] (``bask/bayesgpr.py:622-635`` -> skopt predict)."""
         if return_std and return_cov:
             raise RuntimeError("Not returning standard deviation of predictions when returning full covariance.")
-        if return_mean_grad or return_std_grad:
-            raise NotImplementedError("prediction gradients are not implemented on the MI355X path")
+        if return_std_grad and not return_std:
+            raise ValueError("Not returning std_gradient without returning the std.")
+        if return_std_grad and not return_mean_grad:
+            raise ValueError("Not returning std_gradient without returning the mean_gradient.")
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if return_mean_grad and X.shape[0] > 1:
+            raise NotImplementedError("Not implemented for n_samples > 1")
         if self.warp_inputs:
             validate_zeroone(X)  # the device warps the query points with the context-level warp
         if self._post_theta is None or getattr(self, "_X_train_", None) is None:
@@ -548,9 +552,57 @@ class BayesGPR:
             return y_mean, cov[0] * self.y_train_std_**2
         mean, var = self._ctx.predict(Hk, X)
         y_mean = self.y_train_std_ * mean[0] + self.y_train_mean_
+        y_std = np.sqrt(var[0] * self.y_train_std_**2)
+        if return_mean_grad:
+            grad_mean, grad_std = self._predict_gradients(X[0], Hk[0], y_std, return_std_grad)
+            if return_std_grad:
+                return y_mean, y_std, grad_mean, grad_std
+            return (y_mean, y_std, grad_mean) if return_std else (y_mean, grad_mean)
         if return_std:
-            return y_mean, np.sqrt(var[0] * self.y_train_std_**2)
+            return y_mean, y_std
         return y_mean
+
+    def _predict_gradients(self, x, hk, y_std, want_std_grad):
+        """Gradients of the predictive mean / std at ONE query point (skopt's
+        ``GaussianProcessRegressor.predict(return_mean_grad, return_std_grad)``, the routine
+        ``bask/bayesgpr.py:633`` forwards to): ``grad = kernel_.gradient_x(x, X_train_)`` (n, d),
+        ``grad_mean = grad^T alpha_``, ``grad_std = -K_* K_inv_ grad / std``.  O(n d) + one O(n^2) product on
+        the host from the device-built ``alpha_`` / ``K_inv_``; with input warping the derivative is with
+        respect to the warped coordinates, as in the reference."""
+        Xt = self.X_train_
+        if self.warp_inputs:
+            x = self.warp(x[None, :])[0]
+        d = Xt.shape[1]
+        ell2 = np.exp(2.0 * hk[1 : d + 1])
+        diff = x[None, :] - Xt                       # (n, d)
+        r = np.sqrt(np.sum(diff * diff / ell2, axis=1))
+        stat = self._plan.stationary
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if stat == "rbf":
+                S = np.exp(-0.5 * r * r)
+                fac = -S
+            elif stat == "matern12":
+                S = np.exp(-r)
+                fac = np.where(r > 0, -S / r, 0.0)
+            elif stat == "matern32":
+                e = np.exp(-np.sqrt(3.0) * r)
+                S = (1.0 + np.sqrt(3.0) * r) * e
+                fac = -3.0 * e
+            else:
+                e = np.exp(-np.sqrt(5.0) * r)
+                S = (1.0 + np.sqrt(5.0) * r + 5.0 / 3.0 * r * r) * e
+                fac = -(5.0 / 3.0) * (1.0 + np.sqrt(5.0) * r) * e
+        cst = np.exp(hk[0])
+        scale = cst if self._plan.form == "product" else 1.0
+        grad = scale * fac[:, None] * diff / ell2     # d k(x, X_i) / d x   (Constant / White terms: zero)
+        grad_mean = (grad.T @ self.alpha_) * self.y_train_std_
+        if not want_std_grad:
+            return grad_mean, None
+        grad_std = np.zeros(d)
+        if not np.allclose(y_std, 0.0):
+            k_trans = cst * S if self._plan.form == "product" else cst + S
+            grad_std = -(k_trans @ (self.K_inv_ @ grad)) / y_std[0] * self.y_train_std_**2
+        return grad_mean, grad_std
 
     def _make_resident(self):
         """Make sure the device holds the posterior that alpha_/L_/K_inv_ describe."""

@@ -166,3 +166,43 @@ def test_device_chain_equals_oracle_chain(bask):
     np.testing.assert_allclose(dev_chain, ref_chain, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(gp._sampler.get_log_prob(), ref_lp, rtol=1e-8)
     np.testing.assert_allclose(gp.theta, O.geometric_median(ref_chain.reshape(-1, d + 2)), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["matern52", "matern32", "rbf", "sum_matern12"])
+def test_predict_gradients_match_finite_differences(bask, kind):
+    """predict(return_mean_grad, return_std_grad) (skopt's predict, forwarded at bask/bayesgpr.py:633): the
+    analytic gradients at one query point against central differences of the device predict itself."""
+    from bayes_skopt_amd.kernels import RBF, ConstantKernel, Matern
+
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(60, 3))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.05 * rng.randn(60)
+    kernel = {
+        "matern52": ConstantKernel(1.0, (0.1, 2.0)) * Matern([0.4, 0.3, 0.5], (0.2, 0.8), nu=2.5),
+        "matern32": ConstantKernel(1.0, (0.1, 2.0)) * Matern(0.4, (0.2, 0.8), nu=1.5),
+        "rbf": ConstantKernel(1.0, (0.1, 2.0)) * RBF([0.4, 0.3, 0.5], (0.2, 0.8)),
+        "sum_matern12": ConstantKernel(0.5, (0.1, 2.0)) + Matern(0.6, (0.2, 0.9), nu=0.5),
+    }[kind]
+    gp = bask.BayesGPR(kernel=kernel, random_state=0, normalize_y=True)
+    gp.fit(X, y, n_desired_samples=40, n_burnin=5, n_walkers_per_thread=20, progress=False)
+    x0 = np.array([[0.37, 0.52, 0.61]])
+    with gp.noise_set_to_zero():
+        mu, std, gmu, gstd = gp.predict(x0, return_std=True, return_mean_grad=True, return_std_grad=True)
+        mu2, gmu2 = gp.predict(x0, return_mean_grad=True)
+        h = 1e-5
+        fd_mu, fd_std = np.zeros(3), np.zeros(3)
+        for k in range(3):
+            e = np.zeros(3)
+            e[k] = h
+            mp, sp = gp.predict(x0 + e, return_std=True)
+            mm, sm = gp.predict(x0 - e, return_std=True)
+            fd_mu[k] = (mp[0] - mm[0]) / (2 * h)
+            fd_std[k] = (sp[0] - sm[0]) / (2 * h)
+    assert gmu.shape == (3,) and gstd.shape == (3,)
+    np.testing.assert_allclose(gmu, gmu2)
+    np.testing.assert_allclose(gmu, fd_mu, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(gstd, fd_std, rtol=2e-4, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        gp.predict(np.vstack([x0, x0]), return_mean_grad=True)
+    with pytest.raises(ValueError):
+        gp.predict(x0, return_std_grad=True)
