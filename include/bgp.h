@@ -164,10 +164,13 @@ int bgp_pvrs_prepare(bgp_ctx* ctx, const double* h_kernel, int has_alpha_vec, in
 int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                  const double* z, double jitter, double* out);
 
-/* Number of walker groups (HIP streams) an LML batch is split over: the latency-bound diagonal-block
- * factorisations of one group can overlap the MFMA-bound trailing updates of another.  Default 1
- * (everything on one stream; measured gain of 2 groups on MI355X is only ~3 % because the trailing
- * updates already fill every CU); environment BGP_STREAMS overrides at context creation. */
+/* Number of walker groups (HIP streams) an LML batch is split over: one group's kernels fill the tail
+ * of the other group's launches.  Default: automatic -- two groups for batches of >= 64 matrices (+3.7 % at
+ * n = 2048 x 128 matrices on MI355X, results bit-identical), one group below that (every group's dependent
+ * chain is as long as the whole batch's, nothing to gain).  This call, or the environment variable
+ * BGP_STREAMS read at context creation, forces a fixed group count.  Other environment switches read at
+ * context creation: BGP_PANELS (block columns per trailing update, default 2), and the experimental
+ * BGP_TWO_PANEL=0, BGP_SYRK3=1, BGP_LEFT_LOOKING=1. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */
