@@ -186,61 +186,58 @@ class Optimizer:
             replace = False
         return create_result(self.Xi, self.yi, self.space, self.rng, models=[self.gp])
 
+    def _optimum_vs_space_draws(self, n_space_samples, n_gp_samples, n_random_starts, use_mean_gp, seed):
+        """Function draws (device ``sample_y``) at [expected optimum, n_space_samples random points]:
+        (1 + n_space_samples, n_gp_samples); row 0 belongs to the minimiser of the surrogate mean found by
+        ``utils.expected_minimum`` (``bask/optimizer.py:493-512``).  ``seed`` is handed unchanged to each of the
+        three consumers, as the reference does."""
+        res = create_result(self.Xi, self.yi, self.space, self.rng, models=[self.gp])
+        x_opt, _ = expected_minimum(res, n_random_starts=n_random_starts, random_state=seed)
+        points = [x_opt] + self.space.rvs(n_samples=n_space_samples, random_state=seed)
+        return self.gp.sample_y(self.space.transform(points), sample_mean=use_mean_gp, n_samples=n_gp_samples,
+                                random_state=seed)
+
     def probability_of_optimality(self, threshold, n_space_samples=500, n_gp_samples=200, n_random_starts=100,
                                   use_mean_gp=True, normalized_scores=True, random_state=None):
-        """Probability that the current expected optimum cannot be improved by more than ``threshold``
-        (``bask/optimizer.py:447-525``, same arguments): the expected optimum and ``n_space_samples`` random
-        points are scored under ``n_gp_samples`` function draws of the GP (device ``sample_y``: median GP, or
-        one posterior build per hyper-posterior sample when ``use_mean_gp=False``)."""
-        result = create_result(self.Xi, self.yi, self.space, self.rng, models=[self.gp])
-        X_orig = [expected_minimum(result, random_state=random_state, n_random_starts=n_random_starts)[0]]
-        X_orig.extend(self.space.rvs(n_samples=n_space_samples, random_state=random_state))
-        X_trans = self.space.transform(X_orig)
-        score_samples = self.gp.sample_y(X_trans, n_samples=n_gp_samples, sample_mean=use_mean_gp,
-                                         random_state=random_state)
+        """Probability that no point of the space beats the current expected optimum by more than
+        ``threshold`` (a float, or a list giving a list of probabilities) -- ``bask/optimizer.py:447-525``,
+        same arguments.  With ``normalized_scores`` the gaps are measured in units of each draw's standard
+        deviation over the points."""
+        draws = self._optimum_vs_space_draws(n_space_samples, n_gp_samples, n_random_starts, use_mean_gp, random_state)
+        gap = draws[0][None, :] - draws          # how much better every point is than the optimum, per draw
         if normalized_scores:
-            std = np.std(score_samples, axis=0)
-        thresholds = threshold if is_listlike(threshold) else [threshold]
-        probabilities = []
-        for eps in thresholds:
-            diff = score_samples[0][None, :] - score_samples
-            if normalized_scores:
-                diff = diff / std
-            probabilities.append(float(((diff - eps).max(axis=0) < 0.0).mean()))
-        return probabilities[0] if len(probabilities) == 1 else probabilities
+            gap = gap / np.std(draws, axis=0)
+        worst = gap.max(axis=0)                  # the best competitor in each draw
+        probs = [float(np.mean(worst - eps < 0.0)) for eps in (threshold if is_listlike(threshold) else [threshold])]
+        return probs if is_listlike(threshold) and len(probs) > 1 else probs[0]
 
     def expected_optimality_gap(self, max_tries=3, n_probabilities=50, n_space_samples=500, n_gp_samples=200,
                                 n_random_starts=100, tol=0.01, use_mean_gp=True, normalized_scores=True,
                                 random_state=None):
         """Expected optimality gap of the current global optimum (``bask/optimizer.py:527-620``): the
-        cumulative distribution of the gap is traced with ``probability_of_optimality`` on a threshold grid
-        whose upper end is found by bounded scalar minimisation."""
+        distribution function of the gap is sampled with ``probability_of_optimality`` on ``n_probabilities``
+        thresholds between 0 and the smallest threshold at which the probability reaches 1 (found by a
+        bounded scalar minimisation of ``(p - 1)^2 + 1e-3 t^2``, at most ``max_tries`` attempts)."""
         from scipy.optimize import minimize_scalar
 
-        random_state = check_random_state(random_state)
-        seed = random_state.randint(0, 2**32 - 1, dtype=np.int64)
-        common = dict(n_random_starts=n_random_starts, n_gp_samples=n_gp_samples, n_space_samples=n_space_samples,
-                      use_mean_gp=use_mean_gp, normalized_scores=normalized_scores, random_state=seed)
-
-        def func(threshold):
-            prob = self.probability_of_optimality(threshold=threshold, **common)
-            return (prob - 1.0) ** 2 + threshold**2 * 1e-3
-
-        max_observed_gap = np.max(self.yi) - np.min(self.yi)
+        seed = check_random_state(random_state).randint(0, 2**32 - 1, dtype=np.int64)
+        kw = dict(n_space_samples=n_space_samples, n_gp_samples=n_gp_samples, n_random_starts=n_random_starts,
+                  use_mean_gp=use_mean_gp, normalized_scores=normalized_scores, random_state=seed)
+        span = float(np.max(self.yi) - np.min(self.yi))
+        upper = None
         for _ in range(max_tries):
             try:
-                upper_threshold = minimize_scalar(func, bounds=(0.0, max_observed_gap), tol=tol).x
-                break
+                upper = minimize_scalar(
+                    lambda t: (self.probability_of_optimality(threshold=t, **kw) - 1.0) ** 2 + 1e-3 * t * t,
+                    bounds=(0.0, span), tol=tol).x
             except ValueError:
-                pass
-        else:
+                continue
+            break
+        if upper is None:
             raise ValueError("Determining the upper threshold was not possible.")
-        thresholds = list(np.linspace(0, upper_threshold, num=n_probabilities))
-        probabilities = self.probability_of_optimality(thresholds, **common)
-        expected_gap = 0.0
-        for i in range(len(probabilities) - 1):
-            expected_gap += (probabilities[i + 1] - probabilities[i]) * thresholds[i + 1]
-        return expected_gap
+        grid = np.linspace(0.0, upper, num=n_probabilities)
+        cdf = np.asarray(self.probability_of_optimality(list(grid), **kw), dtype=np.float64)
+        return float(np.sum(np.diff(cdf) * grid[1:]))
 
     def optimum_intervals(self, hdi_prob=0.95, multimodal=True, opt_samples=200, space_samples=500, only_mean=True,
                           random_state=None):
