@@ -65,13 +65,17 @@ static __device__ __forceinline__ double bc16(double v) {
   return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xF, 0xF, false);  // row_newbcast:C (all lanes written)
 }
 
+// One fused instruction per update: v_fmac_f64 with a DPP row broadcast on its first source (64-bit DPP
+// supports exactly this control on gfx90a+):  D += bcast_C(a[J]) * S1.
+#define PF_FMAC_BCAST(D, SRC, S1, C)                                                                  \
+  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(D) : "v"(SRC), "v"(S1), "n"(C))
+
 template <int J, int C>
-static __device__ __forceinline__ void micro_cols(double (&a)[16], double (&macc)[16], double mj) {
+static __device__ __forceinline__ void micro_cols(double (&a)[16], double (&macc)[16], double naj, double mj) {
   if constexpr (C < 16) {
-    const double l = bc16<C>(a[J]);
-    a[C] = fma(-a[J], l, a[C]);
-    macc[C] = fma(l, mj, macc[C]);
-    micro_cols<J, C + 1>(a, macc, mj);
+    PF_FMAC_BCAST(a[C], a[J], naj, C);     // a[C]    -= L[lane][J] * L[C][J]
+    PF_FMAC_BCAST(macc[C], a[J], mj, C);   // macc[C] += L[C][J] * M[J][lane]
+    micro_cols<J, C + 1>(a, macc, naj, mj);
   }
 }
 
@@ -79,6 +83,7 @@ template <int J>
 static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr,
                                                       int& bad) {
   if constexpr (J < 16) {
+    asm volatile("s_nop 1");  // a[J] was last written by the inline-asm updates above: DPP read hazard (2 wait states)
     const double djj = bc16<J>(a[J]);
     bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
     // sqrt and 1/sqrt together from the hardware seed by one coupled (Goldschmidt) step: three dependent
@@ -90,9 +95,11 @@ static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&
     const double hh = fma(h, r, h);
     const double inv = hh + hh;            // 1 / sqrt(djj)
     a[J] = (lr == J) ? dj : a[J] * inv;
+    const double naj = -a[J];
     const double mj = (((lr == J) ? 1.0 : 0.0) - macc[J]) * inv;  // M[J][lane]
     mrow[J] = mj;
-    micro_cols<J, J + 1>(a, macc, mj);
+    if constexpr (J < 15) asm volatile("s_nop 1" ::"v"(a[J]), "v"(naj), "v"(mj));  // VALU write -> DPP read
+    micro_cols<J, J + 1>(a, macc, naj, mj);
     micro_chol_inv<J + 1>(a, macc, mrow, lr, bad);
   }
 }
@@ -185,7 +192,8 @@ static __device__ __forceinline__ void pf_wfinish(d4 acc, double* __restrict__ s
   for (int r = 0; r < 4; r++) Wg[(I * 16 + lk + 4 * r) * 128 + J * 16 + lr] = wn[r];
 }
 
-__global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
+#define PF_THREADS 512
+__global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                      double* __restrict__ yw, double* __restrict__ accb,
                                                      double* __restrict__ lml, int* __restrict__ status, int n,
                                                      int ld, size_t mstride, int ystride, int nblk, int k) {
@@ -195,8 +203,8 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   __shared__ double Minv[8 * 16 * PF_MLD];
   __shared__ double xrow[2][16 * PF_MLD];  // X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
   __shared__ double ylds[128];
-  __shared__ double zpart[2 * 128];
-  __shared__ double red[8];
+  __shared__ double zpart[4 * 128];
+  __shared__ double red[16];
   __shared__ int fail_lds;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
@@ -205,19 +213,19 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   PF_T(0);
 
   {
-    // lower triangle of the tile -> LDS, all 32 16-byte loads of a thread in flight at once (the block is
+    // lower triangle of the tile -> LDS, all 16 16-byte loads of a thread in flight at once (the block is
     // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
-    // (t >> 6) + 4 i; pairs entirely above the diagonal are never read.
+    // (t >> 6) + 8 i; pairs entirely above the diagonal are never read.
     const int seg = tid & 63, rbase = tid >> 6;
-    d2 v[32];
+    d2 v[16];
 #pragma unroll
-    for (int u = 0; u < 32; u++) {
-      const int row = rbase + 4 * u;
+    for (int u = 0; u < 16; u++) {
+      const int row = rbase + 8 * u;
       v[u] = (2 * seg <= row + 15) ? *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2) : (d2){0.0, 0.0};
     }
 #pragma unroll
-    for (int u = 0; u < 32; u++) {
-      const int row = rbase + 4 * u;
+    for (int u = 0; u < 16; u++) {
+      const int row = rbase + 8 * u;
       *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
     }
   }
@@ -237,8 +245,10 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   int failed = 0;
   d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written in place one step later (the update
                                         // waves still read the unscaled block T_{sb,sb-1} during this step)
-  d4 w7[2];                             // update waves: partial sums of row 7 of W, finished after the loop
-  w7[0] = w7[1] = (d4){0.0, 0.0, 0.0, 0.0};
+  d4 w7 = (d4){0.0, 0.0, 0.0, 0.0};     // update waves: partial sum of one block of row 7 of W, finished after the loop
+  // update waves: 1-3 and 5-7 (two per SIMD so that one's LDS latency hides behind the other's MFMAs); wave 4
+  // shares the panel wave's SIMD and stays idle (every VALU / MFMA issue there would delay the pivot chain)
+  const int u6 = (w < 4) ? w - 1 : w - 2;  // 0..5 for the update waves
 #pragma unroll 1
   for (int sb = 0; sb < 8; sb++) {
     if (w == 0) {
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
 #pragma unroll
         for (int c = 0; c < 16; c++) s[(sb * 16 + lr) * PF_LD + sb * 16 + c] = (c <= lr) ? a[c] : 0.0;
       }
-    } else if (sb > 0) {
+    } else if (sb > 0 && w != 4) {
       const int p = sb - 1;  // phase: M_p was published at the previous barrier
       d4 xt = (d4){0.0, 0.0, 0.0, 0.0};  // X_{p+1,p}^T (every update wave forms its own copy)
       if (p + 2 < 8) {
@@ -302,8 +312,7 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
           xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
         }
       }
-      for (int I = p + 2; I < 8; I++) {
-        if (I % 3 + 1 != w) continue;  // row ownership
+      for (int I = p + 2 + u6; I < 8; I += 6) {  // at most one row per update wave
         d4 xi = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
@@ -340,31 +349,23 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
         }
       }
       // row p of W = L^-1: M_p, its panel blocks (the last one via xrow) and rows < p of W are visible
-      // (blocks dealt to the three waves so that phase rows + W blocks balance: 4 bits per J, greedy by cost)
-      const unsigned wown = (p == 0) ? 0x1u : (p == 1) ? 0x33u : (p == 2) ? 0x331u : (p == 3) ? 0x2321u
-                          : (p == 4) ? 0x31233u : (p == 5) ? 0x311331u : 0x1321321u;
-      for (int J = 0; J <= p; J++) {
-        if ((int)((wown >> (4 * J)) & 15u) != w) continue;
+      // (heavy blocks = small J go to the waves without a phase row: rows occupy update waves 0 .. 5-p)
+      for (int J = 5 - u6; J <= p; J += 6) {
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         if (J < p) acc = pf_wsum(acc, s, Minv, xrow[p & 1], p, J, J, p, lane);
         pf_wfinish(acc, s, Minv, Wg, p, J, lane);
       }
       // row block sb-2 of L is final and visible: stream it out now (lower triangle, 16-byte pairs)
       if (sb >= 2 && sb <= 6) {  // (the last step is the update waves' busiest: blocks 5..7 go out after the loop)
-        const int R = sb - 2, ut = tid - 64;  // 192 update threads: 12 per row
-        const int rr = ut / 12, c0 = ut - 12 * rr, row = R * 16 + rr;
-        for (int seg = c0; seg < 8 * R + 8; seg += 12) {
+        const int R = sb - 2, ut = u6 * 64 + lane;  // 384 update threads: 24 per row
+        const int rr = ut / 24, c0 = ut - 24 * rr, row = R * 16 + rr;
+        for (int seg = c0; seg < 8 * R + 8; seg += 24) {
           if (2 * seg <= row)
             *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
         }
       }
-      // last step: rows <= 5 of W are complete -> the terms K <= 5 of row 7 (two blocks per wave)
-      if (sb == 7) {
-        for (int q = 0; q < 2; q++) {
-          const int J = (3 - w) + 3 * q;  // J = 0..5, heavy blocks to the wave with the lightest row-6 share
-          w7[q] = pf_wsum(w7[q], s, Minv, nullptr, 7, J, J, 6, lane);
-        }
-      }
+      // last step: rows <= 5 of W are complete -> the terms K <= 5 of row 7 (one block per update wave)
+      if (sb == 7) w7 = pf_wsum(w7, s, Minv, nullptr, 7, u6, u6, 6, lane);  // block J = u6 (W row 6 went 5 - u6)
     }
     __syncthreads();
     PF_T(2 + sb * 3);
@@ -384,9 +385,9 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
   // in the panel wave's registers and goes out from there.  The stores drain while row 7 of W is formed.
   {
     const int seg = tid & 63, rbase = tid >> 6;
-#pragma unroll 8
-    for (int i = 20; i < 32; i++) {  // row blocks 5, 6 and 7 (0..4 went out inside the loop)
-      const int row = rbase + 4 * i;
+#pragma unroll
+    for (int i = 10; i < 16; i++) {  // row blocks 5, 6 and 7 (0..4 went out inside the loop)
+      const int row = rbase + 8 * i;
       if (2 * seg <= row && !(row >= 112 && seg >= 48 && seg < 56))
         *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
     }
@@ -399,46 +400,41 @@ __global__ void __launch_bounds__(256) potrf_kernel(double* __restrict__ Kbuf, d
     acc = pf_wsum(acc, s, Minv, xrow[1], 7, 6, 6, 7, lane);
     pf_wfinish(acc, s, Minv, Wg, 7, 6, lane);
     pf_wfinish(acc, s, Minv, Wg, 7, 7, lane);
-  } else {
-    for (int q = 0; q < 2; q++) {
-      const int J = (3 - w) + 3 * q;
-      w7[q] = pf_wsum(w7[q], s, Minv, xrow[1], 7, J, 6, 7, lane);
-      pf_wfinish(w7[q], s, Minv, Wg, 7, J, lane);
-    }
+  } else if (w != 4) {
+    w7 = pf_wsum(w7, s, Minv, xrow[1], 7, u6, 6, 7, lane);
+    pf_wfinish(w7, s, Minv, Wg, 7, u6, lane);
   }
   double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
   for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
   if (lane == 0) red[w] = ldv;
   __syncthreads();
   PF_T(27);
-  // ---- z = W y from the LDS copy of W (transposed in the upper triangle, diagonal blocks in Minv); two
+  // ---- z = W y from the LDS copy of W (transposed in the upper triangle, diagonal blocks in Minv); four
   // threads per row, fixed summation order (bitwise reproducible)
   {
-    const int row = tid & 127, h = tid >> 7, Ib = row >> 4, ri = row & 15;
-    double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;  // four chains (16 Ib is a multiple of 8), fixed order
+    const int row = tid & 127, h = tid >> 7, Ib = row >> 4, ri = row & 15;  // h = 0..3
+    double z0 = 0.0, z1 = 0.0;  // two chains (16 Ib is a multiple of 8), fixed order
     for (int j = h; j < 16 * Ib; j += 8) {
       z0 = fma(s[j * PF_LD + row], ylds[j], z0);
-      z1 = fma(s[(j + 2) * PF_LD + row], ylds[j + 2], z1);
-      z2 = fma(s[(j + 4) * PF_LD + row], ylds[j + 4], z2);
-      z3 = fma(s[(j + 6) * PF_LD + row], ylds[j + 6], z3);
+      z1 = fma(s[(j + 4) * PF_LD + row], ylds[j + 4], z1);
     }
-    double zs = (z0 + z1) + (z2 + z3);
-    for (int jj = h; jj <= ri; jj += 2) zs = fma(Minv[Ib * 16 * PF_MLD + ri * PF_MLD + jj], ylds[16 * Ib + jj], zs);
+    double zs = z0 + z1;
+    for (int jj = h; jj <= ri; jj += 4) zs = fma(Minv[Ib * 16 * PF_MLD + ri * PF_MLD + jj], ylds[16 * Ib + jj], zs);
     zpart[h * 128 + row] = zs;
   }
   __syncthreads();
   double zv = 0.0;
   if (tid < 128) {
-    zv = zpart[tid] + zpart[128 + tid];
+    zv = (zpart[tid] + zpart[128 + tid]) + (zpart[256 + tid] + zpart[384 + tid]);
     yk[tid] = zv;
   }
   double zz = zv * zv;
   for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
-  if (lane == 0) red[4 + w] = zz;
+  if (lane == 0) red[8 + w] = zz;
   __syncthreads();
   if (tid == 0) {
-    double ldt = red[0] + red[1] + red[2] + red[3];
-    double zzt = red[4] + red[5] + red[6] + red[7];
+    double ldt = red[0] + red[1];  // threads 0..127 (waves 0 and 1) hold the diagonal and z
+    double zzt = red[8] + red[9];
     ldt += ld_prev;
     zzt += zz_prev;
     accb[b * 4 + 0] = ldt;
@@ -685,7 +681,7 @@ void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
-  hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+  hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
                      ystride, ctx->nblk, k);
 }
 
@@ -718,7 +714,7 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
       const int np = std::min(P, nblk - k);
       for (int j = 0; j < np; j++) {
         bgp_tbegin(ctx, 1, st);
-        hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld,
+        hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld,
                            mstride, ystride, nblk, k + j);
         bgp_tend(ctx, st);
         if (k + j + 1 >= nblk) break;
@@ -751,7 +747,7 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
   }
   for (int k = 0; k < nblk; k++) {
     bgp_tbegin(ctx, 1, st);
-    hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(256), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
+    hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
                        ystride, nblk, k);
     bgp_tend(ctx, st);
     const int nlow = nblk - k - 1;
