@@ -106,3 +106,56 @@ def test_update_data_grows_n(lib):
         got = ctx.lml(th)
         np.testing.assert_allclose(got[0], O.lml(X[:n], y[:n], np.full(n, 1e-10), th[0]), rtol=RTOL)
     ctx.close()
+
+
+# ---- size-independent properties at the BASELINE full sizes (no CPU oracle needed at that size)
+def test_full_size_permutation_invariance(lib):
+    """LML(P X, P y) == LML(X, y): a row permutation changes every tile, every pivot order and every partial sum,
+    the value only by rounding (n = 4096, d = 32: BASELINE config D)."""
+    n, d = 4096, 32
+    X, y = synth(n, d, 7)
+    perm = np.random.RandomState(8).permutation(n)
+    H = np.concatenate([[0.1], np.full(d, np.log(0.35)), [np.log(0.02)]])[None, :] + \
+        0.05 * np.random.RandomState(9).randn(2, d + 2)
+    a = lib.Context(X, y, np.full(n, 1e-10), max_batch=2)
+    la = a.lml(H)
+    a.close()
+    b = lib.Context(X[perm], y[perm], np.full(n, 1e-10), max_batch=2)
+    lb = b.lml(H)
+    b.close()
+    np.testing.assert_allclose(la, lb, rtol=1e-10)
+
+
+def test_full_size_known_answer_white_dominated(lib):
+    """Signal variance -> 0: K = (c + s2 + alpha) I up to 1e-18, so the LML has the closed form
+    -y'y / (2 d0) - n/2 log d0 - n/2 log 2 pi at ANY size (n = 4096 and a ragged n = 3001)."""
+    for n, d in ((4096, 8), (3001, 3)):
+        X, y = synth(n, d, 11)
+        c, s2, a0 = np.exp(-42.0), 4.0, 1e-3
+        h = np.concatenate([[-42.0], np.full(d, np.log(0.3)), [np.log(s2)]])
+        ctx = lib.Context(X, y, np.full(n, a0), max_batch=1)
+        got = ctx.lml(h)[0]
+        ctx.close()
+        d0 = c + s2 + a0
+        ref = -0.5 * float(y @ y) / d0 - 0.5 * n * np.log(d0) - 0.5 * n * np.log(2 * np.pi)
+        np.testing.assert_allclose(got, ref, rtol=1e-12)
+
+
+def test_full_size_block_diagonal_additivity(lib):
+    """Two clusters further apart than the kernel's range: the cross-covariance underflows to exactly 0, K is block
+    diagonal and LML(A u B) = LML(A) + LML(B) + n/2-terms -- a checksum-of-checksums over 2 x 1024 points whose
+    blocks straddle the 128-row tiles differently in the joint and in the separate factorisations."""
+    na, nb, d = 1000, 1100, 4
+    rng = np.random.RandomState(21)
+    XA = rng.uniform(0.0, 0.2, size=(na, d))
+    XB = rng.uniform(0.8, 1.0, size=(nb, d))
+    yA, yB = np.sin(20 * XA.sum(1)), np.cos(17 * XB.sum(1))
+    h = np.concatenate([[0.2], np.full(d, np.log(2e-4)), [np.log(0.05)]])  # ell so small that exp(-sqrt5 r/ell) == 0 across
+    def lml_of(X, y):
+        ctx = lib.Context(X, y, np.full(len(y), 1e-10), max_batch=1)
+        v = ctx.lml(h)[0]
+        ctx.close()
+        return v
+    order = rng.permutation(na + nb)  # interleave the clusters: the block structure is hidden from the tiling
+    joint = lml_of(np.vstack([XA, XB])[order], np.concatenate([yA, yB])[order])
+    np.testing.assert_allclose(joint, lml_of(XA, yA) + lml_of(XB, yB), rtol=1e-12)
