@@ -1,0 +1,61 @@
+"""bench.py contract: one JSON line with the driver's keys plus `roofline`, on one GPU and as a 2-rank job
+(both ranks on GPU 0 over gloo -- the box has one device) in both sharding modes."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+        "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _line(res):
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    d = _line(res)
+    assert KEYS <= set(d)
+    assert d["metric"] == "mcmc_lml_evals_per_s_n2048" and d["n_gpus"] == 1 and d["dtype"] == "f64"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
+    assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+@pytest.mark.parametrize("shard", ["chains", "ensemble"])
+def test_bench_two_ranks_on_one_gpu(shard):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BGP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline", "--shard", shard]
+    d = _line(subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900))
+    assert KEYS <= set(d) and d["n_gpus"] == 2
+    if shard == "chains":   # independent 256-walker sub-ensemble per rank: whole-job evaluations = 2 x
+        assert d["scaling"] == "weak" and d["gathered_chain_rows"] == 2 * 2 * 256  # ranks x kept steps x walkers
+        assert abs(d["value"] - 2 * 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
+    else:                   # ONE 256-walker ensemble split over the ranks
+        assert d["scaling"] == "strong" and d["config"]["walkers_per_gpu"] == 128
+        assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
