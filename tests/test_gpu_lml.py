@@ -128,8 +128,9 @@ def test_full_size_permutation_invariance(lib):
 
 def test_full_size_known_answer_white_dominated(lib):
     """Signal variance -> 0: K = (c + s2 + alpha) I up to 1e-18, so the LML has the closed form
-    -y'y / (2 d0) - n/2 log d0 - n/2 log 2 pi at ANY size (n = 4096 and a ragged n = 3001)."""
-    for n, d in ((4096, 8), (3001, 3)):
+    -y'y / (2 d0) - n/2 log d0 - n/2 log 2 pi at ANY size (n = 4096, a ragged n = 3001, and n = 12288: 96 block
+    columns, a 1.2 GB matrix)."""
+    for n, d in ((4096, 8), (3001, 3), (12288, 4)):
         X, y = synth(n, d, 11)
         c, s2, a0 = np.exp(-42.0), 4.0, 1e-3
         h = np.concatenate([[-42.0], np.full(d, np.log(0.3)), [np.log(s2)]])
