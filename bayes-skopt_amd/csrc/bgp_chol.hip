@@ -626,14 +626,35 @@ __global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf
 
   if (I != J) {
     if (SPLIT == 2) {
+      // small launches are latency-bound: the next chunk's global loads are in flight (registers) while the
+      // current one is multiplied -- the half-size accumulator block leaves room for the 64 staging VGPRs
       d4 acc[2][4];
       const int r0 = half * 64 + wr * 32;
+      d2 va[8], vb[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int c = tid + 256 * i;
+        va[i] = *reinterpret_cast<const d2*>(XI + (size_t)(c >> 4) * ld + (c & 15) * 2);
+        vb[i] = *reinterpret_cast<const d2*>(XJ + (size_t)(c >> 4) * ld + (c & 15) * 2);
+      }
       gk_load_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
       for (int k0 = 0; k0 < K; k0 += GK_KC) {
         __syncthreads();
-        gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-        gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int c = tid + 256 * i;
+          *reinterpret_cast<d2*>(sm.A + (c >> 4) * GK_LD + (c & 15) * 2) = va[i];
+          *reinterpret_cast<d2*>(sm.B + (c >> 4) * GK_LD + (c & 15) * 2) = vb[i];
+        }
         __syncthreads();
+        if (k0 + GK_KC < K) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const int c = tid + 256 * i;
+            va[i] = *reinterpret_cast<const d2*>(XI + k0 + GK_KC + (size_t)(c >> 4) * ld + (c & 15) * 2);
+            vb[i] = *reinterpret_cast<const d2*>(XJ + k0 + GK_KC + (size_t)(c >> 4) * ld + (c & 15) * 2);
+          }
+        }
         gk_mma_block<2, 4, 1, 0, -64>(sm.A, sm.B, acc, r0, wc * 64, lane, k0);
       }
       gk_store_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
