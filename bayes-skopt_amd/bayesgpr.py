@@ -21,7 +21,7 @@ from contextlib import contextmanager, nullcontext
 
 import numpy as np
 import scipy.optimize
-from sklearn.base import clone
+from sklearn.base import BaseEstimator, RegressorMixin, clone
 from sklearn.utils import check_random_state
 
 from . import _lib, distributed
@@ -38,7 +38,7 @@ _PD_MESSAGE = (
 )
 
 
-class BayesGPR:
+class BayesGPR(RegressorMixin, BaseEstimator):
     """Gaussian process regressor of which the kernel hyper-parameters are inferred in a fully
     Bayesian framework (constructor arguments as ``bask/bayesgpr.py:148-159``).
 
@@ -82,13 +82,39 @@ class BayesGPR:
         self.pos_ = None
         self.kernel_ = None
         self.noise_ = None
-        self._ctx = None
+        self._ctx_obj = None  # device context (ctypes handle; never pickled, rebuilt on demand)
+        self._needs_rebuild = False
         self._plan = None
         self._post_theta = None  # theta the resident posterior (L_, alpha_, K_inv_) was built with
         self._L = self._K_inv = None
         self.alpha_ = None
 
     # ------------------------------------------------------------------ device plumbing
+    @property
+    def _ctx(self):
+        """The device context.  After unpickling / deep-copying (the ctypes handle does not travel) it is
+        rebuilt from the stored training data the first time something needs it."""
+        if self._ctx_obj is None and self._needs_rebuild:
+            self._needs_rebuild = False
+            saved = (self._post_theta, self.alpha_, self._L, self._K_inv)
+            self._ensure_context()
+            self._post_theta, self.alpha_, self._L, self._K_inv = saved
+        return self._ctx_obj
+
+    @_ctx.setter
+    def _ctx(self, value):
+        self._ctx_obj = value
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_ctx_obj"] = None
+        state["_sampler"] = None  # holds the bound (possibly rank-sharded) log-probability
+        state["_needs_rebuild"] = getattr(self, "_X_train_", None) is not None and self.kernel_ is not None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
     def _ensure_context(self, batch_hint=None):
         """(Re)create / update the device context for the current training set."""
         X, y = self._X_train_, self.y_train_
@@ -100,7 +126,7 @@ class BayesGPR:
                              f"({alpha_diag.shape[0]} != {n})")
         plan = analyse_kernel(self.kernel_)
         want_batch = int(self.max_batch or batch_hint or 64)
-        ctx = self._ctx
+        ctx = self._ctx_obj
         if (ctx is None or ctx.d != X.shape[1] or ctx.form != plan.form or ctx.stationary != plan.stationary
                 or ctx.max_batch < want_batch):
             if ctx is not None:
@@ -720,7 +746,7 @@ class BayesGPR:
         return (self.y_train_std_ * out + self.y_train_mean_).T
 
     def __del__(self):
-        ctx = getattr(self, "_ctx", None)
+        ctx = self.__dict__.get("_ctx_obj")
         if ctx is not None:
             try:
                 ctx.close()

@@ -308,3 +308,25 @@ def test_searchcv_initial_design_only_runs_on_cpu():
     assert len(two.cv_results_["params"]) == 5 and len(two.optimizer_results_) == 2
     with pytest.raises(ValueError):
         bask.BayesSearchCV(SVC(), [({"C": Real(1e-3, 1e3)}, 0)]).fit(Xtr, ytr)
+
+
+def test_bayesgpr_is_an_sklearn_estimator_without_a_device():
+    """get_params / set_params / clone / pickle of an UNFITTED BayesGPR need no device (the reference's class is
+    an sklearn estimator through skopt's GaussianProcessRegressor)."""
+    import copy
+    import pickle
+
+    from sklearn.base import clone
+
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd.kernels import ConstantKernel, Matern
+
+    gp = bask.BayesGPR(kernel=ConstantKernel(1.0) * Matern(0.3, nu=2.5), normalize_y=True, random_state=1, warp_inputs=True)
+    params = gp.get_params(deep=False)
+    assert params["normalize_y"] is True and params["warp_inputs"] is True and params["noise"] == "gaussian"
+    g2 = clone(gp)
+    assert g2 is not gp and g2.normalize_y is True and g2.chain_ is None
+    g2.set_params(normalize_y=False, kernel__k2__length_scale=0.5)
+    assert g2.normalize_y is False and g2.kernel.k2.length_scale == 0.5 and gp.kernel.k2.length_scale == 0.3
+    for other in (pickle.loads(pickle.dumps(gp)), copy.deepcopy(gp)):
+        assert other.get_params(deep=False).keys() == params.keys() and other._ctx is None

@@ -206,3 +206,39 @@ def test_predict_gradients_match_finite_differences(bask, kind):
         gp.predict(np.vstack([x0, x0]), return_mean_grad=True)
     with pytest.raises(ValueError):
         gp.predict(x0, return_std_grad=True)
+
+
+def test_sklearn_estimator_protocol_pickle_and_score(bask):
+    """The reference's BayesGPR is a scikit-learn estimator (it subclasses skopt's / sklearn's
+    GaussianProcessRegressor): get_params / set_params / clone / score work, and a fitted model survives pickle
+    and deepcopy -- the ctypes device context does not travel and is rebuilt from the stored training data."""
+    import copy
+    import pickle
+
+    from sklearn.base import clone
+
+    from bayes_skopt_amd.kernels import ConstantKernel, Matern
+
+    rng = np.random.RandomState(0)
+    X = rng.uniform(size=(70, 2))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.05 * rng.randn(70)
+    gp = bask.BayesGPR(kernel=ConstantKernel(1.0, (0.1, 2.0)) * Matern([0.4, 0.4], (0.2, 0.8), nu=2.5), normalize_y=True,
+                       random_state=2)
+    assert {"kernel", "alpha", "normalize_y", "warp_inputs", "noise", "random_state"} <= set(gp.get_params(deep=False))
+    fresh = clone(gp)
+    assert fresh.chain_ is None and fresh.normalize_y is True
+    gp.fit(X, y, n_desired_samples=40, n_burnin=5, n_walkers_per_thread=20, progress=False)
+    Xq = rng.uniform(size=(25, 2))
+    mu, std = gp.predict(Xq, return_std=True)
+    r2 = gp.score(X, y)
+    assert 0.9 < r2 <= 1.0
+    for other in (pickle.loads(pickle.dumps(gp)), copy.deepcopy(gp)):
+        assert other._ctx_obj is None          # nothing device-side travelled
+        np.testing.assert_array_equal(other.chain_, gp.chain_)
+        mu2, std2 = other.predict(Xq, return_std=True)   # rebuilds the context and the posterior on demand
+        np.testing.assert_array_equal(mu2, mu)
+        np.testing.assert_array_equal(std2, std)
+        np.testing.assert_allclose(other.K_inv_, gp.K_inv_, rtol=0, atol=0)
+        assert other.score(X, y) == r2
+        other.sample(n_desired_samples=40, n_burnin=2, n_walkers_per_thread=20)  # MCMC resumes from pos_
+        assert other.chain_.shape == gp.chain_.shape
