@@ -255,3 +255,22 @@ def test_optimum_intervals(bask):
     opt_cat = bask.Optimizer(dimensions=[(0.0, 1.0), ["a", "b"]], n_initial_points=2)
     with pytest.raises(NotImplementedError):
         opt_cat.optimum_intervals()
+
+
+def test_optimizer_survives_pickle(bask):
+    """A tuning run checkpointed with pickle continues where it stopped (the GP's device context is rebuilt)."""
+    import pickle
+
+    rng = np.random.RandomState(0)
+    opt = bask.Optimizer(dimensions=[(0.0, 1.0), (0.0, 1.0)], n_initial_points=4, random_state=0, n_points=200)
+    for _ in range(6):
+        x = opt.ask()
+        opt.tell(x, float(np.sin(5 * x[0]) + x[1] ** 2 + 0.01 * rng.randn()), gp_samples=40, gp_burnin=3)
+    clone = pickle.loads(pickle.dumps(opt))
+    assert clone.Xi == opt.Xi and clone.yi == opt.yi
+    np.testing.assert_array_equal(clone.gp.chain_, opt.gp.chain_)
+    x = clone.ask()
+    res = clone.tell(x, 0.3, gp_samples=40, gp_burnin=3)
+    assert len(res.x_iters) == 7 and clone.gp.X_train_.shape[0] == 7
+    Xq = rng.uniform(size=(5, 2))
+    assert np.all(np.isfinite(clone.gp.predict(Xq)))
