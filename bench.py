@@ -265,6 +265,15 @@ def main():
         "gathered_chain_rows": int(chain_all.shape[0]),
         "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
     }
+    if rank == 0 and ws == 1:
+        # the other half of BASELINE.json's metric: wall clock of a whole BayesGPR.fit() (MAP start by L-BFGS-B on
+        # the device LML + gradient, then 256 walkers x 25 steps after 5 burn-in steps) at the same size
+        gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device)
+        tf0 = time.perf_counter()
+        gp2.fit(X, y, n_desired_samples=W * 25, n_burnin=5, n_walkers_per_thread=W, progress=False)
+        line["fit_plus_sample_ms"] = (time.perf_counter() - tf0) * 1e3
+        line["fit_plus_sample_evals"] = int(gp2._sampler.n_log_prob_evals)
+        del gp2
     if rank == 0:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
