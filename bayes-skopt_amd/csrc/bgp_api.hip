@@ -161,8 +161,8 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->nstreams = ns;
     const char* envl = getenv("BGP_LEFT_LOOKING");
     c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
-    const char* envs = getenv("BGP_SYRK3");
-    c->use_syrk3 = (envs && atoi(envs) != 0) ? 1 : 0;
+    const char* envs = getenv("BGP_SYRK2");
+    c->use_syrk2 = (envs && atoi(envs) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");
     c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
     c->panels = c->two_panel ? 2 : 1;

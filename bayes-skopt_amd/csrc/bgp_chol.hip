@@ -695,7 +695,8 @@ extern "C" void bgp_debug_launch_syrk2(hipStream_t st, int B8, int ntile, double
 }
 #endif
 
-void bgp_launch_syrk3(hipStream_t st, int grid, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+// LDS-DMA pipelined trailing update (bgp_syrk4.hip): the default of the LML path; BGP_SYRK2=1 selects syrk2_kernel
+void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
                       int K, int jstart, int colmode, int B);
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k);
@@ -744,21 +745,20 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 3, st);
-          if (ctx->use_syrk3)
-            bgp_launch_syrk3(st, B8 * (nblk - (k + j + 1)), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1,
-                             B);
-          else
+          if (ctx->use_syrk2)
             launch_syrk2(st, B8, nblk - (k + j + 1), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
+          else
+            bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
           bgp_tend(ctx, st);
         }
       }
       const int nt = nblk - (k + np);
       if (nt > 0) {
         bgp_tbegin(ctx, 3, st);
-        if (ctx->use_syrk3)
-          bgp_launch_syrk3(st, B8 * (nt * (nt + 1) / 2), dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
-        else
+        if (ctx->use_syrk2)
           launch_syrk2(st, B8, nt * (nt + 1) / 2, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
+        else
+          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         bgp_tend(ctx, st);
       }
       k += np;

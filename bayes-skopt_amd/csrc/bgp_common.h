@@ -39,7 +39,7 @@ struct bgp_ctx {
   hipStream_t stream = nullptr;
   // walker groups: the batch of an LML call is split over nstreams HIP streams so that the
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
-  int use_syrk3 = 0;     // trailing update with global_load_lds staging + 4x4x4 MFMA (env BGP_SYRK3=1)
+  int use_syrk2 = 0;     // trailing update with the VGPR-staged syrk2_kernel instead of syrk4_kernel (env BGP_SYRK2=1)
   int two_panel = 1;     // (legacy switch) env BGP_TWO_PANEL=0 == BGP_PANELS=1
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
   int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)

@@ -1,0 +1,275 @@
+// Trailing update of the LML path, software-pipelined:  A_IJ -= X_I X_J^T  over a panel of width K
+// (the n^3/3 bulk of cholesky(K, lower=True), sklearn/_gpr.py:587).
+//
+// Same arithmetic and the same per-element summation order as syrk2_kernel (bgp_chol.hip) -- results are
+// bit-identical to it -- but the operands reach the MFMAs differently.  syrk2 stages a 128x32 chunk through
+// VGPRs between two barriers and waits for the global loads in the open (A, then B: two exposed L2 round
+// trips per chunk).  Here:
+//   * `global_load_lds_dwordx4` (LDS-DMA) writes 16-wide k-chunks straight into a two-stage LDS ring; the
+//     loads of chunk c+1 are in flight while chunk c is multiplied, ONE barrier per chunk, no staging VGPRs,
+//     no ds_write instructions, scalar-only address arithmetic in the loop;
+//   * the LDS image is the DMA's lane-linear one (row-major [T][16] doubles, one wave instruction = 8 rows
+//     x 128 B); bank conflicts are removed by an XOR swizzle of the 16-byte granules applied to the per-lane
+//     SOURCE address and again on every fragment read (cdna_hip_programming.md 5.4 rule 21):
+//         element (row, k) lives at byte  row*128 + (((k>>1) ^ ((row>>1)&7)) << 4) + ((k&1) << 3);
+//   * the subtraction rides on the MFMA's A-negate modifier (blgp = 1 on the f64 forms): no VALU in the loop;
+//   * fragments of k-step kk+1 are read while k-step kk multiplies;
+//   * tile edge T = 64 (each wave a 32x32 block, 66 VGPRs, 32 KB of LDS: five workgroups = 20 waves per CU)
+//     is what the library launches: measured on MI355X it ties the 128x128 tile (two workgroups per CU) on the
+//     largest launch of BASELINE config C (62.6 vs 63.0 TF) although it moves twice the bytes per flop from
+//     L2 and LDS, and wins everywhere else (B=16: 62.5 vs 55.4 TF; 320 tiles: 43 vs 28 TF) because small
+//     launches fill the chip 4x better and the deeper occupancy hides the per-tile C round trip.  T = 128 is
+//     kept as a template instantiation for tools/syrk4_bench.hip.  A persistent variant (workgroups walking
+//     the tile list, next tile's first chunk in flight during the epilogue) was measured 8-12 % SLOWER: the
+//     resident workgroups start in lockstep and stay there, so their C-tile traffic comes in bursts.
+// Results do not depend on T or the launch geometry: every C element is owned by one lane and accumulated in
+// the same k order (k ascending in steps of 4) -- bitwise reproducible and batch-split invariant.
+#include "bgp_common.h"
+#include "bgp_device.h"
+#include "bgp_gemm.h"
+
+#define S4_KC 16
+#define S4_ROWB (S4_KC * 8)  // bytes per LDS row
+
+// One LDS-DMA instruction: 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to LDS
+// [lds_addr, lds_addr + 1 KB).  hipcc neither counts it in its vmcnt bookkeeping nor waits for it: the kernel
+// places its own waits.  (M0 is compiler-reserved: saved and restored inside the statement,
+// cdna_hip_programming.md 5.7.)
+static __device__ __forceinline__ void s4_glds(const double* gbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(gbase), "s"(lds_addr)
+      : "memory");
+}
+#define S4_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// Wave w stages rows [w T/4, (w+1) T/4) of one T x 16 operand chunk: T/32 instructions x 8 rows.  voff[i] is this
+// lane's (swizzled) byte offset for instruction i, the same for every operand panel and chunk: the panel origin
+// and the chunk's k0 go into the wave-uniform base (scalar adds only).
+template <int T>
+static __device__ __forceinline__ void s4_issue(const double* X, const unsigned (&voff)[T / 32], int k0,
+                                                unsigned lds_op_base, int w) {
+#pragma unroll
+  for (int i = 0; i < T / 32; i++)
+    s4_glds(X + k0, voff[i], lds_op_base + (unsigned)(((T / 4) * w + 8 * i) * S4_ROWB));
+}
+
+template <int T>
+static __device__ __forceinline__ void s4_src(unsigned (&voff)[T / 32], int ld, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < T / 32; i++) {
+    const int row = (T / 4) * w + 8 * i + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    voff[i] = (unsigned)(row * ld + g * 2) * 8u;
+  }
+}
+
+// Per-lane LDS byte addresses of the fragment rows: (row row0 + (lane & 15), k-step kk), swizzle applied.
+static __device__ __forceinline__ void s4_frag_addr(unsigned (&p)[4], unsigned base, int row0, int lane) {
+  const int lr = lane & 15, lk = lane >> 4, f = (lr >> 1) & 7;  // (row0 is a multiple of 16: f depends on lr only)
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++)
+    p[kk] = base + (unsigned)((row0 + lr) * S4_ROWB + ((((kk * 2) + (lk >> 1)) ^ f) << 4) + ((lk & 1) << 3));
+}
+
+// acc[i][j] -= A_i B_j^T over one 16-wide chunk.  pa / pb: see s4_frag_addr; `soff` = compile-time stage offset.
+// (hipcc pairs the fragment reads into ds_read2st64_b64; hand-placed single ds_read_b64 with counted lgkmcnt
+// waits -- conflict-free and twice the LDS rate on paper -- measured no faster: the LDS is not the limiter.)
+// VAR (bench builds only, tools/syrk4_bench.hip): bit 0 = no LDS-DMA issue, bit 1 = no MFMAs, bit 2 = timestamps.
+template <int NR, int NC, int CREL, int VAR>
+static __device__ __forceinline__ void s4_mma(const unsigned (&pa)[4], const unsigned (&pb)[4], int soff,
+                                              d4 (&acc)[NR][NC]) {
+  typedef __attribute__((address_space(3))) const double* lds_cdp;
+  double a[2][NR], b[2][NC];
+#pragma unroll
+  for (int i = 0; i < NR; i++) a[0][i] = *(lds_cdp)(uintptr_t)(pa[0] + soff + i * 16 * S4_ROWB);
+#pragma unroll
+  for (int j = 0; j < NC; j++) b[0][j] = *(lds_cdp)(uintptr_t)(pb[0] + soff + j * 16 * S4_ROWB);
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    const int cur = kk & 1, nxt = cur ^ 1;
+    if (kk < 3) {
+#pragma unroll
+      for (int i = 0; i < NR; i++) a[nxt][i] = *(lds_cdp)(uintptr_t)(pa[kk + 1] + soff + i * 16 * S4_ROWB);
+#pragma unroll
+      for (int j = 0; j < NC; j++) b[nxt][j] = *(lds_cdp)(uintptr_t)(pb[kk + 1] + soff + j * 16 * S4_ROWB);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        if (j + CREL > i) continue;  // compile-time (lower part of a diagonal block)
+        if (VAR & 2)
+          asm volatile("" ::"v"(a[cur][i]), "v"(b[cur][j]));
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc[i][j], 0, 0, 1);  // neg A
+      }
+  }
+}
+
+struct S4Tile {
+  const double* XA;  // rows of block I, panel columns
+  const double* XB;  // rows of block J
+  double* C;
+  int q;      // position in the launch's tile list (>= total: none)
+  int diag;   // I == J: X_I is both operands; only the lower triangle is updated
+  int label;  // I * 1000 + J (bench timeline)
+};
+
+#define S4_STAMP(i)                                                      \
+  do {                                                                   \
+    if ((VAR & 4) && trace) {                                            \
+      __builtin_amdgcn_sched_barrier(0);                                 \
+      const unsigned long long t__ = __builtin_readcyclecounter();       \
+      if (threadIdx.x == 0) trace[(size_t)cur.q * 8 + (i)] = t__;        \
+      __builtin_amdgcn_sched_barrier(0);                                 \
+    }                                                                    \
+  } while (0)
+
+// One tile for a wave's NR x NC block at (r0, c0) of the T x T workgroup tile.
+template <int T, int NR, int NC, int CREL, int VAR>
+static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsigned lds0, const S4Tile& cur,
+                                               const unsigned (&voff)[T / 32], int ld, int K, int r0, int c0, int w,
+                                               int lane) {
+  constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
+  unsigned pa[4], pb[4];
+  s4_frag_addr(pa, lds0, r0, lane);
+  s4_frag_addr(pb, cur.diag ? lds0 : lds0 + OPB, c0, lane);
+  const int nch = K / S4_KC;
+  d4 acc[NR][NC];
+  if (!(VAR & 1)) {  // chunk 0 -> stage 0
+    s4_issue<T>(cur.XA, voff, 0, lds0, w);
+    if (!cur.diag) s4_issue<T>(cur.XB, voff, 0, lds0 + OPB, w);
+  }
+  // The empty asm makes hipcc wait for its C loads HERE (its in-order vmcnt wait also covers chunk 0, needed
+  // next anyway) instead of at their first use inside the loop, where such a wait would drain the LDS-DMA queue.
+  gk_load_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++)
+      if (j + CREL <= i) asm volatile("" : "+v"(acc[i][j]));
+  S4_STAMP(1);
+  for (int c = 0; c < nch; c += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      S4_WAIT_VM0();                 // this wave's share of chunk c+s has landed
+      __builtin_amdgcn_s_barrier();  // ... everybody's has; everybody finished reading chunk c+s-1
+      if (!(VAR & 1) && c + s + 1 < nch) {
+        const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
+        s4_issue<T>(cur.XA, voff, (c + s + 1) * S4_KC, nb, w);
+        if (!cur.diag) s4_issue<T>(cur.XB, voff, (c + s + 1) * S4_KC, nb + OPB, w);
+      }
+      s4_mma<NR, NC, CREL, VAR>(pa, pb, s * STAGEB, acc);
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs of this chunk above the next wait + barrier
+    }
+  }
+  S4_STAMP(2);
+  gk_store_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
+}
+
+// Tile list of one launch, in blocks of T rows:  nt128 = trailing 128-row blocks, colmode 0: every tile with
+// I >= J, colmode 1: only the tiles inside the first 128 columns (the look-ahead block column).
+template <int T>
+static __host__ __device__ __forceinline__ int s4_ntile(int nt128, int colmode) {
+  const int nt = nt128 * (128 / T);
+  if (!colmode) return nt * (nt + 1) / 2;
+  return (T == 128) ? nt : 2 * nt - 1;
+}
+
+template <int T>
+static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, double* Kbuf, const int* status, int ld,
+                                                   size_t mstride, int kp, int jstart, int colmode, int nt128, int B) {
+  S4Tile d;
+  d.XA = d.XB = nullptr;
+  d.C = nullptr;
+  d.diag = 0;
+  d.label = 0;
+  d.q = total;
+  do {
+    int b, t;
+    bgp_map_block(q, ntile, B, b, t);
+    if (b >= B || status[b] != 0) break;  // padding slot / failed factorisation: nothing to update
+    int ti, tj;
+    if (!colmode) {
+      bgp_tri_decode(t, ti, tj);
+    } else if (T == 128 || t < nt128 * 2) {
+      ti = t;
+      tj = 0;
+    } else {
+      ti = t - nt128 * 2 + 1;
+      tj = 1;
+    }
+    double* M = Kbuf + (size_t)b * mstride;
+    const size_t rowI = (size_t)jstart * 128 + (size_t)ti * T, rowJ = (size_t)jstart * 128 + (size_t)tj * T;
+    d.XA = M + rowI * ld + kp * 128;
+    d.XB = M + rowJ * ld + kp * 128;
+    d.C = M + rowI * ld + rowJ;
+    d.diag = (ti == tj);
+    d.label = ti * 1000 + tj;
+    d.q = q;
+  } while (0);
+  return d;
+}
+
+template <int T, int VAR>
+__global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
+    syrk4_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp,
+                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace) {
+  constexpr unsigned STAGEB = 2 * T * S4_ROWB;
+  constexpr int NRF = T / 32;  // MFMA tiles per wave and direction (each wave a T/2 x T/2 block)
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int nt128 = nblk - jstart;
+  const S4Tile cur = s4_decode<T>(blockIdx.x, total, s4_ntile<T>(nt128, colmode), Kbuf, status, ld, mstride, kp, jstart,
+                                  colmode, nt128, B);
+  if (cur.q >= total) return;
+  unsigned voff[T / 32];
+  s4_src<T>(voff, ld, w, lane);
+  if ((VAR & 4) && trace && threadIdx.x == 0) {
+    trace[(size_t)cur.q * 8 + 4] = wall_clock64();                               // 100 MHz constant clock
+    trace[(size_t)cur.q * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    trace[(size_t)cur.q * 8 + 6] = (unsigned long long)cur.label;
+  }
+  S4_STAMP(0);
+  if (!cur.diag) {
+    s4_tile<T, NRF, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane);
+  } else if (w < 2) {
+    // Diagonal tile: only its lower triangle is ever read again.  Waves 0 / 1: the two (T/2)^2 triangles on the
+    // diagonal; waves 2 / 3: the square below the diagonal cut into two row halves (3/3/2/2 MFMA tiles at T = 64).
+    s4_tile<T, NRF, NRF, 0, VAR>(trace, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane);
+  } else {
+    s4_tile<T, NRF / 2, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane);
+  }
+  S4_STAMP(3);
+  if ((VAR & 4) && trace && threadIdx.x == 0) trace[(size_t)cur.q * 8 + 7] = wall_clock64();
+}
+
+void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+                      int K, int jstart, int colmode, int B) {
+  const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
+  hipLaunchKernelGGL((syrk4_kernel<64, 0>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
+                     colmode, B, total, nullptr);
+}
+
+#ifdef S4_BENCH  // ablation / trace instantiations for tools/syrk4_bench.hip (not in the product library)
+extern "C" int bgp_debug_launch_syrk4(int T, int var, hipStream_t st, int B8, double* dK, const int* dstatus, int ld,
+                                      size_t mstride, int nblk, int kp, int K, int jstart, int colmode, int B,
+                                      unsigned long long* trace) {
+  const int nt = nblk - jstart;
+  const int total = B8 * (T == 128 ? s4_ntile<128>(nt, colmode) : s4_ntile<64>(nt, colmode));
+#define S4_CASE(TT, V)                                                                                               \
+  if (T == TT && var == V) {                                                                                         \
+    hipLaunchKernelGGL((syrk4_kernel<TT, V>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,    \
+                       jstart, colmode, B, total, trace);                                                            \
+    return total;                                                                                                    \
+  }
+  S4_CASE(128, 0) S4_CASE(128, 4) S4_CASE(64, 0) S4_CASE(64, 1) S4_CASE(64, 2) S4_CASE(64, 3) S4_CASE(64, 4)
+  fprintf(stderr, "bgp_debug_launch_syrk4: no instantiation T=%d var=%d\n", T, var);
+  return 0;
+}
+#endif

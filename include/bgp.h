@@ -170,7 +170,7 @@ int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const doubl
  * chain is as long as the whole batch's, nothing to gain).  This call, or the environment variable
  * BGP_STREAMS read at context creation, forces a fixed group count.  Other environment switches read at
  * context creation: BGP_PANELS (block columns per trailing update, default 2), and the experimental
- * BGP_TWO_PANEL=0, BGP_SYRK3=1, BGP_LEFT_LOOKING=1. */
+ * BGP_TWO_PANEL=0, BGP_SYRK2=1, BGP_LEFT_LOOKING=1. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */

@@ -143,7 +143,7 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
-                {"BGP_PANELS": "4"}, {"BGP_SYRK3": "1"}):
+                {"BGP_PANELS": "4"}, {"BGP_SYRK2": "1"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
