@@ -55,6 +55,7 @@ SIGNATURES = {
     "bgp_pvrs": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]),
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
+    "bgp_sample_y_batch": (C.c_int, [_vp, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_double, _dp, _ip]),
     "bgp_device_synchronize": (C.c_int, [C.c_int]),
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
@@ -267,6 +268,21 @@ class Context:
             raise NotPositiveDefinite(self._lib.bgp_last_error().decode())
         _check(rc, "bgp_sample_y")
         return out
+
+    def sample_y_batch(self, pidx, H_kernel, Xq, z, jitter=0.0):
+        """One draw per resident posterior pidx[i]: returns (out (B, m), status (B,))."""
+        H = self._H(H_kernel)
+        Xq = _c(np.atleast_2d(Xq))
+        z = _c(np.atleast_2d(z))
+        pidx = np.ascontiguousarray(pidx, dtype=np.int32)
+        B, m = H.shape[0], Xq.shape[0]
+        if z.shape != (B, m) or pidx.shape != (B,):
+            raise ValueError("z must be (B, m) and pidx (B,)")
+        out = np.empty_like(z)
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_sample_y_batch(self._h, B, _p(pidx), _p(H), m, _p(Xq), _p(z), float(jitter), _p(out),
+                                            _p(st)), "bgp_sample_y_batch")
+        return out, st
 
     def set_streams(self, nstreams):
         _check(self._lib.bgp_set_streams(self._h, int(nstreams)), "bgp_set_streams")

@@ -90,26 +90,27 @@ def evaluate_acquisitions(X, gpr, acquisition_functions=None, n_samples=10, prog
 
     has_unc = any(isinstance(a, UncertaintyAcquisition) for a in acqs)
     has_smp = any(isinstance(a, SampleAcquisition) for a in acqs)
+    rows = gpr.chain_[trace_i]
     if len(trace_i) > 0 and has_unc:
         # ONE batched posterior build + ONE batched predict for all hyper-posterior draws
-        mus, stds = gpr._predict_hyper_samples(gpr.chain_[trace_i], X, noise_zero=True)
-    for pos, i in enumerate(trace_i):
-        if has_smp:
-            gpr.theta = gpr.chain_[i]
-        sample = None
+        mus, stds = gpr._predict_hyper_samples(rows, X, noise_zero=True)
+    samples = None
+    if len(trace_i) > 0 and has_smp:
+        # one function realisation per draw, each from a chain row chosen by sample_y itself (bask/acquisition.py:132-136
+        # -> bask/bayesgpr.py:679), with that row's kernel parameters and -- with input warping -- its own warp
+        samples = gpr._sample_hyper_rows(len(trace_i), X, random_state)
+    for pos in range(len(trace_i)):
         for j, acq in enumerate(acqs):
             if isinstance(acq, UncertaintyAcquisition):
                 tmp = acq(mus[pos], stds[pos], **kwargs)
             elif isinstance(acq, SampleAcquisition):
-                if sample is None:
-                    with gpr.noise_set_to_zero():
-                        sample = gpr.sample_y(X, random_state=random_state).flatten()
-                tmp = acq(sample, **kwargs)
+                tmp = acq(samples[pos], **kwargs)
             else:
                 continue
             if np.all(np.isfinite(tmp)):
                 out[j] += tmp / n_samples
-    gpr.theta = theta_backup
+    if not np.array_equal(gpr.theta, theta_backup):
+        gpr.theta = theta_backup
     return out
 
 

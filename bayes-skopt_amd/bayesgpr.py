@@ -703,30 +703,75 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             cm = nullcontext(self) if noise else self.noise_set_to_zero()
             with cm:
                 return self._draw(X, n_samples, rng)
+        # hyper-posterior draws: one chain row (with replacement) and one function per sample.  The generator is
+        # consumed in the reference's order -- all row indices first, then one normal vector per sample -- and the
+        # device builds all posteriors and factorises all predictive covariances in batched calls.
         ind = rng.choice(len(self.chain_), size=n_samples, replace=True)
-        current_theta = self.theta
-        saved = (self._post_theta, self.alpha_, self._L, self._K_inv)
-        result = np.empty((X.shape[0], n_samples))
-        n_theta = len(current_theta)
+        Z = np.vstack([rng.standard_normal((1, X.shape[0])) for _ in range(n_samples)])
+        return self._draw_rows(self.chain_[ind], X, Z, noise).T
+
+    def _sample_hyper_rows(self, n_draws, X, rng):
+        """The sample acquisitions of ``evaluate_acquisitions``: per draw the reference calls
+        ``gpr.sample_y(X, random_state=rng)`` (``bask/acquisition.py:132-136``), i.e. ONE function of ONE freshly
+        chosen chain row with the noise off -- same generator consumption here (row index, then the normal vector,
+        per draw), one batched device call for all draws.  Returns (n_draws, m)."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        rows, Z = [], []
+        for _ in range(n_draws):
+            rows.append(self.chain_[rng.choice(len(self.chain_), size=1, replace=True)[0]])
+            Z.append(rng.standard_normal((1, X.shape[0])))
+        return self._draw_rows(np.array(rows), X, np.vstack(Z), noise=False)
+
+    def _draw_rows(self, rows, X, Z, noise):
+        """f_i = mean_i + chol(cov_i) Z[i] for the GP of chain row i (kernel parameters and, with input warping, its
+        own warp); (len(rows), m) in the units of y.  The resident posterior of ``theta`` is rebuilt lazily by the
+        next call that needs it (``_make_resident``), so ``theta`` / ``alpha_`` / ``L_`` / ``K_inv_`` are untouched."""
+        rows = np.atleast_2d(rows)
+        n_theta = len(self.kernel_.theta)
         if self.warp_inputs:
             validate_zeroone(X)
-            warp_backup = (np.copy(self.warp_alphas_), np.copy(self.warp_betas_))
             d = self._X_train_.shape[1]
-        for i, j in enumerate(ind):
-            row = self.chain_[j]
-            if self.warp_inputs:
-                self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
+            backup = (np.copy(self.warp_alphas_), np.copy(self.warp_betas_))
+            out = np.empty((len(rows), X.shape[0]))
+            try:
+                for i, row in enumerate(rows):  # every draw has its own warped training inputs
+                    self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
+                    self.rewarp()
+                    out[i] = self._draw_rows_device(row[None, :n_theta], X, Z[i : i + 1], noise)[0]
+            finally:
+                self.create_warpers(*backup)
                 self.rewarp()
-            self.theta = row[:n_theta]
-            cm = nullcontext(self) if noise else self.noise_set_to_zero()
-            with cm:
-                result[:, i] = self._draw(X, 1, rng).flatten()
-        self.kernel_.theta = current_theta
-        if self.warp_inputs:  # the reference restores only the parameter arrays (bask/bayesgpr.py:714-716);
-            self.create_warpers(*warp_backup)  # here the warp itself is restored as well
-            self.rewarp()
-        self._post_theta, self.alpha_, self._L, self._K_inv = saved
-        return result
+            return out
+        return self._draw_rows_device(rows[:, :n_theta], X, Z, noise)
+
+    def _draw_rows_device(self, thetas, X, Z, noise):
+        H = self._canonical(thetas)
+        uniq, inverse = np.unique(H, axis=0, return_inverse=True)  # repeated chain rows share one posterior build
+        res = self._ctx.posterior(uniq, want_alpha=False)
+        if np.any(res["status"] != 0):
+            bad = int(np.flatnonzero(res["status"])[0])
+            raise np.linalg.LinAlgError(
+                _PD_MESSAGE % self.kernel_,
+                "%d-th leading minor of the array is not positive definite" % res["status"][bad],
+            )
+        Hk = H.copy()
+        if not noise:
+            Hk[:, -1] = -np.inf  # noise_set_to_zero(): the factors keep the noise, the predictive kernel drops it
+        pidx = np.asarray(inverse, dtype=np.int32).ravel()
+        out = np.empty_like(Z)
+        todo = np.arange(len(H))
+        jitter = 1e-10
+        while len(todo):
+            o, st = self._ctx.sample_y_batch(pidx[todo], Hk[todo], X, Z[todo], jitter=jitter)
+            ok = st == 0
+            out[todo[ok]] = o[ok]
+            todo = todo[~ok]
+            # numpy's SVD-based draw tolerates a numerically semi-definite covariance; the Cholesky-based draw
+            # needs a growing diagonal jitter instead
+            jitter *= 100.0
+            if len(todo) and jitter > 1e-2:
+                raise _lib.NotPositiveDefinite("predictive covariance not positive definite (jitter %.3g)" % jitter)
+        return self.y_train_std_ * out + self.y_train_mean_
 
     def _draw(self, X, n_samples, rng):
         self._make_resident()

@@ -75,6 +75,7 @@ struct bgp_ctx {
   double* dKinv = nullptr;
   double* dalpha_sol = nullptr;
   size_t cap_kinv = 0;
+  size_t cap_alpha = 0;
   // resident posterior state
   int post_B = 0;            // number of resident posteriors (0 = none)
   std::vector<double> post_h;
@@ -143,6 +144,9 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
 // Cross kernel matrix k(Xq, X_train) for hyper-vector index b: out is m x ldo row-major (device).
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int symmetric_diag_fix);
+// the same for nb hyper-vectors dH (nb x (d+2)) into dout + b * ostride
+int bgp_launch_kcross_batch(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
+                            double* dout, int ldo, size_t ostride);
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
 // Beta-CDF warp of n x d inputs for B parameter sets (bgp_warp.hip)
 int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* dW, double* dout, int n, int B,

@@ -131,13 +131,15 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
                              npad);
 }
 
+// blockIdx.y = item of a batch: hyper-parameters h + b (d+2), output out + b ostride (the inputs are shared)
 template <int STAT, int FORM>
 __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restrict__ Xq, int m,
                                                             const double* __restrict__ Xt, int n, int d,
                                                             const double* __restrict__ h, double* __restrict__ out,
-                                                            int ldo, int tiles_j) {
-  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
-  kbuild_tile<0, STAT, FORM>(Xq, m, Xt, n, d, h, nullptr, ti * 128, tj * 128, out, (size_t)ldo, m, n);
+                                                            int ldo, int tiles_j, size_t ostride) {
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j, b = blockIdx.y;
+  kbuild_tile<0, STAT, FORM>(Xq, m, Xt, n, d, h + (size_t)b * (d + 2), nullptr, ti * 128, tj * 128,
+                             out + (size_t)b * ostride, (size_t)ldo, m, n);
 }
 
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
@@ -168,10 +170,15 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
 
 int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq, int nx, const double* dXt,
                       double* dout, int ldo, int /*unused*/) {
+  return bgp_launch_kcross_batch(ctx, 1, dh_b, m, dXq, nx, dXt, dout, ldo, 0);
+}
+
+int bgp_launch_kcross_batch(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
+                            double* dout, int ldo, size_t ostride) {
   const int tiles_i = (m + 127) / 128, tiles_j = (nx + 127) / 128;
   KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-              hipLaunchKernelGGL((kbuild_cross_kernel<S, F>), dim3(tiles_i * tiles_j), dim3(256), 0, ctx->stream, dXq, m,
-                                 dXt, nx, ctx->d, dh_b, dout, ldo, tiles_j));
+              hipLaunchKernelGGL((kbuild_cross_kernel<S, F>), dim3(tiles_i * tiles_j, nb), dim3(256), 0, ctx->stream, dXq,
+                                 m, dXt, nx, ctx->d, dH, dout, ldo, tiles_j, ostride));
   BGP_HIP(hipGetLastError());
   return BGP_OK;
 }

@@ -60,25 +60,38 @@ __global__ void extract_L_kernel(const double* __restrict__ Kbuf, double* __rest
   }
 }
 
+// Batched launches below run item b = blockIdx.y of a chunk; operands that live in the resident posterior arrays
+// (K^-1, alpha) are addressed through `pidx[b]` (NULL: item b is posterior b0 + b ... callers pass explicit maps).
 // mean_i = sum_j Ks[i][j] alpha[j]   (one wave per row)
-__global__ void __launch_bounds__(256) matvec_rows_kernel(const double* __restrict__ Ks, int lds,
-                                                           const double* __restrict__ v, int n, int m,
-                                                           double* __restrict__ out) {
+__global__ void __launch_bounds__(256) matvec_rows_kernel(const double* __restrict__ Ks, int lds, size_t sK,
+                                                           const double* __restrict__ v, size_t sv,
+                                                           const int* __restrict__ pidx, int n, int m,
+                                                           double* __restrict__ out, size_t so) {
+  const int b = blockIdx.y;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= m) return;
+  const double* K = Ks + (size_t)b * sK;
+  const double* vb = v + (size_t)(pidx ? pidx[b] : b) * sv;
   double s = 0.0;
-  for (int j = lane; j < n; j += 64) s += Ks[(size_t)row * lds + j] * v[j];
+  for (int j = lane; j < n; j += 64) s += K[(size_t)row * lds + j] * vb[j];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) out[row] = s;
+  if (lane == 0) out[(size_t)b * so + row] = s;
 }
 
-// var_i = max(0, diag - q_i)
-__global__ void finish_var_kernel(const double* __restrict__ q, double diag, int m, double* __restrict__ var) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// kernel_.diag(X) incl. the white level (sklearn/kernels.py:868-884, 968-984) from a canonical vector on the device
+static __device__ __forceinline__ double dev_kernel_diag(const double* hk, int d, int form) {
+  const double cst = exp(hk[0]), s2 = exp(hk[d + 1]);
+  return ((form == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0) + s2;
+}
+
+// var_i = max(0, diag_b - q_i)
+__global__ void finish_var_kernel(const double* __restrict__ q, size_t sq, const double* __restrict__ H, int d, int form,
+                                  int m, double* __restrict__ var, size_t so) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (i >= m) return;
-  double v = diag - q[i];
-  var[i] = v < 0.0 ? 0.0 : v;
+  const double v = dev_kernel_diag(H + (size_t)b * (d + 2), d, form) - q[(size_t)b * sq + i];
+  var[(size_t)b * so + i] = v < 0.0 ? 0.0 : v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -89,13 +102,27 @@ __global__ void finish_var_kernel(const double* __restrict__ q, double diag, int
 //          variance; the launcher then sums the column tiles in a fixed order (no fp atomics to global)
 //   EPI 2: C = E - acc                                    -- predictive covariance
 // ------------------------------------------------------------------------------------------
+struct GemmBatch {  // per-item strides (doubles) of a batched launch; pidxB maps item -> B-operand slot
+  size_t sA = 0, sB = 0, sC = 0, sE = 0;
+  const int* pidxB = nullptr;
+  int nb = 1;
+};
+
 template <int EPI>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__ A, int lda,
                                                        const double* __restrict__ Bm, int ldb, int K,
                                                        double* __restrict__ C, int ldc,
                                                        const double* __restrict__ E, int lde,
-                                                       double* __restrict__ rowdot, int tiles_n) {
+                                                       double* __restrict__ rowdot, int tiles_n, GemmBatch gb) {
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
+  {
+    const int b = blockIdx.y;
+    A += (size_t)b * gb.sA;
+    Bm += (size_t)(gb.pidxB ? gb.pidxB[b] : b) * gb.sB;
+    if (C) C += (size_t)b * gb.sC;
+    if (E) E += (size_t)b * gb.sE;
+    if (EPI == 1) rowdot += (size_t)b * tiles_n * ((size_t)gridDim.x / tiles_n * 128);
+  }
   __shared__ GemmSmem sm;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
   const double* At = A + (size_t)(ti * 128) * lda;
@@ -144,11 +171,11 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__
 }
 
 __global__ void rowdot_reduce_kernel(const double* __restrict__ part, int tn, int M, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (i >= M) return;
   double s = 0.0;
-  for (int t = 0; t < tn; t++) s += part[(size_t)t * M + i];
-  out[i] = s;
+  for (int t = 0; t < tn; t++) s += part[((size_t)b * tn + t) * M + i];
+  out[(size_t)b * M + i] = s;  // (batched row dots are packed with stride M)
 }
 
 // column-tile partials of the EPI-1 row dots (own buffer: the callers' scratch layouts stay as they are)
@@ -165,19 +192,19 @@ static int ensure_rowpart(bgp_ctx* c, size_t doubles) {
 
 template <int EPI>
 static int launch_gemm_nt(bgp_ctx* c, const double* A, int lda, const double* Bm, int ldb, int M, int N, int K,
-                          double* C, int ldc, const double* E, int lde, double* rowdot) {
+                          double* C, int ldc, const double* E, int lde, double* rowdot, GemmBatch gb = GemmBatch()) {
   const int tm = M / 128, tn = N / 128;
   double* rd = rowdot;
   if (EPI == 1) {
-    int rc = ensure_rowpart(c, (size_t)tn * M);
+    int rc = ensure_rowpart(c, (size_t)gb.nb * tn * M);
     if (rc) return rc;
     rd = c->drowpart;
   }
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn), dim3(256), 0, c->stream, A, lda, Bm, ldb, K, C, ldc, E, lde,
-                     rd, tn);
+  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn, gb.nb), dim3(256), 0, c->stream, A, lda, Bm, ldb, K, C, ldc, E,
+                     lde, rd, tn, gb);
   BGP_HIP(hipGetLastError());
   if (EPI == 1) {
-    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((M + 255) / 256), dim3(256), 0, c->stream, rd, tn, M, rowdot);
+    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((M + 255) / 256, gb.nb), dim3(256), 0, c->stream, rd, tn, M, rowdot);
     BGP_HIP(hipGetLastError());
   }
   return BGP_OK;
@@ -191,15 +218,23 @@ static inline int pad128(int v) { return ((v + 127) / 128) * 128; }
 // posterior build
 // ------------------------------------------------------------------------------------------
 static int ensure_resident(bgp_ctx* c, int B) {
-  const size_t need = (size_t)B * c->npad * c->npad;
+  // K^-1 needs B npad^2 doubles, alpha B npad: the two capacities are tracked separately (a context reused through
+  // bgp_ctx_update_data may see n shrink and B grow: B=1 at npad=1024 and B=64 at npad=128 need the same K^-1
+  // bytes but 8x the alpha bytes)
+  const size_t need = (size_t)B * c->npad * c->npad, need_a = (size_t)B * c->npad;
   if (need > c->cap_kinv) {
     if (c->dKinv) (void)hipFree(c->dKinv);
-    if (c->dalpha_sol) (void)hipFree(c->dalpha_sol);
-    c->dKinv = c->dalpha_sol = nullptr;
+    c->dKinv = nullptr;
     c->cap_kinv = 0;
     BGP_HIP(hipMalloc(&c->dKinv, need * sizeof(double)));
-    BGP_HIP(hipMalloc(&c->dalpha_sol, (size_t)B * c->npad * sizeof(double)));
     c->cap_kinv = need;
+  }
+  if (need_a > c->cap_alpha) {
+    if (c->dalpha_sol) (void)hipFree(c->dalpha_sol);
+    c->dalpha_sol = nullptr;
+    c->cap_alpha = 0;
+    BGP_HIP(hipMalloc(&c->dalpha_sol, need_a * sizeof(double)));
+    c->cap_alpha = need_a;
   }
   return BGP_OK;
 }
@@ -295,6 +330,16 @@ static double kernel_diag_value(const bgp_ctx* c, const double* hk) {
   return base + s2;
 }
 
+__global__ void add_diag_batch_kernel(double* __restrict__ C, int ld, size_t sC, int m, const double* __restrict__ H,
+                                      int d) {
+  // + white level of item b on the diagonal of its m x m block (kernel_(X) of a Sum with WhiteKernel)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i < m) C[(size_t)b * sC + (size_t)i * ld + i] += exp(H[(size_t)b * (d + 2) + d + 1]);
+}
+
+// Posteriors are processed in chunks of `nb` items whose scratch slices sit side by side: every launch covers the
+// whole chunk (grid.y = item), nothing synchronises inside a chunk, and the host waits once at the end of the call.
+// Results per item are the same bits as an item-by-item loop (each item's tiles are reduced in the same order).
 extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double* mean,
                                  double* var, double* cov) {
   if (!c || !h_kernel || !Xq || !mean || !var || m <= 0 || B <= 0) {
@@ -309,64 +354,76 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
   BGP_HIP(hipSetDevice(c->device));
   const int npad = c->npad, n = c->n, d = c->d, mpad = pad128(m);
   const size_t p = d + 2;
-  size_t need = (size_t)m * d + 2 + p + (size_t)mpad * npad + 2 * (size_t)mpad + 64;
-  if (cov) need += (size_t)mpad * npad + 2 * (size_t)mpad * mpad;
+  const size_t per_item = (size_t)mpad * npad + 2 * (size_t)mpad + (cov ? (size_t)mpad * npad + (size_t)mpad * mpad : 0);
+  const size_t budget = (size_t)1 << 29;  // doubles of scratch per chunk (4 GiB)
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, budget / per_item));
+  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * per_item + 64;
   int rc = bgp_ensure_scratch(c, need);
   if (rc) return rc;
   Scratch s{c->dscratch, 0};
   double* dXq = s.take((size_t)m * d);
-  double* dhk = s.take(p);
-  double* dKs = s.take((size_t)mpad * npad);
-  double* dq = s.take(mpad);
-  double* dout = s.take(mpad);
-  double *dP = nullptr, *dKss = nullptr, *dCov = nullptr;
+  double* dH = s.take((size_t)B * p);
+  double* dKs = s.take((size_t)chunk * mpad * npad);
+  double* dq = s.take((size_t)chunk * mpad);
+  double* dout = s.take((size_t)chunk * mpad);
+  double *dP = nullptr, *dCov = nullptr;
   if (cov) {
-    dP = s.take((size_t)mpad * npad);
-    dKss = s.take((size_t)mpad * mpad);
-    dCov = s.take((size_t)mpad * mpad);
+    dP = s.take((size_t)chunk * mpad * npad);
+    dCov = s.take((size_t)chunk * mpad * mpad);
   }
+  const size_t sKs = (size_t)mpad * npad, sCv = (size_t)mpad * mpad;
   BGP_HIP(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpyAsync(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (c->has_warp) {  // BayesGPR.predict warps the query points with the current warpers (bask/bayesgpr.py:630-632)
     rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0);
     if (rc) return rc;
   }
-  for (int b = 0; b < B; b++) {
-    const double* hk = h_kernel + (size_t)b * p;
-    BGP_HIP(hipMemcpyAsync(dhk, hk, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)mpad * npad * sizeof(double), c->stream));
-    BGP_HIP(hipMemsetAsync(dq, 0, (size_t)mpad * sizeof(double), c->stream));
-    rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0);
+  for (int off = 0; off < B; off += chunk) {
+    const int nb = std::min(chunk, B - off);
+    const double* dHc = dH + (size_t)off * p;
+    const double* Kinv = c->dKinv + (size_t)off * npad * npad;  // items off .. off+nb-1 are posteriors off .. off+nb-1
+    const double* al = c->dalpha_sol + (size_t)off * npad;
+    GemmBatch gb;
+    gb.nb = nb;
+    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)nb * sKs * sizeof(double), c->stream));  // zero padding rows / columns
+    rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
     if (rc) return rc;
-    const double* Kinv = c->dKinv + (size_t)b * npad * npad;
-    const double* al = c->dalpha_sol + (size_t)b * npad;
-    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4), dim3(256), 0, c->stream, dKs, npad, al, n, m, dout);
-    BGP_HIP(hipMemcpyAsync(mean + (size_t)b * m, dout, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (!cov) {
-      rc = launch_gemm_nt<1>(c, dKs, npad, Kinv, npad, mpad, npad, npad, nullptr, 0, dKs, npad, dq);
+    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, al,
+                       (size_t)npad, (const int*)nullptr, n, m, dout, (size_t)mpad);
+    BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
+                             (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    // q_i = rowsum((K_* K^-1) o K_*)
+    gb.sA = sKs, gb.sB = (size_t)npad * npad, gb.sC = 0, gb.sE = sKs;
+    rc = launch_gemm_nt<1>(c, dKs, npad, Kinv, npad, mpad, npad, npad, nullptr, 0, dKs, npad, dq, gb);
+    if (rc) return rc;
+    if (cov) {
+      gb.sC = sKs, gb.sE = 0;
+      rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr, gb);
       if (rc) return rc;
-    } else {
-      rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr);
+      // K_** (no white noise off the diagonal; the diagonal gets c(+1) + s2 like kernel_(X)); then cov = K_** - P K_*^T
+      // in place (every element is read and written by the same lane)
+      BGP_HIP(hipMemsetAsync(dCov, 0, (size_t)nb * sCv * sizeof(double), c->stream));
+      rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, dCov, mpad, sCv);
       if (rc) return rc;
-      // K_** (no white noise off the diagonal; diag gets c(+1)+s2 like kernel_(X))
-      BGP_HIP(hipMemsetAsync(dKss, 0, (size_t)mpad * mpad * sizeof(double), c->stream));
-      rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, dKss, mpad, 0);
+      hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dCov, mpad, sCv, m,
+                         dHc, d);
+      GemmBatch gc;
+      gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv;
+      rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, dCov, mpad, dCov, mpad, nullptr, gc);
       if (rc) return rc;
-      hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dKss, mpad, m,
-                         std::exp(hk[d + 1]));
-      rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, dCov, mpad, dKss, mpad, nullptr);
-      if (rc) return rc;
-      BGP_HIP(hipMemcpy2DAsync(cov + (size_t)b * m * m, (size_t)m * sizeof(double), dCov,
-                               (size_t)mpad * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost,
-                               c->stream));
-      // variance from the covariance diagonal is not needed by the callers of return_cov
-      rc = launch_gemm_nt<1>(c, dKs, npad, Kinv, npad, mpad, npad, npad, nullptr, 0, dKs, npad, dq);
-      if (rc) return rc;
+      for (int b = 0; b < nb; b++)
+        BGP_HIP(hipMemcpy2DAsync(cov + (size_t)(off + b) * m * m, (size_t)m * sizeof(double), dCov + (size_t)b * sCv,
+                                 (size_t)mpad * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost,
+                                 c->stream));
     }
-    hipLaunchKernelGGL(finish_var_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dq, kernel_diag_value(c, hk),
-                       m, dout);
-    BGP_HIP(hipMemcpyAsync(var + (size_t)b * m, dout, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(finish_var_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dq, (size_t)mpad, dHc, d,
+                       c->ks.form, m, dq, (size_t)mpad);  // in place
+    BGP_HIP(hipGetLastError());
+    BGP_HIP(hipMemcpy2DAsync(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
+                             (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    // (the next chunk reuses the scratch slices: stream order keeps its launches behind these copies)
   }
+  BGP_HIP(hipStreamSynchronize(c->stream));
   return BGP_OK;
 }
 
@@ -670,7 +727,8 @@ extern "C" int bgp_pvrs_prepare(bgp_ctx* c, const double* h_kernel, int has_alph
 // sample_y:  f = mean + L_cov z  with  L_cov = chol(cov + jitter I)  (same batched Cholesky, B = 1)
 // ------------------------------------------------------------------------------------------
 __global__ void cov_prepare_kernel(double* __restrict__ C, int m, int mpad, double jitter) {
-  // jitter on the diagonal, identity padding, zero rhs handled by the caller
+  // jitter on the diagonal, identity padding, zero rhs handled by the caller; blockIdx.y = matrix of a batch
+  C += (size_t)blockIdx.y * mpad * mpad;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)mpad * mpad;
        idx += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)(idx / mpad), j = (int)(idx - (size_t)i * mpad);
@@ -712,6 +770,8 @@ static void free_child(bgp_ctx* w) {
   delete w;
 }
 
+static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out);
+
 extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                             const double* z, double jitter, double* out) {
   if (!c || !h_kernel || !Xq || !z || !out || m <= 0 || n_draws <= 0 || b < 0) {
@@ -727,32 +787,9 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   const size_t p = d + 2;
   // child workspace for the m x m Cholesky (shares the stream); cached on the context and grown on demand
   // (an m = 10 000 candidate grid needs 0.8 GB: re-allocating it per call costs more than the factorisation)
-  bgp_ctx* w = c->child;
-  if (w && w->cap_n < (size_t)mpad) {
-    free_child(w);
-    w = c->child = nullptr;
-  }
-  int rc = BGP_OK;
-  if (!w) {
-    w = new bgp_ctx();
-    w->device = c->device;
-    w->stream = c->stream;
-    w->d = d;
-    w->max_batch = 1;
-    w->two_panel = c->two_panel;
-    w->panels = c->panels;
-    if (hipMalloc(&w->dK, (size_t)mpad * mpad * sizeof(double)) != hipSuccess ||
-        hipMalloc(&w->dW, (size_t)(mpad / 128) * 128 * 128 * sizeof(double)) != hipSuccess ||
-        hipMalloc(&w->dyw, (size_t)mpad * sizeof(double)) != hipSuccess ||
-        hipMalloc(&w->dacc, 4 * sizeof(double)) != hipSuccess || hipMalloc(&w->dlml, sizeof(double)) != hipSuccess ||
-        hipMalloc(&w->dstatus, sizeof(int)) != hipSuccess) {
-      bgp_set_error("bgp_sample_y: hipMalloc of the %d x %d covariance workspace failed", mpad, mpad);
-      free_child(w);
-      return BGP_ERR_HIP;
-    }
-    w->cap_n = mpad;
-    c->child = w;
-  }
+  bgp_ctx* w = nullptr;
+  int rc = ensure_child(c, mpad, 1, &w);
+  if (rc) return rc;
   w->n = m;
   w->npad = mpad;
   w->nblk = mpad / 128;
@@ -788,7 +825,8 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     SY(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
                         n_draws, hipMemcpyHostToDevice, c->stream));
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0))) break;
-    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4), dim3(256), 0, c->stream, dKs, npad, al, n, m, dmean);
+    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, 1), dim3(256), 0, c->stream, dKs, npad, (size_t)0, al,
+                       (size_t)0, (const int*)nullptr, n, m, dmean, (size_t)0);
     if ((rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr))) break;
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, dKss, mpad, 0))) break;
     hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dKss, mpad, m,
@@ -820,6 +858,145 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   } while (0);
   (void)hipStreamSynchronize(c->stream);
   return rc;
+}
+
+// out_b = mean_b + L_b z_b for the lower factors left by the batched Cholesky (one wave per row, fixed order)
+__global__ void __launch_bounds__(256) tri_matvec_kernel(const double* __restrict__ Lb, int mpad, const double* __restrict__ z,
+                                                          const double* __restrict__ mean, int m,
+                                                          double* __restrict__ out) {
+  const int b = blockIdx.y, row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* L = Lb + (size_t)b * mpad * mpad + (size_t)row * mpad;
+  const double* zb = z + (size_t)b * mpad;
+  double s = 0.0;
+  for (int j = lane; j <= row; j += 64) s += L[j] * zb[j];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[(size_t)b * mpad + row] = s + mean[(size_t)b * mpad + row];
+}
+
+// workspace of the m x m covariance factorisations: a child context sharing the parent's stream, cached on the
+// parent and grown on demand (rows mpad, nb matrices side by side)
+static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out) {
+  bgp_ctx* w = c->child;
+  if (w && (w->cap_n < (size_t)mpad || w->max_batch < nb)) {
+    free_child(w);
+    w = c->child = nullptr;
+  }
+  if (!w) {
+    w = new bgp_ctx();
+    w->device = c->device;
+    w->stream = c->stream;
+    w->d = c->d;
+    w->max_batch = nb;
+    const size_t B8 = 8 * ((size_t)(nb + 7) / 8);
+    if (hipMalloc(&w->dK, (size_t)nb * mpad * mpad * sizeof(double)) != hipSuccess ||
+        hipMalloc(&w->dW, (size_t)nb * (mpad / 128) * 128 * 128 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&w->dyw, (size_t)nb * mpad * sizeof(double)) != hipSuccess ||
+        hipMalloc(&w->dacc, B8 * 4 * sizeof(double)) != hipSuccess ||
+        hipMalloc(&w->dlml, B8 * sizeof(double)) != hipSuccess || hipMalloc(&w->dstatus, B8 * sizeof(int)) != hipSuccess) {
+      bgp_set_error("hipMalloc of the %d x (%d x %d) covariance workspace failed", nb, mpad, mpad);
+      (void)hipGetLastError();
+      free_child(w);
+      return BGP_ERR_HIP;
+    }
+    w->cap_n = mpad;
+    c->child = w;
+  }
+  w->two_panel = c->two_panel;
+  w->panels = c->panels;
+  w->use_syrk2 = c->use_syrk2;
+  *out = w;
+  return BGP_OK;
+}
+
+// One function draw per resident posterior (the hyper-posterior branch of BayesGPR.sample_y, bask/bayesgpr.py:679-718,
+// and the Thompson-sampling acquisition): item i uses posterior pidx[i] with the kernel parameters h_kernel[i] (noise
+// already switched off by the caller where the reference does), its own standard-normal vector z[i] and returns
+// out[i] = mean_i + chol(cov_i + jitter I) z[i].  All items of a chunk share every launch (grid.y = item), including
+// ONE batched Cholesky of their covariance matrices.  status[i] != 0: covariance i not positive definite at that
+// jitter (out[i] undefined) -- the caller retries those items with a larger jitter.
+extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const double* h_kernel, int m, const double* Xq,
+                                  const double* z, double jitter, double* out, int* status) {
+  if (!c || !pidx || !h_kernel || !Xq || !z || !out || !status || m <= 0 || B <= 0) {
+    bgp_set_error("bgp_sample_y_batch: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  for (int i = 0; i < B; i++)
+    if (pidx[i] < 0 || pidx[i] >= c->post_B) {
+      bgp_set_error("bgp_sample_y_batch: posterior %d not resident (%d resident)", pidx[i], c->post_B);
+      return BGP_ERR_STATE;
+    }
+  BGP_HIP(hipSetDevice(c->device));
+  const int npad = c->npad, n = c->n, d = c->d, mpad = pad128(m);
+  const size_t p = d + 2;
+  const size_t sKs = (size_t)mpad * npad, sCv = (size_t)mpad * mpad;
+  const size_t per_item = 2 * sKs + sCv + 3 * (size_t)mpad;  // K_*, P, cov (child), mean / z / out
+  const size_t budget = (size_t)1 << 30;                     // doubles per chunk (8 GiB)
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, budget / per_item));
+  bgp_ctx* w = nullptr;
+  int rc = ensure_child(c, mpad, chunk, &w);
+  if (rc) return rc;
+  w->n = m;
+  w->npad = mpad;
+  w->nblk = mpad / 128;
+  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * (2 * sKs + 3 * (size_t)mpad) + (size_t)B + 64;
+  rc = bgp_ensure_scratch(c, need);
+  if (rc) return rc;
+  Scratch s{c->dscratch, 0};
+  double* dXq = s.take((size_t)m * d);
+  double* dH = s.take((size_t)B * p);
+  double* dKs = s.take((size_t)chunk * sKs);
+  double* dP = s.take((size_t)chunk * sKs);
+  double* dmean = s.take((size_t)chunk * mpad);
+  double* dZ = s.take((size_t)chunk * mpad);
+  double* dO = s.take((size_t)chunk * mpad);
+  int* dpidx = reinterpret_cast<int*>(s.take(((size_t)B + 1) / 2 + 1));
+  BGP_HIP(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpyAsync(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpyAsync(dpidx, pidx, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (c->has_warp) {
+    rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0);
+    if (rc) return rc;
+  }
+  for (int off = 0; off < B; off += chunk) {
+    const int nb = std::min(chunk, B - off);
+    const double* dHc = dH + (size_t)off * p;
+    const int* dpc = dpidx + off;
+    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)nb * sKs * sizeof(double), c->stream));
+    BGP_HIP(hipMemsetAsync(w->dK, 0, (size_t)nb * sCv * sizeof(double), c->stream));
+    BGP_HIP(hipMemsetAsync(dZ, 0, (size_t)nb * mpad * sizeof(double), c->stream));
+    BGP_HIP(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z + (size_t)off * m, (size_t)m * sizeof(double),
+                             (size_t)m * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));
+    rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, c->dalpha_sol,
+                       (size_t)npad, dpc, n, m, dmean, (size_t)mpad);
+    GemmBatch gp;  // P = K_* K^-1
+    gp.nb = nb, gp.sA = sKs, gp.sB = (size_t)npad * npad, gp.sC = sKs, gp.pidxB = dpc;
+    rc = launch_gemm_nt<0>(c, dKs, npad, c->dKinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr, gp);
+    if (rc) return rc;
+    // cov = K_** - P K_*^T in place in the child's matrices, + jitter, identity padding
+    rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, w->dK, mpad, sCv);
+    if (rc) return rc;
+    hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, w->dK, mpad, sCv, m, dHc,
+                       d);
+    GemmBatch gc;
+    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv;
+    rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, w->dK, mpad, nullptr, gc);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cov_prepare_kernel, dim3(256, nb), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
+    BGP_HIP(hipMemsetAsync(w->dyw, 0, (size_t)nb * mpad * sizeof(double), c->stream));
+    BGP_HIP(hipMemsetAsync(w->dstatus, 0, (size_t)nb * sizeof(int), c->stream));
+    rc = bgp_launch_cholesky(w, nb, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tri_matvec_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, w->dK, mpad, dZ, dmean, m, dO);
+    BGP_HIP(hipGetLastError());
+    BGP_HIP(hipMemcpyAsync(status + off, w->dstatus, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(hipMemcpy2DAsync(out + (size_t)off * m, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
+                             (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+  }
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
 }
 
 void bgp_free_child(bgp_ctx* c) {

@@ -164,6 +164,17 @@ int bgp_pvrs_prepare(bgp_ctx* ctx, const double* h_kernel, int has_alpha_vec, in
 int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                  const double* z, double jitter, double* out);
 
+/*
+ * One draw per hyper-posterior sample, batched: item i draws f_i ~ N(mean_i, cov_i) at the m points from the
+ * resident posterior pidx[i] with kernel parameters h_kernel[i] (B*(d+2)) and the standard normals z[i] (B*m);
+ * out is B*m.  The B covariance matrices are factorised by ONE batched Cholesky.  status[i] != 0: cov_i + jitter*I
+ * not numerically positive definite (out[i] undefined; the caller retries those items with a larger jitter).
+ * Replaces: the per-sample loop of BayesGPR.sample_y(sample_mean=False) -- theta setter + sklearn sample_y per
+ * chain row (bask/bayesgpr.py:679-718) -- after one bgp_posterior_batch over the drawn chain rows.
+ */
+int bgp_sample_y_batch(bgp_ctx* ctx, int B, const int* pidx, const double* h_kernel, int m, const double* Xq,
+                       const double* z, double jitter, double* out, int* status);
+
 /* Number of walker groups (HIP streams) an LML batch is split over: one group's kernels fill the tail
  * of the other group's launches.  Default: automatic -- two groups for batches of >= 64 matrices (+3.7 % at
  * n = 2048 x 128 matrices on MI355X, results bit-identical), one group below that (every group's dependent

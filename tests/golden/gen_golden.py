@@ -314,6 +314,56 @@ def gen_reference_tier1(out):
     print("tier1 ok")
 
 
+def gen_sizes_posterior(out):
+    """Posterior mean / std at the BASELINE sizes (configs B, C, D: bask/bayesgpr.py:622-635 -> skopt predict,
+    SURVEY.md 3.4) and the reference's own PVRS on a candidate subset at config E's size
+    (bask/acquisition.py:316-339).  Seeds + scalars only: X, y, Xq are regenerated by synth() / RandomState."""
+    ref = import_reference_tier1()
+    rec = {}
+    for tag, n, d in (("B", 1024, 8), ("C", 2048, 16), ("D", 4096, 32)):
+        X, y = synth(n, d, seed=0)
+        m = 64
+        Xq = np.random.RandomState(200 + n).uniform(size=(m, d))
+        th = thetas(d, 1, seed=210 + n, spread=0.15)[0]
+        g = sk_gpr(make_kernel("matern52", "product", d).clone_with_theta(th), X, y, 1e-10)
+        L_inv = solve_triangular(g.L_.T, np.eye(n))
+        K_inv = L_inv.dot(L_inv.T)  # the explicit inverse the reference forms (bask/bayesgpr.py:214-216)
+        mean, std = skopt_predict(g, K_inv, Xq)
+        m2, s2 = g.predict(Xq, return_std=True)
+        assert np.allclose(mean, m2, rtol=1e-8, atol=1e-11)
+        g.kernel_.set_params(k2=sk.WhiteKernel(noise_level=0.0))  # noise_set_to_zero, no refit
+        mean0, std0 = skopt_predict(g, K_inv, Xq)
+        rec[tag + "_nd_seed_m_qseed"] = np.array([n, d, 0, m, 200 + n])
+        rec[tag + "_theta"] = th
+        rec[tag + "_mean"], rec[tag + "_std"], rec[tag + "_std0"] = mean, std, std0
+        rec[tag + "_lml"] = np.array(sk_gpr(make_kernel("matern52", "product", d), X, y, 1e-10).log_marginal_likelihood(th))
+        rec[tag + "_alpha_head"] = g.alpha_[:16]
+        print(tag, "mean[:3]", mean[:3], "std[:3]", std[:3], "cond(K) ~ %.2e" % np.linalg.cond(g.L_) ** 2)
+
+    # config E size: n = 1024, d = 8, vector alpha (Optimizer.tell always passes one), 64 candidates, 8 Thompson draws
+    class DuckGP:
+        warp_inputs = False
+
+        def __init__(self, X, kernel_, alpha, thompson):
+            self.X_train_, self.kernel_, self.alpha, self._th = X, kernel_, alpha, thompson
+
+        def sample_y(self, X, sample_mean=True, n_samples=1, random_state=None):
+            return self._th
+
+    n, d, m, T = 1024, 8, 64, 8
+    X, y = synth(n, d, seed=0)
+    Xc = np.random.RandomState(300).uniform(size=(m, d))
+    th = thetas(d, 1, seed=301, spread=0.15)[0]
+    k = make_kernel("matern52", "product", d).clone_with_theta(th)
+    alpha = 1e-10 + 0.01 * np.random.RandomState(302).rand(n)
+    thompson = np.random.RandomState(303).randn(m, T)
+    covs = ref["acquisition"].PVRS()(Xc, DuckGP(X, k, alpha, thompson), n_thompson=T, random_state=0)
+    rec["E_nd_seed_m_T"] = np.array([n, d, 0, m, T])
+    rec["E_theta"], rec["E_covs"] = th, covs
+    print("E covs[:4]", covs[:4])
+    np.savez_compressed(os.path.join(out, "posterior_sizes.npz"), **rec)
+
+
 def gen_mvn(out):
     """numpy legacy multivariate_normal (SVD path) used by sklearn sample_y
     (sklearn:_gpr.py:522-526)."""
@@ -334,4 +384,5 @@ if __name__ == "__main__":
     gen_predict(HERE)
     gen_reference_tier1(HERE)
     gen_mvn(HERE)
+    gen_sizes_posterior(HERE)
     print("done")

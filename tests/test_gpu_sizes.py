@@ -1,0 +1,238 @@
+"""Parity at the BASELINE.json sizes (north star: LML AND posterior mean / variance within 1e-6 relative):
+
+* posterior mean / std (with noise and inside noise_set_to_zero) at 64 query points for configs B (n=1024, d=8),
+  C (n=2048, d=16) and D (n=4096, d=32) against scikit-learn 1.7.2 + the skopt predict formula with the explicit
+  inverse the reference forms (``bask/bayesgpr.py:200-217,622-635``; ``tests/golden/posterior_sizes.npz``);
+* the reference's own ``bask.acquisition.PVRS`` (per-candidate bordered Cholesky loop, ``bask/acquisition.py:316-339``)
+  on 64 candidates at config E's size (n = 1024, vector alpha);
+* config E itself: ``Optimizer.tell`` with PVRS over 10 000 candidates at n = 975..977, 128 posterior samples -- the
+  device PVRS vector against the oracle's per-candidate loop on a candidate subset, argmax consistency, and the
+  ``ei`` / ``n_samples = 128`` variant against per-sample oracle predictions on a subset;
+* the batched posterior consumers against their item-by-item forms (bit-equal).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import _lib
+
+    assert _lib.device_count() >= 1
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def bask():
+    import bayes_skopt_amd as bask
+
+    return bask
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gp_oracle
+
+    return gp_oracle
+
+
+@pytest.mark.parametrize("tag", ["B", "C", "D"])
+def test_posterior_mean_and_std_at_baseline_sizes(lib, tag):
+    g = load_golden("posterior_sizes.npz")
+    n, d, seed, m, qseed = [int(v) for v in g[tag + "_nd_seed_m_qseed"]]
+    X, y = synth(n, d, seed)
+    Xq = np.random.RandomState(qseed).uniform(size=(m, d))
+    th = g[tag + "_theta"]
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    res = ctx.posterior(th, want_alpha=True)
+    assert res["status"][0] == 0
+    np.testing.assert_allclose(res["lml"][0], float(g[tag + "_lml"]), rtol=RTOL)
+    np.testing.assert_allclose(res["alpha"][0][:16], g[tag + "_alpha_head"], rtol=RTOL, atol=1e-9)
+    mean, var = ctx.predict(th, Xq)
+    scale = np.abs(g[tag + "_mean"]).max()
+    np.testing.assert_allclose(mean[0], g[tag + "_mean"], rtol=RTOL, atol=1e-6 * scale)
+    np.testing.assert_allclose(np.sqrt(var[0]), g[tag + "_std"], rtol=RTOL)
+    th0 = th.copy()
+    th0[-1] = -np.inf  # noise_set_to_zero: factors keep the noise, the predictive kernel drops it
+    mean0, var0 = ctx.predict(th0, Xq)
+    np.testing.assert_array_equal(mean0, mean)
+    np.testing.assert_allclose(np.sqrt(var0[0]), g[tag + "_std0"], rtol=RTOL)
+    ctx.close()
+
+
+def test_pvrs_reference_loop_at_config_e_size(lib):
+    g = load_golden("posterior_sizes.npz")
+    n, d, seed, m, T = [int(v) for v in g["E_nd_seed_m_T"]]
+    X, _ = synth(n, d, seed)
+    Xc = np.random.RandomState(300).uniform(size=(m, d))
+    alpha = 1e-10 + 0.01 * np.random.RandomState(302).rand(n)
+    thompson = np.random.RandomState(303).randn(m, T)
+    ctx = lib.Context(X, np.zeros(n), alpha, max_batch=2)
+    th = g["E_theta"]
+    assert ctx.pvrs_prepare(th, True) == 0
+    covs = ctx.pvrs(th, Xc, Xc[np.argmin(thompson, axis=0)])
+    np.testing.assert_allclose(covs, g["E_covs"], rtol=RTOL)
+    ctx.close()
+
+
+def _config_e_optimizer(bask, acq, n0=974, n_points=10_000, seed=0):
+    rng = np.random.RandomState(seed)
+    opt = bask.Optimizer(dimensions=[(0.0, 1.0)] * 8, n_points=n_points, n_initial_points=5, acq_func=acq,
+                         random_state=seed)
+    X0 = rng.uniform(size=(n0, 8))
+
+    def f(x):
+        return float(np.sin(3.0 * np.sum(x)) + 0.1 * rng.randn())
+
+    opt.tell(X0.tolist(), [f(x) for x in X0], fit=False)  # pre-seed so that n reaches config E's size
+    return opt, f
+
+
+def test_config_e_tell_loop_pvrs_at_size(bask, O):
+    """BASELINE config E: Optimizer.tell, PVRS over a 10 000-candidate grid, 128 posterior samples, n ~ 1000."""
+    opt, f = _config_e_optimizer(bask, "pvrs")
+    for it in range(3):
+        x = opt.ask() if it else [0.5] * 8
+        res = opt.tell(x, f(x), gp_samples=128, gp_burnin=10, n_samples=0)
+    n = 974 + 3
+    gp = opt.gp
+    assert len(opt.Xi) == n and gp.X_train_.shape == (n, 8)
+    assert gp.chain_.shape == (200, 10)  # 100 walkers x ceil(128 / 100) kept steps (bask/bayesgpr.py:390,496-500)
+    cand, vals = opt._last_candidates, opt._last_acq_values
+    assert cand.shape == (10_000, 8) and vals.shape == (10_000,) and np.all(np.isfinite(vals)) and np.all(vals > 0)
+    np.testing.assert_allclose(opt.ask(), opt.space.inverse_transform(cand[np.argmax(vals)][None, :])[0])
+    assert res.fun == min(opt.yi)
+    # the device PVRS vector for the median GP and fixed Thompson points vs the reference's per-candidate
+    # (n+1) x (n+1) Cholesky loop (oracle restatement) on a candidate subset that includes the chosen point
+    tp = cand[[3, 77, 1234, 5000, 9999]]
+    dev = gp._pvrs(cand, tp, True)
+    sub = np.unique(np.concatenate([[int(np.argmax(vals)), int(np.argmax(dev)), int(np.argmin(dev))],
+                                    np.random.RandomState(1).choice(10_000, size=13, replace=False)]))
+    h = gp._canonical(gp._kernel_theta_for_predict())[0]
+    ref = O.pvrs_covs(gp.X_train_, np.asarray(gp.alpha), h, cand[sub], tp)
+    np.testing.assert_allclose(dev[sub], ref, rtol=RTOL)
+    # and the hyper-posterior LML at the median the optimizer reports (bask/bayesgpr.py:545-547)
+    ad = np.asarray(gp.alpha, dtype=np.float64)
+    np.testing.assert_allclose(gp.log_marginal_likelihood_value_,
+                               O.lml(gp.X_train_, gp.y_train_, ad, gp._canonical(gp.theta)[0]), rtol=RTOL)
+
+
+def test_config_e_tell_ei_128_hyper_samples_at_size(bask, O):
+    """The EI variant of config E: 128 hyper-posterior samples x 10 000 candidates -- one batched
+    posterior build + one batched predict; per-sample mean / std against the oracle on a candidate subset."""
+    opt, f = _config_e_optimizer(bask, "ei", seed=1)
+    opt.tell([0.5] * 8, f([0.5] * 8), gp_samples=128, gp_burnin=10, n_samples=128)
+    gp = opt.gp
+    cand, vals = opt._last_candidates, opt._last_acq_values
+    assert np.all(np.isfinite(vals)) and vals.max() > 0
+    rows = gp.chain_[[0, 57, 199]]
+    sub = np.random.RandomState(2).choice(10_000, size=40, replace=False)
+    mus, stds = gp._predict_hyper_samples(rows, cand, noise_zero=True)
+    ad = np.asarray(gp.alpha, dtype=np.float64)
+    for k, row in enumerate(rows):
+        mo, so = O.predict(gp.X_train_, gp.y_train_, ad, gp._canonical(row)[0], cand[sub], noise_zero=True)
+        mo = gp.y_train_std_ * mo + gp.y_train_mean_
+        np.testing.assert_allclose(mus[k][sub], mo, rtol=RTOL, atol=1e-6 * np.abs(mo).max())
+        np.testing.assert_allclose(stds[k][sub], so * gp.y_train_std_, rtol=RTOL)
+
+
+def test_batched_predict_equals_item_by_item(lib):
+    """bgp_predict_batch covers a chunk of posteriors per launch (grid.y = item): same bits as one call per item."""
+    n, d, m, B = 300, 4, 333, 7
+    X, y = synth(n, d, 5)
+    Xq = np.random.RandomState(6).uniform(size=(m, d))
+    TH = np.concatenate([[0.0], np.full(d, np.log(0.4)), [np.log(0.02)]]) + 0.2 * np.random.RandomState(7).randn(B, d + 2)
+    ctx = lib.Context(X, y, 1e-10, max_batch=4)
+    assert np.all(ctx.posterior(TH)["status"] == 0)
+    mean, var, cov = ctx.predict(TH, Xq, return_cov=True)
+    mean2, var2 = ctx.predict(TH, Xq)
+    np.testing.assert_array_equal(mean, mean2)
+    np.testing.assert_array_equal(var, var2)
+    for b in range(B):
+        assert ctx.posterior(TH[b])["status"][0] == 0
+        m1, v1, c1 = ctx.predict(TH[b], Xq, return_cov=True)
+        np.testing.assert_array_equal(m1[0], mean[b])
+        np.testing.assert_array_equal(v1[0], var[b])
+        np.testing.assert_array_equal(c1[0], cov[b])
+    ctx.close()
+
+
+def test_batched_sample_y_equals_item_by_item(lib, bask):
+    """BayesGPR.sample_y(sample_mean=False): one batched posterior build over the drawn chain rows + one batched
+    covariance Cholesky (bgp_sample_y_batch) -- the same draws as one posterior build + one bgp_sample_y per draw
+    (same factors bit for bit; the final L z is a wave-per-row dot product here and a tile GEMM there, so the last
+    bit may differ)."""
+    n, d, m = 120, 2, 201
+    X, y = synth(n, d, 11)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=3)
+    gp.fit(X, y, n_desired_samples=60, n_burnin=3, n_walkers_per_thread=20, progress=False)
+    Xq = np.random.RandomState(12).uniform(size=(m, d))
+    theta_before, alpha_before = gp.theta.copy(), gp.alpha_.copy()
+    out = gp.sample_y(Xq, n_samples=9, random_state=5)
+    assert out.shape == (m, 9)
+    np.testing.assert_array_equal(gp.theta, theta_before)
+    np.testing.assert_array_equal(gp.alpha_, alpha_before)
+    rng = np.random.RandomState(5)
+    ind = rng.choice(len(gp.chain_), size=9, replace=True)
+    ctx = gp._ctx
+    for k, j in enumerate(ind):
+        z = rng.standard_normal((1, m))
+        H = gp._canonical(gp.chain_[j])
+        assert ctx.posterior(H, want_alpha=False)["status"][0] == 0
+        Hk = H.copy()
+        Hk[:, -1] = -np.inf
+        ref = gp.y_train_std_ * ctx.sample_y(0, Hk, Xq, z, jitter=1e-10)[0] + gp.y_train_mean_
+        np.testing.assert_allclose(out[:, k], ref, rtol=1e-12, atol=1e-13)
+    # the median GP still predicts as before (its posterior is made resident again on demand)
+    mu = gp.predict(Xq[:5])
+    gp2 = gp.predict(Xq[:5])
+    np.testing.assert_array_equal(mu, gp2)
+
+
+def test_thompson_sampling_with_input_warping(bask):
+    """Optimizer(acq_func='ts') with warp_inputs=True: chain rows carry 2d warp parameters behind the kernel's theta
+    (bask/acquisition.py:112-119); every draw installs its own warp and the warpers are restored afterwards."""
+    rng = np.random.RandomState(0)
+    opt = bask.Optimizer(dimensions=[(0.0, 1.0)] * 2, n_points=200, n_initial_points=6, init_strategy="r2",
+                         acq_func="ts", gp_kwargs=dict(warp_inputs=True), random_state=0)
+    for _ in range(8):
+        x = opt.ask()
+        opt.tell(x, float(np.sin(4 * x[0]) + x[1] ** 2 + 0.01 * rng.randn()), gp_samples=100, gp_burnin=2, n_samples=3)
+    gp = opt.gp
+    assert gp.chain_.shape[1] == len(gp.kernel_.theta) + 4
+    wa, wb = gp.warp_alphas_.copy(), gp.warp_betas_.copy()
+    vals = bask.acquisition.evaluate_acquisitions(opt._last_candidates, gp, (bask.acquisition.ThompsonSampling(),),
+                                                  n_samples=4, random_state=1)
+    assert vals.shape == (1, 200) and np.all(np.isfinite(vals)) and np.ptp(vals) > 0
+    np.testing.assert_array_equal(gp.warp_alphas_, wa)
+    np.testing.assert_array_equal(gp.warp_betas_, wb)
+    assert all(0.0 <= v <= 1.0 for v in opt.ask())
+
+
+def test_resident_buffers_follow_shrinking_n_and_growing_batch(lib, O):
+    """A context reused through update_data: B = 1 at n ~ 1000, then n ~ 100 with B = 64 posteriors (the alpha
+    buffer needs 8x the doubles although K^-1 needs the same)."""
+    X, y = synth(1000, 3, 1)
+    ctx = lib.Context(X, y, 1e-10, max_batch=64)
+    th = np.array([0.0, -1.0, -1.1, -0.9, -3.0])
+    assert ctx.posterior(th)["status"][0] == 0
+    X2, y2 = synth(100, 3, 2)
+    ctx.update_data(X2, y2, np.full(100, 1e-10))
+    TH = th + 0.1 * np.random.RandomState(3).randn(64, 5)
+    res = ctx.posterior(TH, want_alpha=True)
+    assert np.all(res["status"] == 0)
+    Xq = np.random.RandomState(4).uniform(size=(9, 3))
+    mean, var = ctx.predict(TH, Xq)
+    for b in (0, 31, 63):
+        _, _, ao = O.posterior(X2, y2, np.full(100, 1e-10), TH[b])
+        np.testing.assert_allclose(res["alpha"][b], ao, rtol=RTOL, atol=1e-9)
+        mo, so = O.predict(X2, y2, np.full(100, 1e-10), TH[b], Xq)
+        np.testing.assert_allclose(mean[b], mo, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(np.sqrt(var[b]), so, rtol=RTOL, atol=1e-9)
+    ctx.close()
