@@ -3,19 +3,28 @@
 // tests/ (layout self-check).  Not part of the reference surface.
 #include "bgp_common.h"
 
-__global__ void __launch_bounds__(256) mfma_f64_peak_kernel(double* out, int iters, double a0, double b0) {
-  d4 acc[8];
+// 16 independent accumulators per wave as a 4 x 4 register block (4 A and 4 B fragments reused like the trailing
+// update's inner loop), back to back, two waves per SIMD: the form in which v_mfma_f64_16x16x4_f64 reaches its
+// issue rate (a chain of 8 accumulators on ONE operand pair, the round-1 probe, stops at ~49 TF).
+#define BGP_PEAK_MFMA(acc, a, b) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+__global__ void __launch_bounds__(256, 2) mfma_f64_peak_kernel(double* out, int iters, double a0, double b0) {
+  d4 acc[16];
 #pragma unroll
-  for (int i = 0; i < 8; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
-  double a = a0 + threadIdx.x * 1e-9, b = b0;
+  for (int i = 0; i < 16; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    a[i] = a0 + threadIdx.x * 1e-9 + i;
+    b[i] = b0 * 0.5 + i;
+  }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 16; i++) BGP_PEAK_MFMA(acc[i], a[i & 3], b[i >> 2]);
   }
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  if (s == 123.456) out[0] = s;  // keep the chain live
+  for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;  // keep the chains live
 }
 
 extern "C" int bgp_bench_mfma_f64(int device, int iters, double* tflops) {
@@ -26,7 +35,7 @@ extern "C" int bgp_bench_mfma_f64(int device, int iters, double* tflops) {
   hipEvent_t e0, e1;
   BGP_HIP(hipEventCreate(&e0));
   BGP_HIP(hipEventCreate(&e1));
-  const int blocks = 256 * 8;  // 8 workgroups x 4 waves per CU: 8 waves per SIMD
+  const int blocks = 256 * 2;  // 2 workgroups x 4 waves per CU: 2 waves per SIMD
   hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, 0, d, 16, 1.0, 1.0);  // warm-up
   BGP_HIP(hipDeviceSynchronize());
   BGP_HIP(hipEventRecord(e0, 0));
@@ -35,7 +44,7 @@ extern "C" int bgp_bench_mfma_f64(int device, int iters, double* tflops) {
   BGP_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
   BGP_HIP(hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)blocks * 4.0 * (double)iters * 8.0 * (2.0 * 16 * 16 * 4);
+  const double flops = (double)blocks * 4.0 * (double)iters * 16.0 * (2.0 * 16 * 16 * 4);
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

@@ -700,6 +700,8 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
                       int K, int jstart, int colmode, int B);
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k);
+void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
+                      int ystride, int nblk, int k);
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
@@ -741,7 +743,10 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
         bgp_tend(ctx, st);
         if (k + j + 1 >= nblk) break;
         bgp_tbegin(ctx, 2, st);
-        bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
+        if (ctx->use_syrk2)
+          bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
+        else
+          bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 3, st);

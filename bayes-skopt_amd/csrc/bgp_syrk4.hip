@@ -78,9 +78,11 @@ static __device__ __forceinline__ void s4_frag_addr(unsigned (&p)[4], unsigned b
 // (hipcc pairs the fragment reads into ds_read2st64_b64; hand-placed single ds_read_b64 with counted lgkmcnt
 // waits -- conflict-free and twice the LDS rate on paper -- measured no faster: the LDS is not the limiter.)
 // VAR (bench builds only, tools/syrk4_bench.hip): bit 0 = no LDS-DMA issue, bit 1 = no MFMAs, bit 2 = timestamps.
-template <int NR, int NC, int CREL, int VAR>
+// jmin (wave-uniform): column blocks j < jmin are skipped (panel solve: B = W_kk is lower triangular and its upper
+// blocks are never written, so this chunk's k range does not reach them); pass 0 for "all".
+template <int NR, int NC, int CREL, int VAR, int NEGA = 1>
 static __device__ __forceinline__ void s4_mma(const unsigned (&pa)[4], const unsigned (&pb)[4], int soff,
-                                              d4 (&acc)[NR][NC]) {
+                                              d4 (&acc)[NR][NC], int jmin = 0) {
   typedef __attribute__((address_space(3))) const double* lds_cdp;
   double a[2][NR], b[2][NC];
 #pragma unroll
@@ -97,15 +99,17 @@ static __device__ __forceinline__ void s4_mma(const unsigned (&pa)[4], const uns
       for (int j = 0; j < NC; j++) b[nxt][j] = *(lds_cdp)(uintptr_t)(pb[kk + 1] + soff + j * 16 * S4_ROWB);
     }
 #pragma unroll
-    for (int j = 0; j < NC; j++)
+    for (int j = 0; j < NC; j++) {
+      if (j < jmin) continue;  // wave-uniform
 #pragma unroll
       for (int i = 0; i < NR; i++) {
         if (j + CREL > i) continue;  // compile-time (lower part of a diagonal block)
         if (VAR & 2)
           asm volatile("" ::"v"(a[cur][i]), "v"(b[cur][j]));
         else
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc[i][j], 0, 0, 1);  // neg A
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc[i][j], 0, 0, NEGA);
       }
+    }
   }
 }
 
@@ -254,6 +258,91 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
   const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
   hipLaunchKernelGGL((syrk4_kernel<64, 0>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
                      colmode, B, total, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Panel solve on the same LDS-DMA ring:  X_i = A_ik W_kk^T  for every row block i > k (W_kk = L_kk^-1 from potrf,
+// lower triangular), fused with the right-hand-side update  y_i -= X_i z_k  (the forward substitution of
+// cho_solve, sklearn/_gpr.py:597).  One workgroup per 64 rows x all 128 columns of a row block (so the in-place
+// overwrite stays inside the rows a workgroup has staged completely), four waves stacked along the rows (16 rows x
+// 128 columns each: every wave sees the same triangular structure of W_kk, so the k-skip leaves them equally
+// loaded), 48 KB of LDS: three workgroups per CU.  Chunk c (k in [16c, 16c+16)) only reaches the column blocks
+// j >= c of W_kk^T.
+// Replaces trsm8_kernel (VGPR staging between two barriers per chunk, 10 registers spilled at its 128-VGPR cap).
+// ------------------------------------------------------------------------------------------
+template <int VAR>
+__global__ void __launch_bounds__(256, 3)
+    trsm4_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
+                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B) {
+  constexpr unsigned AOPB = 64 * S4_ROWB, STAGEB = (64 + 128) * S4_ROWB;
+  const int nrb = nblk - k - 1;
+  int b, t;
+  bgp_map_block(blockIdx.x, 2 * nrb, B, b, t);
+  if (b >= B || status[b] != 0) return;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ib = k + 1 + (t >> 1), half = t & 1;
+  double* A = Kbuf + (size_t)b * mstride + (size_t)(ib * 128 + half * 64) * ld + k * 128;
+  const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
+  unsigned voffA[2], voffW[4];
+  s4_src<64>(voffA, ld, w, lane);
+  s4_src<128>(voffW, 128, w, lane);
+  const int r0 = w * 16;
+  unsigned pa[4], pb[4];
+  s4_frag_addr(pa, lds0, r0, lane);
+  s4_frag_addr(pb, lds0 + AOPB, 0, lane);
+  d4 acc[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) acc[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  s4_issue<64>(A, voffA, 0, lds0, w);
+  s4_issue<128>(W, voffW, 0, lds0 + AOPB, w);
+  for (int c = 0; c < 8; c += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      S4_WAIT_VM0();
+      __builtin_amdgcn_s_barrier();
+      if (c + s + 1 < 8) {
+        const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
+        s4_issue<64>(A, voffA, (c + s + 1) * S4_KC, nb, w);
+        s4_issue<128>(W, voffW, (c + s + 1) * S4_KC, nb + AOPB, w);
+      }
+      s4_mma<1, 8, -64, VAR, 0>(pa, pb, s * STAGEB, acc, c + s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // Every read of this workgroup's A rows was staged through LDS before the last barrier (all waves passed it
+  // after landing their own share): overwrite in place.  A row belongs to one wave: 16 lanes share it, fixed
+  // shuffle order, and the right-hand side is updated directly -- bitwise reproducible.
+  const double* zk = yw + (size_t)b * ystride + k * 128;
+  double zc[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
+  double* yi = yw + (size_t)b * ystride + ib * 128 + half * 64;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int row = GK_ROWB(r0, 0, lane, r);
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const double x = acc[0][j][r];
+      A[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
+      part += x * zc[j];
+    }
+    part += __shfl_xor(part, 1);
+    part += __shfl_xor(part, 2);
+    part += __shfl_xor(part, 4);
+    part += __shfl_xor(part, 8);
+    if ((lane & 15) == 0) yi[row] -= part;
+  }
+}
+
+void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
+                      int ystride, int nblk, int k) {
+  const int B8 = 8 * ((B + 7) / 8);
+  hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * (nblk - k - 1)), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride,
+                     ystride, nblk, k, B);
 }
 
 #ifdef S4_BENCH  // ablation / trace instantiations for tools/syrk4_bench.hip (not in the product library)

@@ -47,59 +47,171 @@ def trailing_flops_per_launch(n, nb=NB):
     return [nb * (n - j * nb) * (n - j * nb + 1) for j in range(1, n // nb)]
 
 
-def cpu_baseline(X, y, thetas, budget_s=20.0):
-    """Oracle (numpy/scipy restatement of sklearn's log_marginal_likelihood) on the host cores,
-    one walker at a time as emcee's map would, bounded sample of the same workload."""
-    from oracle import gp_oracle as O
-
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
 
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = os.cpu_count() or 1
-    ad = np.full(len(y), 1e-10)
-    O.lml(X, y, ad, thetas[0])  # warm-up
-    t0 = time.perf_counter()
-    done = 0
+        return os.cpu_count() or 1
+
+
+def _timed_evals(fn, thetas, budget_s, min_evals=3):
+    """Sequential evaluations (one walker at a time, as emcee's map would) until the budget is used up, at least
+    `min_evals`; returns the per-evaluation times."""
+    fn(thetas[0])  # warm-up
+    times = []
+    t_start = time.perf_counter()
     for th in thetas:
-        O.lml(X, y, ad, th)
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
+        t0 = time.perf_counter()
+        fn(th)
+        times.append(time.perf_counter() - t0)
+        if len(times) >= min_evals and time.perf_counter() - t_start > budget_s:
             break
-    dt = time.perf_counter() - t0
+    return times
+
+
+def cpu_baseline(X, y, thetas, budget_s=8.0):
+    """Oracle (numpy/scipy restatement of sklearn's log_marginal_likelihood) on the host cores, a bounded sample of
+    the same workload, at ONE BLAS thread and at all of them; `value` = the better of the two from
+    the median evaluation time."""
+    from threadpoolctl import threadpool_limits
+
+    from oracle import gp_oracle as O
+
+    ad = np.full(len(y), 1e-10)
+    all_threads = _blas_threads()
+    runs = {}
+    for label, nthreads in (("1_thread", 1), ("all_cores", all_threads)):
+        with threadpool_limits(limits=nthreads):
+            t = _timed_evals(lambda th: O.lml(X, y, ad, th), thetas, budget_s)
+        runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                       "evals_per_s": float(1.0 / np.median(t))}
+    best = max(runs, key=lambda k: runs[k]["evals_per_s"])
     return {
-        "value": done / dt,
+        "value": runs[best]["evals_per_s"],
         "unit": "LML-evals/s",
-        "cores": int(threads),
+        "cores": runs[best]["threads"],
         "kind": "port",
-        "sample": f"{done} sequential LML evaluations (n={len(y)}, d={X.shape[1]}) of walker positions from the same "
-        f"start ball, oracle/gp_oracle.py (numpy+scipy LAPACK, {threads} BLAS threads), {dt:.1f} s",
+        "host_cpu_count": os.cpu_count(),
+        "runs": runs,
+        "sample": f"sequential LML evaluations (n={len(y)}, d={X.shape[1]}) of walker positions from the same start "
+        f"ball with oracle/gp_oracle.py (numpy + scipy LAPACK): {runs['1_thread']['evals']} at 1 BLAS thread, "
+        f"{runs['all_cores']['evals']} at {all_threads}; median time per evaluation; value = the faster setting",
     }
 
 
-def cpu_baseline_sklearn(X, y, thetas, budget_s=10.0):
-    """The call the reference itself makes per walker (bask/bayesgpr.py:374): scikit-learn's
-    GaussianProcessRegressor.log_marginal_likelihood(theta) -- third-party code present in the image on both
-    sides, timed on the same bounded sample next to the oracle restatement (they agree to 1e-12)."""
+def _sklearn_gpr(X, y):
     from sklearn.gaussian_process import GaussianProcessRegressor
     from sklearn.gaussian_process.kernels import ConstantKernel, Matern, WhiteKernel
 
     d = X.shape[1]
     k = ConstantKernel(1.0, (0.1, 2.0)) * Matern(length_scale=[0.3] * d, length_scale_bounds=(0.2, 0.5), nu=2.5) \
         + WhiteKernel(0.01)
-    gpr = GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
-    vals = [gpr.log_marginal_likelihood(thetas[0])]  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    for th in thetas:
+    return GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
+
+
+def cpu_baseline_sklearn(X, y, thetas, budget_s=6.0):
+    """The call the reference itself makes per walker (bask/bayesgpr.py:374): scikit-learn's
+    GaussianProcessRegressor.log_marginal_likelihood(theta) -- third-party code present in the image on both
+    sides, timed on the same bounded sample next to the oracle restatement (they agree to 1e-12)."""
+    from threadpoolctl import threadpool_limits
+
+    gpr = _sklearn_gpr(X, y)
+    vals = []
+
+    def f(th):
         vals.append(gpr.log_marginal_likelihood(th))
-        done += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
+
+    runs = {}
+    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+        del vals[:]
+        with threadpool_limits(limits=nthreads):
+            t = _timed_evals(f, thetas, budget_s)
+        runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                       "evals_per_s": float(1.0 / np.median(t))}
+    best = max(runs, key=lambda k: runs[k]["evals_per_s"])
+    return {"value": runs[best]["evals_per_s"], "unit": "LML-evals/s", "cores": runs[best]["threads"],
+            "kind": "sklearn 1.7 GaussianProcessRegressor.log_marginal_likelihood", "runs": runs}, vals[1:]
+
+
+def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget_walkers=36, budget_steps=2):
+    """TIMED host run of the reference's sampling loop at this size: the package's host ensemble sampler (emcee's
+    stretch move, one proposal block per half-step) driving scikit-learn's log_marginal_likelihood one walker at a
+    time -- what BayesGPR.sample does on the CPU (bask/bayesgpr.py:510-530, :351-379).  Bounded: `budget_walkers`
+    walkers (the smallest ensemble emcee accepts, 2p) x `budget_steps` steps; the full-size figure is that time per
+    evaluation x the evaluations of the full run, stated as an extrapolation."""
+    from bayes_skopt_amd.sampler import EnsembleSampler
+
+    gpr = _sklearn_gpr(X, y)
+    n_eval = [0]
+
+    def log_prob(Theta, priors=None):
+        out = np.empty(len(Theta))
+        for i, th in enumerate(Theta):
+            lp = sum(float(pr(t)) for pr, t in zip(priors, th))
+            out[i] = lp + gpr.log_marginal_likelihood(th) if np.isfinite(lp) else -np.inf
+            n_eval[0] += 1
+        return out
+
+    p = len(theta0)
+    W = max(budget_walkers, 2 * p)
+    rng = np.random.RandomState(0)
+    pos = theta0 + 1e-2 * rng.randn(W, p)
+    smp = EnsembleSampler(W, p, log_prob, kwargs=dict(priors=priors))
+    smp.random_state = np.random.RandomState(1).get_state()
+    t0 = time.perf_counter()
+    smp.run_mcmc(pos, budget_steps)
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "LML-evals/s", "kind": "sklearn 1.7 GaussianProcessRegressor.log_marginal_likelihood",
-            "sample": f"{done} sequential evaluations, {dt:.1f} s"}, vals[1:]
+    evals_full = n_walkers_full * (steps_full + 1)
+    return {
+        "timed_ms": dt * 1e3,
+        "timed_evals": int(n_eval[0]),
+        "timed_config": f"{W} walkers x {budget_steps} steps (+ initial ensemble), sklearn log_marginal_likelihood per "
+        f"walker, {_blas_threads()} BLAS threads",
+        "ms_per_eval": dt * 1e3 / max(n_eval[0], 1),
+        "extrapolated_full_ms": dt * 1e3 / max(n_eval[0], 1) * evals_full,
+        "extrapolated_full_evals": int(evals_full),
+        "extrapolation": f"timed ms per evaluation x {evals_full} evaluations = {n_walkers_full} walkers x "
+        f"({steps_full} steps + initial ensemble); the MAP start of fit() (a few dozen more evaluations with gradients) "
+        "is not included",
+    }
+
+
+def config_d_roofline(bask_lib, device, peak_tflops):
+    """BASELINE config D (n=4096, d=32, blocked fp64 Cholesky, MFMA trailing update): B = 8 matrices per batch, every
+    launch on one stream with HIP events around it (as for the config C roofline).  Reports the trailing update's
+    algorithmic TFLOP/s against the fp64 MFMA peak -- the north star's ">= 40 % at n = 4096" target."""
+    n, d, B = 4096, 32, 8
+    X, y = synth(n, d, seed=0)
+    ctx = bask_lib.Context(X, y, 1e-10, max_batch=B, device=device)
+    H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.05 * np.random.RandomState(3).randn(B, d + 2)
+    ctx.set_streams(1)
+    ctx.lml(H)  # warm-up
+    ctx.set_timing(True)
+    reps, syrk_ms, launches, total_ms = 5, 0.0, 0, 0.0
+    for _ in range(reps):
+        lml = ctx.lml(H)
+        tm = ctx.last_timing()
+        syrk_ms += tm["syrk"]["ms"]
+        launches += tm["syrk"]["launches"]
+        total_ms += tm["device_total_ms"]
+    ctx.set_timing(False)
+    t0 = time.perf_counter()
+    ctx.lml(H[:1])
+    b1_ms = (time.perf_counter() - t0) * 1e3
+    ctx.close()
+    flops = float(sum(trailing_flops_per_launch(n))) * B * reps
+    achieved = flops / (syrk_ms * 1e-3) / 1e12
+    return {
+        "workload": f"n={n}, d={d}, {B} matrices per batch (BASELINE config D)",
+        "kernel": "syrk4_kernel<64> (trailing update, two-panel K=256)",
+        "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved / peak_tflops,
+        "avg_launch_ms": syrk_ms / max(launches, 1), "launches_per_factorisation": launches // reps,
+        "ms_per_batch_of_8": total_ms / reps, "ms_single_matrix_wall": b1_ms,
+        "algorithmic_flops_per_factorisation": float(sum(trailing_flops_per_launch(n))),
+        "lml_finite": bool(np.all(np.isfinite(lml))),
+    }
 
 
 def main():
@@ -108,6 +220,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the config C hot path (no fit(), no config D, no CPU baselines): what the rocprofv3 "
+                    "passes of tools/profile_round.sh run, so that their per-kernel numbers are config C's alone")
     ap.add_argument("--shard", choices=("chains", "ensemble"), default="chains",
                     help="chains (default): independent 256-walker sub-ensemble per GPU, weak scaling, no collective in "
                     "the loop; ensemble: ONE 256-walker ensemble, each half-step's 128 proposals split over the GPUs + "
@@ -119,8 +234,10 @@ def main():
     from bayes_skopt_amd.kernels import WhiteKernel
 
     rank, local_rank, ws = distributed.init_process_group()
-    if ws != args.gpus and ws > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}")
+    if ws != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch one rank per GPU with\n  python -m "
+                         f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     ndev = _lib.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
@@ -212,24 +329,34 @@ def main():
     achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
     traffic = None
     try:  # HBM bytes per launch from the committed PMC passes (cannot be collected without rocprofv3)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["traffic_bytes_per_launch"]
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["traffic_bytes_per_launch"]
     except Exception:
         pass
+    # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated
+    try:
+        mfma_measured = float(_lib.bench_mfma_f64(device))
+    except Exception:
+        mfma_measured = None
+    peak = min(FP64_MFMA_PEAK_TFLOPS, mfma_measured) if mfma_measured else FP64_MFMA_PEAK_TFLOPS
     roofline = {
         "bound": "mfma",
-        "kernel": "syrk2_kernel (blocked-Cholesky trailing update, two-panel K=256, fp64 v_mfma_f64_16x16x4_f64)",
+        "kernel": "syrk4_kernel<64> (blocked-Cholesky trailing update, two-panel K=256, LDS-DMA ring, fp64 "
+        "v_mfma_f64_16x16x4_f64)",
         "achieved": achieved,
-        "peak": FP64_MFMA_PEAK_TFLOPS,
+        "peak": peak,
+        "peak_spec": FP64_MFMA_PEAK_TFLOPS,
+        "mfma_peak_measured": mfma_measured,
         "unit": "TFLOP/s",
-        "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+        "frac": achieved / peak,
         "traffic": traffic,
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
         "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
         "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
-        "peak = datasheet fp64 matrix peak (MI355X_MICROARCH.md has no fp64 row); traffic = bytes per launch "
-        "from profiles/r01_pmc_traffic.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+        "peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
+        "MI355X_MICROARCH.md has no fp64 row; traffic = bytes per launch from profiles/r02_pmc_traffic.json "
+        "(rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)",
     }
 
     evals = W * args.steps * (1 if ensemble else ws)
@@ -265,7 +392,9 @@ def main():
         "gathered_chain_rows": int(chain_all.shape[0]),
         "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
     }
-    if rank == 0 and ws == 1:
+    if args.no_extras:
+        args.no_cpu_baseline = True
+    if rank == 0 and ws == 1 and not args.no_extras:
         # the other half of BASELINE.json's metric: wall clock of a whole BayesGPR.fit() (MAP start by L-BFGS-B on
         # the device LML + gradient, then 256 walkers x 25 steps after 5 burn-in steps) at the same size
         gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device)
@@ -273,11 +402,22 @@ def main():
         gp2.fit(X, y, n_desired_samples=W * 25, n_burnin=5, n_walkers_per_thread=W, progress=False)
         line["fit_plus_sample_ms"] = (time.perf_counter() - tf0) * 1e3
         line["fit_plus_sample_evals"] = int(gp2._sampler.n_log_prob_evals)
+        line["fit_plus_sample_config"] = f"BayesGPR.fit: MAP start (L-BFGS-B on the device LML + gradient) + {W} walkers x 30 steps"
         del gp2
+        line["roofline_n4096"] = config_d_roofline(_lib, device, peak)
     if rank == 0:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
             line["speedup_vs_cpu_baseline"] = value / (1 if ensemble else ws) / line["cpu_baseline"]["value"]
+            if ws == 1:
+                try:  # the CPU side of BASELINE.json's fit+sample metric, timed (bounded) instead of estimated
+                    cf = cpu_fit_plus_sample(X, y, priors, theta0, W, 30)
+                    line["cpu_fit_plus_sample_ms"] = cf["extrapolated_full_ms"]
+                    line["cpu_fit_plus_sample"] = cf
+                    if "fit_plus_sample_ms" in line:
+                        line["fit_plus_sample_speedup_vs_cpu"] = cf["extrapolated_full_ms"] / line["fit_plus_sample_ms"]
+                except Exception as exc:
+                    line["cpu_fit_plus_sample"] = {"error": repr(exc)}
             try:  # the reference's own per-walker call, and a live parity check of the device path against it
                 sk, sk_vals = cpu_baseline_sklearn(X, y, pos[:32])
                 dev_vals = gp._ctx.lml(gp._canonical(pos[: len(sk_vals)]))

@@ -40,9 +40,22 @@ def test_bench_single_gpu_line():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak_spec"] == 78.6
+    # peak = min(datasheet, measured on the box), both stated
+    assert r["peak"] == min(r["peak_spec"], r["mfma_peak_measured"]) and 60.0 < r["mfma_peak_measured"] < 90.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
     assert "workload" in d["config"] and "model" not in d["config"]
+    n4 = d["roofline_n4096"]  # the north star's own target: >= 40 % of fp64 peak on the trailing update at n = 4096
+    assert n4["lml_finite"] and n4["peak"] == r["peak"] and 0.4 < n4["frac"] < 1.0
+    assert d["fit_plus_sample_ms"] > 0 and d["fit_plus_sample_evals"] == 256 * 31
+
+
+def test_bench_refuses_multi_gpu_without_launcher():
+    """--gpus N without torch.distributed.run (WORLD_SIZE unset) must not silently run on one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
 
 
 @pytest.mark.parametrize("shard", ["chains", "ensemble"])
