@@ -56,6 +56,13 @@ SIGNATURES = {
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
     "bgp_sample_y_batch": (C.c_int, [_vp, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_double, _dp, _ip]),
+    "bgp_comm_unique_id": (C.c_int, [_vp]),
+    "bgp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "bgp_comm_destroy": (None, [_vp]),
+    "bgp_comm_allgather": (C.c_int, [_vp, _dp, C.c_size_t, _dp]),
+    "bgp_comm_allreduce_max": (C.c_int, [_vp, _dp, C.c_size_t]),
+    "bgp_comm_broadcast": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
+    "bgp_comm_barrier": (C.c_int, [_vp]),
     "bgp_device_synchronize": (C.c_int, [C.c_int]),
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
@@ -298,6 +305,58 @@ class Context:
         out = {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(names)}
         out["device_total_ms"] = float(ms[4])
         return out
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through libbgp (rank 0): 128 opaque bytes every rank needs for ``Comm``."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(load().bgp_comm_unique_id(C.cast(buf, _vp)), "bgp_comm_unique_id")
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of this process (one process per GPU) behind the C-ABI: host arrays in, host arrays out."""
+
+    def __init__(self, device, rank, world, unique_id):
+        self._lib = load()
+        self.rank, self.world = int(rank), int(world)
+        h = _vp()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _check(self._lib.bgp_comm_init(int(device), self.rank, self.world, C.cast(buf, _vp), C.byref(h)), "bgp_comm_init")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bgp_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather(self, a):
+        a = _c(a)
+        out = np.empty((self.world,) + a.shape)
+        _check(self._lib.bgp_comm_allgather(self._h, _p(a), a.size, _p(out)), "bgp_comm_allgather")
+        return out
+
+    def allreduce_max(self, a):
+        a = _c(np.array(a, dtype=np.float64, copy=True))
+        _check(self._lib.bgp_comm_allreduce_max(self._h, _p(a), a.size), "bgp_comm_allreduce_max")
+        return a
+
+    def broadcast(self, a, root=0):
+        a = _c(np.array(a, dtype=np.float64, copy=True))
+        _check(self._lib.bgp_comm_broadcast(self._h, _p(a), a.size, int(root)), "bgp_comm_broadcast")
+        return a
+
+    def barrier(self):
+        _check(self._lib.bgp_comm_barrier(self._h), "bgp_comm_barrier")
 
 
 def device_synchronize(device=0):

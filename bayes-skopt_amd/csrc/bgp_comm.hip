@@ -1,0 +1,203 @@
+// RCCL behind the C-ABI: the one real exchange of the multi-GPU path -- the final all-gather of the
+// posterior samples (and, in the exact single-ensemble mode, the B log-probabilities per half-step) -- without any
+// PyTorch in the product path.  One communicator per process (one process per GPU), collectives on the
+// communicator's own HIP stream over device-resident staging buffers that are grown on demand and reused.
+// librccl is loaded lazily with dlopen: libbgp.so has no link-time dependency on it and single-GPU use never
+// touches it.  The rendezvous (rank 0's ncclUniqueId to every rank) is the caller's: bayes-skopt_amd/distributed.py
+// ships the 128 bytes over a TCP socket on MASTER_ADDR:MASTER_PORT.
+#include "bgp_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int load_rccl() {
+  if (g_rccl.handle) return BGP_OK;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) {
+    bgp_set_error("bgp_comm: cannot load librccl.so (%s)", dlerror());
+    return BGP_ERR_STATE;
+  }
+#define BGP_SYM(field, name)                                          \
+  g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+  if (!g_rccl.field) {                                                \
+    bgp_set_error("bgp_comm: librccl.so lacks %s", name);             \
+    dlclose(h);                                                       \
+    return BGP_ERR_STATE;                                             \
+  }
+  BGP_SYM(GetUniqueId, "ncclGetUniqueId")
+  BGP_SYM(CommInitRank, "ncclCommInitRank")
+  BGP_SYM(CommDestroy, "ncclCommDestroy")
+  BGP_SYM(AllGather, "ncclAllGather")
+  BGP_SYM(AllReduce, "ncclAllReduce")
+  BGP_SYM(Broadcast, "ncclBroadcast")
+  BGP_SYM(GetErrorString, "ncclGetErrorString")
+#undef BGP_SYM
+  g_rccl.handle = h;
+  return BGP_OK;
+}
+}  // namespace
+
+struct bgp_comm {
+  int device = 0, rank = 0, world = 1;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  double* dsend = nullptr;  // device-resident staging, grown on demand
+  double* drecv = nullptr;
+  size_t cap_send = 0, cap_recv = 0;
+};
+
+#define BGP_NCCL(call)                                                                          \
+  do {                                                                                          \
+    ncclResult_t r__ = (call);                                                                  \
+    if (r__ != ncclSuccess) {                                                                   \
+      bgp_set_error("%s failed: %s (%s:%d)", #call, g_rccl.GetErrorString(r__), __FILE__, __LINE__); \
+      return BGP_ERR_HIP;                                                                       \
+    }                                                                                           \
+  } while (0)
+
+static int comm_reserve(bgp_comm* c, size_t nsend, size_t nrecv) {
+  if (nsend > c->cap_send) {
+    if (c->dsend) (void)hipFree(c->dsend);
+    c->dsend = nullptr;
+    c->cap_send = 0;
+    BGP_HIP(hipMalloc(&c->dsend, nsend * sizeof(double)));
+    c->cap_send = nsend;
+  }
+  if (nrecv > c->cap_recv) {
+    if (c->drecv) (void)hipFree(c->drecv);
+    c->drecv = nullptr;
+    c->cap_recv = 0;
+    BGP_HIP(hipMalloc(&c->drecv, nrecv * sizeof(double)));
+    c->cap_recv = nrecv;
+  }
+  return BGP_OK;
+}
+
+extern "C" int bgp_comm_unique_id(void* id128) {
+  if (!id128) {
+    bgp_set_error("bgp_comm_unique_id: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  int rc = load_rccl();
+  if (rc) return rc;
+  ncclUniqueId id;
+  BGP_NCCL(g_rccl.GetUniqueId(&id));
+  static_assert(sizeof(id) == BGP_COMM_ID_BYTES, "ncclUniqueId size");
+  memcpy(id128, &id, sizeof(id));
+  return BGP_OK;
+}
+
+extern "C" int bgp_comm_init(int device, int rank, int world, const void* id128, bgp_comm** out) {
+  if (!out || !id128 || world < 1 || rank < 0 || rank >= world) {
+    bgp_set_error("bgp_comm_init: bad argument (rank %d of %d)", rank, world);
+    return BGP_ERR_INVALID;
+  }
+  *out = nullptr;
+  int rc = load_rccl();
+  if (rc) return rc;
+  int ndev = bgp_device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev) {
+    bgp_set_error("bgp_comm_init: no usable HIP device (count=%d, requested=%d)", ndev, device);
+    return BGP_ERR_NODEVICE;
+  }
+  BGP_HIP(hipSetDevice(device));
+  bgp_comm* c = new bgp_comm();
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    bgp_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
+    delete c;
+    return BGP_ERR_HIP;
+  }
+  if (hipStreamCreate(&c->stream) != hipSuccess) {
+    bgp_set_error("bgp_comm_init: hipStreamCreate failed");
+    (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+    return BGP_ERR_HIP;
+  }
+  *out = c;
+  return BGP_OK;
+}
+
+extern "C" void bgp_comm_destroy(bgp_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+  if (c->dsend) (void)hipFree(c->dsend);
+  if (c->drecv) (void)hipFree(c->drecv);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count, double* recv) {
+  if (!c || !send || !recv) {
+    bgp_set_error("bgp_comm_allgather: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  if (count == 0) return BGP_OK;
+  BGP_HIP(hipSetDevice(c->device));
+  int rc = comm_reserve(c, count, count * c->world);
+  if (rc) return rc;
+  BGP_HIP(hipMemcpyAsync(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, count, ncclFloat64, c->comm, c->stream));
+  BGP_HIP(hipMemcpyAsync(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
+}
+
+extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) {
+  if (!c || !inout) {
+    bgp_set_error("bgp_comm_allreduce_max: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  if (count == 0) return BGP_OK;
+  BGP_HIP(hipSetDevice(c->device));
+  int rc = comm_reserve(c, count, count);
+  if (rc) return rc;
+  BGP_HIP(hipMemcpyAsync(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_NCCL(g_rccl.AllReduce(c->dsend, c->drecv, count, ncclFloat64, ncclMax, c->comm, c->stream));
+  BGP_HIP(hipMemcpyAsync(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
+}
+
+extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int root) {
+  if (!c || !buf || root < 0 || root >= c->world) {
+    bgp_set_error("bgp_comm_broadcast: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (count == 0) return BGP_OK;
+  BGP_HIP(hipSetDevice(c->device));
+  int rc = comm_reserve(c, count, count);
+  if (rc) return rc;
+  BGP_HIP(hipMemcpyAsync(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_NCCL(g_rccl.Broadcast(c->dsend, c->drecv, count, ncclFloat64, root, c->comm, c->stream));
+  BGP_HIP(hipMemcpyAsync(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
+}
+
+extern "C" int bgp_comm_barrier(bgp_comm* c) {
+  double one = 1.0;
+  return bgp_comm_allreduce_max(c, &one, 1);
+}

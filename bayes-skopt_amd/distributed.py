@@ -1,9 +1,10 @@
-"""Multi-GPU sharding of the MCMC chains: one process per GPU (``torch.distributed.run``).
+"""Multi-GPU sharding of the MCMC chains: one process per GPU (launched by ``torch.distributed.run`` or any other
+launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
 
 Default (SURVEY.md 8(e) option 2 / BASELINE.json north_star: "chains shard naturally ... RCCL over xGMI
 only for the final posterior-sample gather"): each rank runs an independent sub-ensemble on its own
 device with NO collective in the sampling loop; the only exchange is the final gather of the posterior
-samples (``gather_chains``: RCCL all-gather over xGMI on GPUs, gloo in the CPU tests).
+samples (``gather_chains``).
 
 Option (SURVEY.md 8(e) option 1, exact single-ensemble semantics): every rank holds the same data and
 the same sampler RNG, so all ranks propose the same (B, p) block each half-step; ``shard_log_prob``
@@ -11,63 +12,152 @@ makes rank r evaluate rows [r*B/G, (r+1)*B/G) on its device and all-gathers the 
 (one latency-bound collective of B doubles per half-step).  Accept/reject then runs identically on
 every rank and the chain equals the single-GPU chain bit for bit.
 
-torch is used here for process-group plumbing only (rendezvous, RCCL); nothing in the numerical path
-touches it.
+Backends (``BGP_DIST_BACKEND`` or the ``backend`` argument):
+  ``rccl``  (default when this process sees a GPU) -- RCCL through libbgp's own C-ABI (``bgp_comm_*``,
+            csrc/bgp_comm.hip): no PyTorch anywhere in the product path.  Rank 0 creates the ncclUniqueId and
+            hands its 128 bytes to the other ranks over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1)
+            (``BGP_COMM_PORT`` overrides; MASTER_PORT itself belongs to the launcher's rendezvous store).
+  ``gloo`` / ``nccl`` -- ``torch.distributed`` process groups: the CPU tests (world size 2 over gloo) and an A/B
+            path for the native one; torch is only imported when one of these is selected.
+``BGP_DIST_FORCE=1`` joins a group even at world size 1 (the GPU test that runs real RCCL collectives on one GPU).
 """
 import os
+import socket
+import time
 
 import numpy as np
 
-__all__ = ["world", "init_process_group", "gather_chains", "barrier", "max_over_ranks", "rank_seed", "shard_rows",
-           "shard_log_prob", "broadcast_array"]
+__all__ = ["world", "init_process_group", "destroy_process_group", "gather_chains", "barrier", "max_over_ranks",
+           "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend"]
+
+_state = {"backend": None, "comm": None, "rank": 0, "world": 1}
 
 
 def world():
-    """(rank, local_rank, world_size) from the torchrun environment (1 process when absent)."""
+    """(rank, local_rank, world_size) from the launcher's environment (1 process when absent)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def _dist():
+def backend():
+    """Name of the active backend ("rccl", "gloo", "nccl") or None outside a group."""
+    return _state["backend"]
+
+
+def _torch_dist():
     import torch.distributed as dist
 
     return dist
 
 
-def init_process_group(backend=None):
-    """Join the process group when launched with WORLD_SIZE > 1 (backend "nccl" == RCCL on ROCm;
-    "gloo" for CPU tests).  Returns (rank, local_rank, world_size)."""
+# ---------------------------------------------------------------------------------------------------------
+# rendezvous of the ncclUniqueId for the native backend
+# ---------------------------------------------------------------------------------------------------------
+def _comm_endpoint():
+    host = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("BGP_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 1))
+    return host, port
+
+
+def _exchange_unique_id(rank, ws, timeout=120.0):
+    from . import _lib
+
+    if rank == 0:
+        uid = _lib.comm_unique_id()
+        if ws == 1:
+            return uid
+        host, port = _comm_endpoint()
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((host, port))
+        srv.listen(ws)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(ws - 1):
+                conn, _addr = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        finally:
+            srv.close()
+        return uid
+    host, port = _comm_endpoint()
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with socket.create_connection((host, port), timeout=5.0) as s:
+                buf = b""
+                while len(buf) < _lib.COMM_ID_BYTES:
+                    part = s.recv(_lib.COMM_ID_BYTES - len(buf))
+                    if not part:
+                        raise ConnectionError("rank 0 closed the id socket early")
+                    buf += part
+                return buf
+        except (ConnectionRefusedError, ConnectionError, socket.timeout, OSError):
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"rank {rank}: no ncclUniqueId from rank 0 at {host}:{port} within {timeout:.0f} s")
+            time.sleep(0.05)
+
+
+def init_process_group(backend=None, device=None):
+    """Join the process group when launched with WORLD_SIZE > 1 (or BGP_DIST_FORCE=1).  Returns
+    (rank, local_rank, world_size)."""
     rank, local_rank, ws = world()
-    if ws > 1:
+    if _state["backend"] is not None or (ws <= 1 and os.environ.get("BGP_DIST_FORCE") != "1"):
+        return rank, local_rank, ws
+    from . import _lib
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = _lib.device_count()
+    name = backend or os.environ.get("BGP_DIST_BACKEND") or ("rccl" if ndev > 0 else "gloo")
+    if name == "rccl":
+        if ndev < 1:
+            raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")
+        dev = (local_rank % ndev) if device is None else int(device)
+        uid = _exchange_unique_id(rank, ws)
+        _state["comm"] = _lib.Comm(dev, rank, ws, uid)
+    else:
         import torch
 
-        dist = _dist()
+        dist = _torch_dist()
         if not dist.is_initialized():
-            if backend is None:
-                backend = os.environ.get("BGP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            if backend == "nccl":
+            if name == "nccl":
                 torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-            dist.init_process_group(backend=backend, rank=rank, world_size=ws)
+            dist.init_process_group(backend=name, rank=rank, world_size=ws)
+    _state.update(backend=name, rank=rank, world=ws)
     return rank, local_rank, ws
 
 
-def _is_dist():
-    try:
-        dist = _dist()
-    except Exception:
-        return False
-    return dist.is_available() and dist.is_initialized()
+def destroy_process_group():
+    if _state["backend"] == "rccl":
+        _state["comm"].close()
+    elif _state["backend"] is not None:
+        dist = _torch_dist()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    _state.update(backend=None, comm=None, rank=0, world=1)
 
 
-def _device_for_backend():
+def _torch_device():
     import torch
 
-    dist = _dist()
-    if dist.get_backend() == "nccl":
+    if _state["backend"] == "nccl":
         return torch.device("cuda", torch.cuda.current_device())
     return torch.device("cpu")
+
+
+def _allgather(a):
+    """(world,) + a.shape, rank-major, on every rank."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if _state["backend"] == "rccl":
+        return _state["comm"].allgather(a)
+    import torch
+
+    dist = _torch_dist()
+    t = torch.from_numpy(a.copy()).to(_torch_device())
+    out = [torch.empty_like(t) for _ in range(_state["world"])]
+    dist.all_gather(out, t)
+    return torch.stack(out, dim=0).cpu().numpy()
 
 
 def rank_seed(seed, rank):
@@ -78,32 +168,28 @@ def rank_seed(seed, rank):
 def gather_chains(chain):
     """All-gather equally shaped per-rank chains (S, p) -> (world*S, p), rank-major, on every rank."""
     chain = np.ascontiguousarray(chain, dtype=np.float64)
-    if not _is_dist():
+    if _state["backend"] is None:
         return chain
-    import torch
-
-    dist = _dist()
-    ws = dist.get_world_size()
-    dev = _device_for_backend()
-    t = torch.from_numpy(chain).to(dev)
-    out = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(out, t)
-    return torch.cat(out, dim=0).cpu().numpy()
+    return _allgather(chain).reshape((-1,) + chain.shape[1:])
 
 
 def barrier():
-    if _is_dist():
-        _dist().barrier()
+    if _state["backend"] == "rccl":
+        _state["comm"].barrier()
+    elif _state["backend"] is not None:
+        _torch_dist().barrier()
 
 
 def max_over_ranks(value):
     """MAX all-reduce of a python float (timing)."""
-    if not _is_dist():
+    if _state["backend"] is None:
         return float(value)
+    if _state["backend"] == "rccl":
+        return float(_state["comm"].allreduce_max([float(value)])[0])
     import torch
 
-    dist = _dist()
-    t = torch.tensor([float(value)], dtype=torch.float64, device=_device_for_backend())
+    dist = _torch_dist()
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_torch_device())
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -121,27 +207,19 @@ def shard_log_prob(fn):
 
     def wrapped(Theta, *args, **kwargs):
         Theta = np.atleast_2d(np.asarray(Theta, dtype=np.float64))
-        if not _is_dist():
+        if _state["backend"] is None:
             return fn(Theta, *args, **kwargs)
-        import torch
-
-        dist = _dist()
-        ws, rank = dist.get_world_size(), dist.get_rank()
+        ws, rank = _state["world"], _state["rank"]
         B = Theta.shape[0]
         lo, hi = shard_rows(B, rank, ws)
-        chunk = -(-B // ws)
-        local = np.zeros(chunk)
+        local = np.zeros(-(-B // ws))
         if hi > lo:
             local[: hi - lo] = fn(Theta[lo:hi], *args, **kwargs)
-        dev = _device_for_backend()
-        t = torch.from_numpy(local).to(dev)
-        out = [torch.empty_like(t) for _ in range(ws)]
-        dist.all_gather(out, t)
+        parts = _allgather(local)
         full = np.empty(B)
         for r in range(ws):
             rlo, rhi = shard_rows(B, r, ws)
-            if rhi > rlo:
-                full[rlo:rhi] = out[r][: rhi - rlo].cpu().numpy()
+            full[rlo:rhi] = parts[r][: rhi - rlo]
         return full
 
     return wrapped
@@ -151,10 +229,12 @@ def broadcast_array(arr, src=0):
     """Broadcast a float64 array from rank `src` (identity outside a process group).  Used to pin the
     start ensemble of the sharded sampler to one rank's copy."""
     arr = np.ascontiguousarray(arr, dtype=np.float64)
-    if not _is_dist():
+    if _state["backend"] is None:
         return arr
+    if _state["backend"] == "rccl":
+        return _state["comm"].broadcast(arr, root=src).reshape(arr.shape)
     import torch
 
-    t = torch.from_numpy(arr.copy()).to(_device_for_backend())
-    _dist().broadcast(t, src=src)
+    t = torch.from_numpy(arr.copy()).to(_torch_device())
+    _torch_dist().broadcast(t, src=src)
     return t.cpu().numpy()

@@ -14,7 +14,8 @@ Inputs (X, y, walker positions) are resident / tiny; only (128, 18) doubles of p
 
 N > 1: one process per GPU, each rank an independent 256-walker sub-ensemble on its own device
 (weak scaling, no collective in the sampling loop); the posterior samples are all-gathered over
-RCCL at the end (outside the timed region, reported as `gather_ms`).
+RCCL at the end (outside the timed region, reported as `gather_ms`) through libbgp's own communicator
+(bgp_comm_*, no PyTorch in the path; `dist_backend` in the JSON line names what ran).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -233,14 +234,14 @@ def main():
     from bayes_skopt_amd import _lib, distributed
     from bayes_skopt_amd.kernels import WhiteKernel
 
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     rank, local_rank, ws = distributed.init_process_group()
     if ws != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch one rank per GPU with\n  python -m "
                          f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                          f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     device = local_rank % ndev
 
     n, d, W = N_POINTS, N_DIMS, N_WALKERS
@@ -266,11 +267,6 @@ def main():
 
     def sync():
         _lib.device_synchronize(device)
-        if ws > 1:
-            import torch
-
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
 
     state = sampler.run_mcmc(pos, max(args.warmup, 1))  # also evaluates the initial ensemble
     pos, lp = state.coords, state.log_prob
@@ -389,6 +385,7 @@ def main():
         "device_ms_per_half_step": dev_total / max(n_calls, 1),
         "instrumented_ms_per_step": dt_instr / args.steps * 1e3,
         "gather_ms": gather_ms,
+        "dist_backend": distributed.backend(),
         "gathered_chain_rows": int(chain_all.shape[0]),
         "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
     }
@@ -427,10 +424,8 @@ def main():
                 line["cpu_baseline_sklearn"] = {"error": repr(exc)}
         print(json.dumps(line))
     if ws > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
-        dist.destroy_process_group()
+        distributed.barrier()
+        distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

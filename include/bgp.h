@@ -27,6 +27,8 @@
 #ifndef BGP_H
 #define BGP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -201,6 +203,26 @@ int bgp_bench_mfma_f64(int device, int iters, double* tflops);
 int bgp_bench_hbm_copy(int device, long long bytes, int iters, double* gbps);
 /* Empirical C/D fragment layout of v_mfma_f64_16x16x4_f64: rows[64*4], cols[64*4] (lane*4+reg). */
 int bgp_mfma_f64_layout(int device, int* rows, int* cols);
+
+/*
+ * Multi-GPU exchange over RCCL (one process per GPU).  The hot path shards by chains: no collective in
+ * the sampling loop, ONE all-gather of the posterior samples at the end (bgp_comm_allgather; in the exact
+ * single-ensemble option also the B log-probabilities of each half-step).  Host buffers in, host buffers out; the
+ * staging buffers stay resident on the device.  bgp_comm_unique_id is called on rank 0 and its BGP_COMM_ID_BYTES bytes
+ * are handed to every rank by the caller (bayes-skopt_amd/distributed.py: a TCP socket on MASTER_ADDR:MASTER_PORT).
+ * Replaces: nothing in the reference (it is single-process); mirrors what torch.distributed's all_gather /
+ * all_reduce(MAX) / broadcast would do, without PyTorch in the product path.
+ */
+#define BGP_COMM_ID_BYTES 128
+typedef struct bgp_comm bgp_comm;
+int bgp_comm_unique_id(void* id128);
+int bgp_comm_init(int device, int rank, int world, const void* id128, bgp_comm** out);
+void bgp_comm_destroy(bgp_comm* comm);
+/* recv (world * count doubles) = concatenation of every rank's send (count doubles), rank-major */
+int bgp_comm_allgather(bgp_comm* comm, const double* send, size_t count, double* recv);
+int bgp_comm_allreduce_max(bgp_comm* comm, double* inout, size_t count);
+int bgp_comm_broadcast(bgp_comm* comm, double* buf, size_t count, int root);
+int bgp_comm_barrier(bgp_comm* comm);
 
 #ifdef __cplusplus
 }

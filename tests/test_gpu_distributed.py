@@ -46,3 +46,53 @@ def test_two_rank_sharded_fit_equals_single_process(tmp_path):
     np.testing.assert_array_equal(c0, gp.chain_)   # in the worker and in this process (reproducible device path)
     r0 = json.load(open(tmp_path / "shard0.json"))
     assert np.isclose(r0["lp_sum"], gp.log_marginal_likelihood_value_, rtol=1e-12)
+
+
+_RCCL_WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import bayes_skopt_amd as bask
+from bayes_skopt_amd import distributed
+rank, local_rank, ws = distributed.init_process_group()
+assert distributed.backend() == "rccl" and "torch" not in sys.modules, (distributed.backend(), "torch" in sys.modules)
+chain = np.arange(12.0).reshape(6, 2) + 100.0 * rank
+allc = distributed.gather_chains(chain)
+tmax = distributed.max_over_ranks(3.25 + rank)
+b = distributed.broadcast_array(np.array([1.5, -2.0, 7.0]))
+lp = distributed.shard_log_prob(lambda T: T.sum(axis=1))(np.arange(10.0).reshape(5, 2))
+distributed.barrier()
+big = distributed.gather_chains(np.random.RandomState(1).randn(5120, 18))   # the bench's final gather, again (buffers reused)
+distributed.destroy_process_group()
+print(json.dumps({"ws": ws, "allc": allc.tolist(), "tmax": tmax, "b": b.tolist(), "lp": lp.tolist(),
+                  "big": [big.shape[0], float(big.sum())], "torch": "torch" in sys.modules}))
+"""
+
+
+def test_native_rccl_collectives_world_size_one():
+    """The multi-GPU exchange goes through libbgp's own RCCL communicator (bgp_comm_*, no PyTorch).  The GPU box
+    has one device, so this is a one-rank group (BGP_DIST_FORCE=1): ncclCommInitRank + all-gather / all-reduce(MAX) /
+    broadcast really execute on the MI355X before the driver's 8-GPU run does."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), BGP_DIST_FORCE="1",
+               BGP_DIST_BACKEND="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, "-c", _RCCL_WORKER % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["ws"] == 1 and d["torch"] is False
+    np.testing.assert_array_equal(np.array(d["allc"]), np.arange(12.0).reshape(6, 2))
+    assert d["tmax"] == 3.25 and d["b"] == [1.5, -2.0, 7.0] and d["lp"] == [1.0, 5.0, 9.0, 13.0, 17.0]
+    ref = np.random.RandomState(1).randn(5120, 18)
+    assert d["big"][0] == 5120 and abs(d["big"][1] - ref.sum()) < 1e-9
+
+
+def test_bench_line_through_native_rccl_group():
+    """bench.py under the launcher with the RCCL group forced at world size 1: barrier, max-over-ranks and the final
+    chain gather run through bgp_comm_*."""
+    env = dict(os.environ, BGP_DIST_FORCE="1", BGP_DIST_BACKEND="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--no-extras"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["dist_backend"] == "rccl" and d["n_gpus"] == 1 and d["gathered_chain_rows"] == 2 * 256
