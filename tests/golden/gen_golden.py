@@ -364,25 +364,11 @@ def gen_sizes_posterior(out):
     np.savez_compressed(os.path.join(out, "posterior_sizes.npz"), **rec)
 
 
-def gen_mvn(out):
-    """numpy legacy multivariate_normal (SVD path) used by sklearn sample_y
-    (sklearn:_gpr.py:522-526)."""
-    rec = {}
-    rng = np.random.RandomState(5)
-    A = rng.randn(12, 12)
-    cov = A @ A.T / 12 + 1e-8 * np.eye(12)
-    mean = rng.randn(12)
-    rec["mean"], rec["cov"] = mean, cov
-    rec["draws"] = np.random.RandomState(0).multivariate_normal(mean, cov, 7).T
-    np.savez_compressed(os.path.join(out, "mvn.npz"), **rec)
-
-
 if __name__ == "__main__":
     gen_lml_small(HERE)
     gen_lml_sizes(HERE)
     gen_grad(HERE)
     gen_predict(HERE)
     gen_reference_tier1(HERE)
-    gen_mvn(HERE)
     gen_sizes_posterior(HERE)
     print("done")

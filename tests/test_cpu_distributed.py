@@ -93,3 +93,25 @@ def test_single_process_helpers():
     np.testing.assert_array_equal(d.gather_chains(c), c)
     assert d.max_over_ranks(3.5) == 3.5
     assert d.rank_seed(0, 0) != d.rank_seed(0, 1)
+
+
+def test_unique_id_rendezvous_over_tcp(tmp_path):
+    """The native RCCL backend's rendezvous: rank 0 hands the 128-byte ncclUniqueId to the other ranks over a TCP
+    socket on MASTER_ADDR:(MASTER_PORT + 1).  (The id itself needs a GPU: patched to fixed bytes here; the real
+    ncclCommInitRank + collectives run in tests/test_gpu_distributed.py.)"""
+    code = (
+        "import os, sys; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib, distributed;"
+        "_lib.comm_unique_id = lambda: bytes(range(128));"
+        "r = int(os.environ['RANK']); ws = int(os.environ['WORLD_SIZE']);"
+        "uid = distributed._exchange_unique_id(r, ws, timeout=60.0);"
+        "open(os.path.join(%r, 'uid%%d.bin' %% r), 'wb').write(uid)"
+    ) % (ROOT, str(tmp_path))
+    port = _free_port()
+    procs = []
+    for r in (2, 0, 1):  # start order must not matter: clients retry until rank 0 listens
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="3")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    for r in range(3):
+        assert open(tmp_path / f"uid{r}.bin", "rb").read() == bytes(range(128))

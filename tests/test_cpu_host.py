@@ -330,3 +330,21 @@ def test_bayesgpr_is_an_sklearn_estimator_without_a_device():
     assert g2.normalize_y is False and g2.kernel.k2.length_scale == 0.5 and gp.kernel.k2.length_scale == 0.3
     for other in (pickle.loads(pickle.dumps(gp)), copy.deepcopy(gp)):
         assert other.get_params(deep=False).keys() == params.keys() and other._ctx is None
+
+
+def test_closed_form_acquisitions_match_the_reference_classes():
+    """The product's own acquisition classes (host numpy closed forms on (mu, std)) against the outputs of the
+    reference's ``bask.acquisition`` classes on the same inputs (``tests/golden/reference_tier1.npz``, generated by
+    importing the reference): EI (default and explicit optimum), LCB (default and alpha = 3), mean and TopTwoEI
+    (``bask/acquisition.py:154-216``)."""
+    from bayes_skopt_amd import acquisition as acq
+
+    g = load_golden("reference_tier1.npz")
+    mu, std = g["acq_mu"], g["acq_std"]
+    np.testing.assert_allclose(acq.ExpectedImprovement()(mu, std), g["acq_ei"], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(acq.ExpectedImprovement()(mu, std, y_opt=-0.3), g["acq_ei_yopt"], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(acq.LCB()(mu, std), g["acq_lcb"], rtol=1e-13)
+    np.testing.assert_allclose(acq.LCB()(mu, std, alpha=3.0), g["acq_lcb3"], rtol=1e-13)
+    np.testing.assert_allclose(acq.Expectation()(mu, std), g["acq_mean"], rtol=1e-13)
+    np.testing.assert_allclose(acq.TopTwoEI()(mu, std), g["acq_ttei"], rtol=1e-13, atol=1e-300)
+    np.testing.assert_array_equal(acq.LCB()(mu, std, alpha="inf"), std)

@@ -187,9 +187,11 @@ def test_tell_loop_pvrs_small(bask):
 
 
 # ---- post-hoc diagnostics (tests/test_optimizer.py:85-175 of the reference).  The reference pins its numbers to
-# two decimals through emcee's stream and numpy's SVD-based MVN draws; the function draws here come from a device
-# Cholesky factor (same distribution, different variates), so the same quantities are checked within their Monte
-# Carlo error (200 draws: +-0.03 on a probability of 0.86) instead of to two decimals.
+# two decimals through emcee's stream and numpy's SVD-based MVN draws (ONE realisation of 200 / 100 function draws);
+# the draws here come from a device Cholesky factor (same distribution, different variates).  The Monte-Carlo error
+# on this side is driven down -- 2000 draws for the probabilities, the mean over six seeds of the reference's own
+# coarse estimator settings for the gap -- and the results must sit within 0.03 of the reference's pins (what is left
+# is the error of the reference's single realisation).
 def _five_point_optimizer(bask, seed):
     opt = bask.Optimizer(dimensions=[(-2.0, 2.0)], n_initial_points=0, random_state=np.random.RandomState(seed))
     opt.tell([[-2.0], [-1.0], [0.0], [1.0], [2.0]], [2.0, 0.0, -2.0, 0.0, 2.0], gp_burnin=10)
@@ -206,10 +208,10 @@ def _five_point_optimizer(bask, seed):
 )
 def test_probability_of_optimality(bask, kw, expected):
     opt = _five_point_optimizer(bask, 0)
-    prob = opt.probability_of_optimality(threshold=kw["threshold"], n_random_starts=100,
+    prob = opt.probability_of_optimality(threshold=kw["threshold"], n_random_starts=100, n_gp_samples=2000,
                                          random_state=np.random.RandomState(0),
                                          normalized_scores=kw["normalized_scores"])
-    np.testing.assert_allclose(prob, expected, atol=0.08)
+    np.testing.assert_allclose(prob, expected, atol=0.03)
     assert np.all(np.asarray(prob) <= 1.0) and np.all(np.asarray(prob) >= 0.0)
 
 
@@ -231,11 +233,11 @@ def test_probability_of_optimality_is_monotone_in_the_threshold(bask):
 )
 def test_expected_optimality_gap(bask, kw, expected):
     opt = _five_point_optimizer(bask, 0)
-    gap = opt.expected_optimality_gap(random_state=np.random.RandomState(0), n_probabilities=10, n_space_samples=100,
-                                      n_gp_samples=100, n_random_starts=10, tol=0.1, use_mean_gp=kw["use_mean_gp"],
-                                      normalized_scores=kw["normalized_scores"])
-    assert 0.0 < gap < 1.0
-    np.testing.assert_allclose(gap, expected, atol=0.15)
+    gaps = [opt.expected_optimality_gap(random_state=np.random.RandomState(seed), n_probabilities=10, n_space_samples=100,
+                                        n_gp_samples=100, n_random_starts=10, tol=0.1, use_mean_gp=kw["use_mean_gp"],
+                                        normalized_scores=kw["normalized_scores"]) for seed in range(6)]
+    assert all(0.0 < g < 1.0 for g in gaps)
+    np.testing.assert_allclose(np.mean(gaps), expected, atol=0.03)
 
 
 def test_optimum_intervals(bask):
