@@ -45,6 +45,8 @@ SIGNATURES = {
     "bgp_ctx_update_data": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
     "bgp_ctx_destroy": (None, [_vp]),
     "bgp_lml_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _ip]),
+    "bgp_lml_batch_submit": (C.c_int, [_vp, C.c_int, _dp]),
+    "bgp_lml_batch_wait": (C.c_int, [_vp, _dp, _ip]),
     "bgp_lml_batch_warped": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip]),
     "bgp_ctx_set_warp": (C.c_int, [_vp, _dp]),
     "bgp_beta_cdf": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp]),
@@ -171,6 +173,27 @@ class Context:
         out = np.empty(B)
         st = np.zeros(B, dtype=np.int32)
         _check(self._lib.bgp_lml_batch(self._h, B, _p(H), _p(out), _p(st)), "bgp_lml_batch")
+        return (out, st) if return_status else out
+
+    def lml_submit(self, H):
+        """Enqueue ``lml(H)`` on the device and return at once (False when the batch cannot go asynchronously: larger
+        than max_batch, or per-launch timing on); ``lml_wait()`` collects the result."""
+        H = self._H(H)
+        if H.shape[0] > self.max_batch or H.shape[0] == 0:
+            return False
+        rc = self._lib.bgp_lml_batch_submit(self._h, H.shape[0], _p(H))
+        if rc == 1:  # BGP_ERR_INVALID: timing mode -- the caller falls back to the synchronous call
+            return False
+        _check(rc, "bgp_lml_batch_submit")
+        self._pending, self._pending_H = H.shape[0], H  # (H stays alive until the upload has certainly happened)
+        return True
+
+    def lml_wait(self, return_status=False):
+        B = self._pending
+        self._pending, self._pending_H = 0, None
+        out = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_lml_batch_wait(self._h, _p(out), _p(st)), "bgp_lml_batch_wait")
         return (out, st) if return_status else out
 
     def lml_warped(self, H, W, return_status=False):

@@ -320,9 +320,17 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             with np.errstate(invalid="ignore"):
                 lp = lp + self._ctx.lml_warped(self._canonical(Tgp), W)
         else:
-            lp = _eval_priors(priors, Theta)
+            # the device factorises while the host evaluates the priors of the same block
+            H = self._canonical(Theta)
+            submitted = self._ctx.lml_submit(H)
+            try:
+                lp = _eval_priors(priors, Theta)
+            finally:
+                lml = self._ctx.lml_wait() if submitted else None
+            if lml is None:
+                lml = self._ctx.lml(H)
             with np.errstate(invalid="ignore"):
-                lp = lp + self._ctx.lml(self._canonical(Theta))
+                lp = lp + lml
         lp[~np.isfinite(lp)] = -np.inf
         return lp
 
@@ -837,18 +845,25 @@ def _eval_priors(priors, Theta):
         raise ValueError(f"zip() argument 2 is {'shorter' if p < len(priors) else 'longer'} than argument 1: "
                          f"{len(priors)} priors for {p} hyper-parameters")
     lp = np.zeros(Ns)
-    for k, prior in enumerate(priors):
-        col = Theta[:, k]
+    k = 0
+    while k < p:
+        prior = priors[k]
+        k1 = k + 1
+        while k1 < p and priors[k1] is prior:  # guess_priors puts the SAME callable on every length scale
+            k1 += 1
+        block = Theta[:, k:k1]
         vals = None
-        try:
+        try:  # one elementwise call for the whole run of columns ...
             with np.errstate(all="ignore"):
-                v = np.asarray(prior(col), dtype=np.float64)
-            if v.shape == (Ns,):
-                vals = v
+                v = np.asarray(prior(block if k1 - k > 1 else block[:, 0]), dtype=np.float64)
+            if v.shape == block.shape or (k1 - k == 1 and v.shape == (Ns,)):
+                vals = v.reshape(Ns, k1 - k)
         except Exception:
             vals = None
         if vals is None:
             with np.errstate(all="ignore"):
-                vals = np.array([float(prior(t)) for t in col])
-        lp += vals
+                vals = np.array([[float(prior(t)) for t in row] for row in block])
+        for j in range(k1 - k):  # ... added column by column, i.e. in the reference's summation order
+            lp += vals[:, j]
+        k = k1
     return lp

@@ -227,6 +227,8 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dwarpB);
   free_dev(c->dscratch);
   free_dev(c->drowpart);
+  if (c->hlml) (void)hipHostFree(c->hlml);
+  if (c->hstatus) (void)hipHostFree(c->hstatus);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
@@ -276,7 +278,8 @@ extern "C" int bgp_lml_batch_warped(bgp_ctx* c, int B, const double* h, const do
   return lml_batch_impl(c, B, h, warp, lml, status);
 }
 
-static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status) {
+static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status,
+                         hipEvent_t& e0, hipEvent_t& e1, int defer_sync = 0) {
   if (B == 0) return BGP_OK;
   BGP_HIP(hipSetDevice(c->device));
   const size_t nd = (size_t)c->n * c->d;
@@ -294,7 +297,6 @@ static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp
   const size_t p = c->d + 2;
   for (int k = 0; k < 5; k++) c->t_ms[k] = 0.0;
   for (int k = 0; k < 4; k++) c->t_cnt[k] = 0;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
   for (int off = 0; off < B; off += c->max_batch) {
     const int nb = std::min(c->max_batch, B - off);
     if (c->timing) {
@@ -354,6 +356,7 @@ static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp
       BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
     if (c->timing) (void)hipEventRecord(e1, c->stream);
+    if (defer_sync) return BGP_OK;  // (single chunk, timing off: bgp_lml_batch_wait synchronises)
     BGP_HIP(hipStreamSynchronize(c->stream));
     bgp_tcollect(c);
     if (c->timing) {
@@ -362,8 +365,88 @@ static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp
       c->t_ms[4] += ms;
       (void)hipEventDestroy(e0);
       (void)hipEventDestroy(e1);
+      e0 = e1 = nullptr;
     }
   }
+  return BGP_OK;
+}
+
+// One exit path: whatever step failed, the context's streams are drained (launches of the other walker group may
+// still be in flight), the per-launch timing events of the call are released and the sticky HIP error is cleared, so
+// that the context stays usable and nothing leaks.
+static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int rc = lml_batch_run(c, B, h, warp, lml, status, e0, e1);
+  if (rc != BGP_OK) {
+    (void)hipStreamSynchronize(c->stream);
+    for (int g = 0; g < BGP_MAX_STREAMS; g++)
+      if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
+    for (hipEvent_t ev : c->ev) (void)hipEventDestroy(ev);
+    c->ev.clear();
+    c->evcat.clear();
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipGetLastError();
+  }
+  return rc;
+}
+
+// Asynchronous form of bgp_lml_batch for the sampler's inner loop: submit enqueues the whole half-step (upload of the
+// proposals, K-build, factorisation, download of the B log-likelihoods into pinned host memory) and returns; the
+// host evaluates the log-priors of the same proposals meanwhile and collects the device results with wait.
+extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h) {
+  if (!c || !h || B <= 0) {
+    bgp_set_error("bgp_lml_batch_submit: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (c->pending_B != 0) {
+    bgp_set_error("bgp_lml_batch_submit: a submitted batch is still pending (call bgp_lml_batch_wait)");
+    return BGP_ERR_STATE;
+  }
+  if (B > c->max_batch || c->timing) {
+    bgp_set_error("bgp_lml_batch_submit: B = %d exceeds max_batch = %d (or per-launch timing is on): use bgp_lml_batch", B,
+                  c->max_batch);
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  if ((size_t)B > c->cap_pinned) {
+    if (c->hlml) (void)hipHostFree(c->hlml);
+    if (c->hstatus) (void)hipHostFree(c->hstatus);
+    c->hlml = nullptr;
+    c->hstatus = nullptr;
+    c->cap_pinned = 0;
+    BGP_HIP(hipHostMalloc(&c->hlml, (size_t)c->max_batch * sizeof(double)));
+    BGP_HIP(hipHostMalloc(&c->hstatus, (size_t)c->max_batch * sizeof(int)));
+    c->cap_pinned = c->max_batch;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const int rc = lml_batch_run(c, B, h, nullptr, c->hlml, c->hstatus, e0, e1, 1);
+  if (rc != BGP_OK) {
+    (void)hipStreamSynchronize(c->stream);
+    for (int g = 0; g < BGP_MAX_STREAMS; g++)
+      if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
+    (void)hipGetLastError();
+    return rc;
+  }
+  c->pending_B = B;
+  return BGP_OK;
+}
+
+extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
+  if (!c || !lml) {
+    bgp_set_error("bgp_lml_batch_wait: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (c->pending_B == 0) {
+    bgp_set_error("bgp_lml_batch_wait: nothing submitted");
+    return BGP_ERR_STATE;
+  }
+  const int B = c->pending_B;
+  c->pending_B = 0;
+  BGP_HIP(hipSetDevice(c->device));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  memcpy(lml, c->hlml, (size_t)B * sizeof(double));
+  if (status) memcpy(status, c->hstatus, (size_t)B * sizeof(int));
   return BGP_OK;
 }
 

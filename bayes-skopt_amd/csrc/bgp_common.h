@@ -84,6 +84,11 @@ struct bgp_ctx {
   double* drowpart = nullptr;  // column-tile partials of the predictive-variance row dots
   size_t cap_rowpart = 0;
   size_t cap_scratch = 0;
+  // asynchronous LML batch (bgp_lml_batch_submit / _wait): pinned result buffers and the pending batch size
+  double* hlml = nullptr;
+  int* hstatus = nullptr;
+  size_t cap_pinned = 0;
+  int pending_B = 0;
   bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
   // timing
   int timing = 0;

@@ -104,6 +104,15 @@ int bgp_ctx_set_warp(bgp_ctx* ctx, const double* warp);
 int bgp_beta_cdf(bgp_ctx* ctx, int m, const double* X, const double* warp, double* out);
 
 /*
+ * Asynchronous bgp_lml_batch (B <= max_batch): submit enqueues the whole batch on the device and returns, wait blocks
+ * until it is done and hands back lml / status (status may be NULL).  Between the two calls the host is free -- the
+ * sampler evaluates the log-priors of the same proposals there (bask/bayesgpr.py:366-372 runs them back to back).
+ * One batch may be pending per context; same results as bgp_lml_batch.
+ */
+int bgp_lml_batch_submit(bgp_ctx* ctx, int B, const double* h);
+int bgp_lml_batch_wait(bgp_ctx* ctx, double* lml, int* status);
+
+/*
  * LML and its gradient w.r.t. the canonical vector (grad is B*(d+2)):
  *     g_k = 1/2 tr((alpha alpha^T - K^-1) dK/dh_k)
  * Replaces: log_marginal_likelihood(theta, eval_gradient=True) (sklearn/_gpr.py:615-647,
