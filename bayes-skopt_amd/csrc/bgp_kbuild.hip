@@ -81,6 +81,21 @@ static __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A,
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     const int gi = i0 + ty + 16 * r;
+    if (!GRAM) {
+      // cross matrices are consumed by 128-tiled GEMMs: the tile's padding (rows >= out_rows, columns >= out_cols,
+      // inside the 128-padded buffer) is written as zeros here, so no memset pass over the buffer is needed
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int gj = j0 + tx + 16 * c;
+        double v = 0.0;
+        if (gi < out_rows && gj < out_cols) {
+          const double sv = kb_stationary<STAT>(acc[r][c]);
+          v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+        }
+        out[(size_t)gi * ldo + gj] = v;
+      }
+      continue;
+    }
     if (gi >= out_rows) continue;
 #pragma unroll
     for (int c = 0; c < 8; c++) {

@@ -212,6 +212,24 @@ static int launch_gemm_nt(bgp_ctx* c, const double* A, int lda, const double* Bm
 
 __global__ void add_diag_kernel(double* __restrict__ C, int ld, int m, double v);
 
+void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
+                        const int* pidx, int M, int n, int nb, double* part);
+int bgp_rowquad_tile();
+
+// out[b][i] = a_i^T S_b a_i for the rows of A_b (M x n, zero padded; S symmetric): half-product on the LDS-DMA ring
+// (rowquad4_kernel, bgp_syrk4.hip) + ordered reduction of the column-tile partials.  out is packed with stride M.
+static int launch_rowquad(bgp_ctx* c, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
+                          const int* pidx, int M, int n, int nb, double* out) {
+  const int tn = n / bgp_rowquad_tile();
+  int rc = ensure_rowpart(c, (size_t)nb * tn * M);
+  if (rc) return rc;
+  bgp_launch_rowquad(c->stream, A, lda, sA, S, lds_, sS, pidx, M, n, nb, c->drowpart);
+  BGP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((M + 255) / 256, nb), dim3(256), 0, c->stream, c->drowpart, tn, M, out);
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
+}
+
 static inline int pad128(int v) { return ((v + 127) / 128) * 128; }
 
 // ------------------------------------------------------------------------------------------
@@ -385,16 +403,15 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
     const double* al = c->dalpha_sol + (size_t)off * npad;
     GemmBatch gb;
     gb.nb = nb;
-    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)nb * sKs * sizeof(double), c->stream));  // zero padding rows / columns
     rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
     if (rc) return rc;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, al,
                        (size_t)npad, (const int*)nullptr, n, m, dout, (size_t)mpad);
     BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
                              (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
-    // q_i = rowsum((K_* K^-1) o K_*)
+    // q_i = k_i^T K^-1 k_i  (= rowsum((K_* K^-1) o K_*), evaluated on the lower block triangle of K^-1)
     gb.sA = sKs, gb.sB = (size_t)npad * npad, gb.sC = 0, gb.sE = sKs;
-    rc = launch_gemm_nt<1>(c, dKs, npad, Kinv, npad, mpad, npad, npad, nullptr, 0, dKs, npad, dq, gb);
+    rc = launch_rowquad(c, dKs, npad, sKs, Kinv, npad, (size_t)npad * npad, nullptr, mpad, npad, nb, dq);
     if (rc) return rc;
     if (cov) {
       gb.sC = sKs, gb.sE = 0;
@@ -402,7 +419,6 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
       if (rc) return rc;
       // K_** (no white noise off the diagonal; the diagonal gets c(+1) + s2 like kernel_(X)); then cov = K_** - P K_*^T
       // in place (every element is read and written by the same lane)
-      BGP_HIP(hipMemsetAsync(dCov, 0, (size_t)nb * sCv * sizeof(double), c->stream));
       rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, dCov, mpad, sCv);
       if (rc) return rc;
       hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dCov, mpad, sCv, m,
@@ -697,9 +713,9 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   // P_T = K_T Kinv ; s_t = rowsum(P_T o K_T) ; u_i = rowsum((K_c Kinv) o K_c) ; G = K_c P_T^T
   rc = launch_gemm_nt<0>(c, dKT, npad, Kinv, npad, Tpad, npad, npad, dPT, npad, nullptr, 0, nullptr);
   if (rc) return rc;
-  rc = launch_gemm_nt<1>(c, dKT, npad, Kinv, npad, Tpad, npad, npad, nullptr, 0, dKT, npad, dst);
+  rc = launch_rowquad(c, dKT, npad, 0, Kinv, npad, 0, nullptr, Tpad, npad, 1, dst);
   if (rc) return rc;
-  rc = launch_gemm_nt<1>(c, dKc, npad, Kinv, npad, mpad, npad, npad, nullptr, 0, dKc, npad, du);
+  rc = launch_rowquad(c, dKc, npad, 0, Kinv, npad, 0, nullptr, mpad, npad, 1, du);
   if (rc) return rc;
   rc = launch_gemm_nt<0>(c, dKc, npad, dPT, npad, mpad, Tpad, npad, dG, Tpad, nullptr, 0, nullptr);
   if (rc) return rc;
@@ -962,8 +978,6 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     const int nb = std::min(chunk, B - off);
     const double* dHc = dH + (size_t)off * p;
     const int* dpc = dpidx + off;
-    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)nb * sKs * sizeof(double), c->stream));
-    BGP_HIP(hipMemsetAsync(w->dK, 0, (size_t)nb * sCv * sizeof(double), c->stream));
     BGP_HIP(hipMemsetAsync(dZ, 0, (size_t)nb * mpad * sizeof(double), c->stream));
     BGP_HIP(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z + (size_t)off * m, (size_t)m * sizeof(double),
                              (size_t)m * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));

@@ -28,6 +28,8 @@
 #include "bgp_device.h"
 #include "bgp_gemm.h"
 
+#include <cstdlib>
+
 #define S4_KC 16
 #define S4_ROWB (S4_KC * 8)  // bytes per LDS row
 
@@ -343,6 +345,116 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
   const int B8 = 8 * ((B + 7) / 8);
   hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * (nblk - k - 1)), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride,
                      ystride, nblk, k, B);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row quadratic forms on the ring:  q_i = a_i^T S a_i  for the rows a_i of A (M x n) and a SYMMETRIC S (n x n) --
+// the predictive variance  k_*^T K^-1 k_*  of BayesGPR.predict (bask/bayesgpr.py:622-635 -> skopt's
+// einsum("ki,kj,ij->k", K_trans, K_trans, K_inv)) and the same terms of PVRS (bask/acquisition.py:335-338).
+// One workgroup per 64 x 64 tile (ti, tj) of  P = A S  restricted by symmetry to the block columns tk <= tj:
+//     q_i = sum_tj [ 2 sum_{tk < tj} a_i[tk]^T S[tk,tj] a_i[tj]  +  a_i[tj]^T S[tj,tj] a_i[tj] ]
+// i.e. HALF the flops of the full product; the tile's accumulators are doubled once before the diagonal block's
+// chunks.  Each tile writes its 64 partial row sums to part[(b tn + tj) M + row]; rowdot_reduce_kernel adds the tn
+// partials in tile order (no floating-point atomics: bitwise reproducible).  blockIdx.y = item of a batch
+// (A + b sA, S = Sbase + pidx[b] sS).
+// ------------------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
+    rowquad4_kernel(const double* __restrict__ A, int lda, size_t sA, const double* __restrict__ Sbase, int lds_,
+                    size_t sS, const int* __restrict__ pidx, int tn, int M, double* __restrict__ part) {
+  constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
+  constexpr int NRF = T / 32;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int b = blockIdx.y;
+  // heavy column tiles (large tj: long k range) first
+  const int tj = tn - 1 - (int)(blockIdx.x % tn), ti = blockIdx.x / tn;
+  const double* Ab = A + (size_t)b * sA + (size_t)(ti * T) * lda;
+  const double* Sb = Sbase + (size_t)(pidx ? pidx[b] : b) * sS + (size_t)(tj * T) * lds_;
+  unsigned voffA[T / 32], voffS[T / 32];
+  s4_src<T>(voffA, lda, w, lane);
+  s4_src<T>(voffS, lds_, w, lane);
+  const int r0 = wr * (T / 2), c0 = wc * (T / 2);
+  unsigned pa[4], pb[4];
+  s4_frag_addr(pa, lds0, r0, lane);
+  s4_frag_addr(pb, lds0 + OPB, c0, lane);
+  d4 acc[NRF][NRF];
+#pragma unroll
+  for (int i = 0; i < NRF; i++)
+#pragma unroll
+    for (int j = 0; j < NRF; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const int nch = (tj + 1) * (T / S4_KC), cdiag = tj * (T / S4_KC);
+  s4_issue<T>(Ab, voffA, 0, lds0, w);
+  s4_issue<T>(Sb, voffS, 0, lds0 + OPB, w);
+  for (int c = 0; c < nch; c += 2) {
+    if (c == cdiag) {  // everything so far came from block columns tk < tj: it counts twice (S symmetric)
+#pragma unroll
+      for (int i = 0; i < NRF; i++)
+#pragma unroll
+        for (int j = 0; j < NRF; j++) acc[i][j] = acc[i][j] * 2.0;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      S4_WAIT_VM0();
+      __builtin_amdgcn_s_barrier();
+      if (c + s + 1 < nch) {
+        const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
+        s4_issue<T>(Ab, voffA, (c + s + 1) * S4_KC, nb, w);
+        s4_issue<T>(Sb, voffS, (c + s + 1) * S4_KC, nb + OPB, w);
+      }
+      s4_mma<NRF, NRF, -64, 0, 0>(pa, pb, s * STAGEB, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // row sums of P o A over this tile's T columns: 16 lanes share a row (fixed shuffle order), the two column
+  // halves (wc = 0, 1) meet in LDS and are added in that order
+  __syncthreads();  // every wave is past its last fragment read: the ring is free
+  double* red = reinterpret_cast<double*>(smem);
+  const double* E = Ab + tj * T;
+#pragma unroll
+  for (int i = 0; i < NRF; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = GK_ROWB(r0, i, lane, r);
+      double ps = 0.0;
+#pragma unroll
+      for (int j = 0; j < NRF; j++) ps += acc[i][j][r] * E[(size_t)row * lda + GK_COLB(c0, j, lane)];
+      ps += __shfl_xor(ps, 1);
+      ps += __shfl_xor(ps, 2);
+      ps += __shfl_xor(ps, 4);
+      ps += __shfl_xor(ps, 8);
+      if ((lane & 15) == 0) red[wc * T + row] = ps;
+    }
+  }
+  __syncthreads();
+  if (tid < T) part[((size_t)b * tn + tj) * M + ti * T + tid] = red[tid] + red[T + tid];
+}
+
+// q (nb x M, packed) needs `part` = nb * (n / T) * M doubles of scratch; M and n are multiples of 128.
+// T = 64 by default; BGP_ROWQUAD_T=128 selects the 128-wide tile (measured equal within noise at 128 posteriors x
+// 10 000 points x n = 1024: 46 vs 43 ms per batched predict -- the kernel is bound by streaming K_* (83 MB per
+// posterior, read by every XCD), not by the tile shape).
+int bgp_rowquad_tile() {
+  static int t = 0;
+  if (!t) {
+    const char* e = getenv("BGP_ROWQUAD_T");
+    t = (e && atoi(e) == 128) ? 128 : 64;
+  }
+  return t;
+}
+void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
+                        const int* pidx, int M, int n, int nb, double* part) {
+  if (bgp_rowquad_tile() == 64) {
+    const int tn = n / 64, tm = M / 64;
+    hipLaunchKernelGGL(rowquad4_kernel<64>, dim3(tm * tn, nb), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M,
+                       part);
+  } else {
+    const int tn = n / 128, tm = M / 128;
+    hipLaunchKernelGGL(rowquad4_kernel<128>, dim3(tm * tn, nb), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M,
+                       part);
+  }
 }
 
 #ifdef S4_BENCH  // ablation / trace instantiations for tools/syrk4_bench.hip (not in the product library)
