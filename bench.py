@@ -329,10 +329,12 @@ def main():
     except Exception:
         pass
     # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated
-    try:
-        mfma_measured = float(_lib.bench_mfma_f64(device))
-    except Exception:
-        mfma_measured = None
+    mfma_measured = None
+    if not args.no_extras:  # (the rocprofv3 passes run --no-extras: their kernel tables hold the hot path only)
+        try:
+            mfma_measured = float(_lib.bench_mfma_f64(device))
+        except Exception:
+            mfma_measured = None
     peak = min(FP64_MFMA_PEAK_TFLOPS, mfma_measured) if mfma_measured else FP64_MFMA_PEAK_TFLOPS
     roofline = {
         "bound": "mfma",
