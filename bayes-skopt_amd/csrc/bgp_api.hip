@@ -163,11 +163,17 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
     const char* envs = getenv("BGP_SYRK2");
     c->use_syrk2 = (envs && atoi(envs) != 0) ? 1 : 0;
+    const char* envk = getenv("BGP_KBUILD1");
+    c->use_kbuild1 = (envk && atoi(envk) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");
     c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
     c->panels = c->two_panel ? 2 : 1;
+    c->panels_auto = envt ? 0 : 1;
     const char* envp = getenv("BGP_PANELS");
-    if (envp && atoi(envp) >= 1 && atoi(envp) <= 8) c->panels = atoi(envp);
+    if (envp && atoi(envp) >= 1 && atoi(envp) <= 8) {
+      c->panels = atoi(envp);
+      c->panels_auto = 0;
+    }
     (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     for (int g = 0; g < ns; g++) {
       (void)hipStreamCreate(&c->gstream[g]);
@@ -223,6 +229,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->dKinv);
   free_dev(c->dXw1);
   free_dev(c->dXwB);
+  free_dev(c->dXs);
   free_dev(c->dwarp);
   free_dev(c->dwarpB);
   free_dev(c->dscratch);

@@ -732,7 +732,10 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
     // of P block columns is factorised with look-ahead column updates only, then everything to its right is
     // updated ONCE with the whole K = 128 P panel (P times fewer passes over the trailing matrix):
     //   potrf(k) trsm(k) | col k+1 (K=128) | potrf(k+1) trsm(k+1) | col k+2 (K=256) | ... | rest (K = 128 P)
-    const int P = ctx->panels;
+    // P block columns per trailing update: 4 from n = 1536 upwards (config C: 16.5 vs 17.1 ms per step against P = 2
+    // with the LDS-DMA kernels, whose look-ahead column launches are cheap enough), 2 below (P = 2, 3, 4 are equal
+    // within noise at n = 1024); BGP_PANELS fixes it.
+    const int P = ctx->panels_auto ? (nblk >= 12 ? 4 : 2) : ctx->panels;
     int k = 0;
     while (k < nblk) {
       const int np = std::min(P, nblk - k);

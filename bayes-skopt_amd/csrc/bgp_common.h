@@ -42,6 +42,7 @@ struct bgp_ctx {
   int use_syrk2 = 0;     // trailing update with the VGPR-staged syrk2_kernel instead of syrk4_kernel (env BGP_SYRK2=1)
   int two_panel = 1;     // (legacy switch) env BGP_TWO_PANEL=0 == BGP_PANELS=1
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
+  int panels_auto = 1;   // no BGP_PANELS / BGP_TWO_PANEL in the environment: chosen per problem size (bgp_chol.hip)
   int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)
   int nstreams = 1;
   int streams_auto = 1;  // choose the group count per call from the batch size (see bgp_ctx_create)
@@ -57,6 +58,9 @@ struct bgp_ctx {
   double* dwarpB = nullptr;  // per-walker warp parameters (max_batch * 2d)
   size_t cap_xwb = 0;
   int has_warp = 0;
+  double* dXs = nullptr;     // scaled inputs of the current batch, k-major: max_batch * dpad * npad (bgp_kbuild.hip)
+  size_t cap_xs = 0;
+  int use_kbuild1 = 0;       // env BGP_KBUILD1=1: the unpipelined Gram build (A/B measurements)
   double* dy = nullptr;      // npad (zero padded)
   double* dalpha = nullptr;  // npad
   size_t cap_n = 0;          // capacity (rows) of the three buffers above

@@ -11,8 +11,73 @@
 // HBM-bound by design: 8 B written per pair, X re-read from L2.
 #include "bgp_common.h"
 #include "bgp_device.h"
+#include "bgp_ring.h"
 
 #define KB_DK 16  // input dimensions staged per pass
+
+// Epilogue of a 128 x 128 tile whose squared scaled distances sit in acc[r][c] (rows ty + 16 r, columns tx + 16 c):
+// stationary kernel, constant, exact diagonal / identity padding (GRAM) or zero padding (cross matrices).
+// R = rows per thread (8: 256 threads, rows ty + 16 r; 4: 512 threads, rows ty + 32 r).
+template <int GRAM, int STAT, int FORM, int R = 8>
+static __device__ __forceinline__ void kb_epilogue(double (&acc)[R][8], int na, int nb, int d,
+                                                   const double* __restrict__ h, const double* __restrict__ alpha,
+                                                   int i0, int j0, double* __restrict__ out, size_t ldo, int out_rows,
+                                                   int out_cols, int tx, int ty) {
+  const double cst = exp(h[0]);
+  const bool interior = (i0 + 128 <= na) && (j0 + 128 <= nb) && (i0 + 128 <= out_rows) && (j0 + 128 <= out_cols) &&
+                        !(GRAM && i0 == j0);
+  if (interior) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      double* orow = out + (size_t)(i0 + ty + (128 / R) * r) * ldo + j0 + tx;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const double s = kb_stationary<STAT>(acc[r][c]);
+        orow[16 * c] = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+      }
+    }
+    return;
+  }
+  const double s2 = exp(h[d + 1]);
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const int gi = i0 + ty + (128 / R) * r;
+    if (!GRAM) {
+      // cross matrices are consumed by 128-tiled GEMMs: the tile's padding (rows >= out_rows, columns >= out_cols,
+      // inside the 128-padded buffer) is written as zeros here, so no memset pass over the buffer is needed
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const int gj = j0 + tx + 16 * c;
+        double v = 0.0;
+        if (gi < out_rows && gj < out_cols) {
+          const double sv = kb_stationary<STAT>(acc[r][c]);
+          v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+        }
+        out[(size_t)gi * ldo + gj] = v;
+      }
+      continue;
+    }
+    if (gi >= out_rows) continue;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gj = j0 + tx + 16 * c;
+      if (gj >= out_cols) continue;
+      double v;
+      if (GRAM && (gi >= na || gj >= nb)) {
+        v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
+      } else if (GRAM && gi == gj) {
+        // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
+        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+        v = (base + s2);
+        if (alpha) v += alpha[gi];
+      } else {
+        const double s = kb_stationary<STAT>(acc[r][c]);
+        v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+      }
+      out[(size_t)gi * ldo + gj] = v;
+    }
+  }
+}
 
 // Generic tile body: out[(i0+..)][(j0+..)] = k(A_i, B_j); A is (na x d), Bm is (nb x d), row-major.
 // GRAM != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.
@@ -54,68 +119,18 @@ static __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A,
 #pragma unroll
       for (int c = 0; c < 8; c++) b[c] = xj[k][tx + 16 * c];
 #pragma unroll
-      for (int r = 0; r < 8; r++)
+      for (int r = 0; r < 8; r++) {  // (subtracts batched ahead of their squares: see kbuild2_kernel)
+        double df[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-          double df = a[r] - b[c];
-          acc[r][c] += df * df;
-        }
-    }
-  }
-  const double cst = exp(h[0]);
-  const bool interior = (i0 + 128 <= na) && (j0 + 128 <= nb) && (i0 + 128 <= out_rows) && (j0 + 128 <= out_cols) &&
-                        !(GRAM && i0 == j0);
-  if (interior) {
+        for (int c = 0; c < 8; c++) df[c] = a[r] - b[c];
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      double* orow = out + (size_t)(i0 + ty + 16 * r) * ldo + j0 + tx;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const double s = kb_stationary<STAT>(acc[r][c]);
-        orow[16 * c] = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+        for (int c = 0; c < 8; c++) acc[r][c] = fma(df[c], df[c], acc[r][c]);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
       }
     }
-    return;
   }
-  const double s2 = exp(h[d + 1]);
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    const int gi = i0 + ty + 16 * r;
-    if (!GRAM) {
-      // cross matrices are consumed by 128-tiled GEMMs: the tile's padding (rows >= out_rows, columns >= out_cols,
-      // inside the 128-padded buffer) is written as zeros here, so no memset pass over the buffer is needed
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int gj = j0 + tx + 16 * c;
-        double v = 0.0;
-        if (gi < out_rows && gj < out_cols) {
-          const double sv = kb_stationary<STAT>(acc[r][c]);
-          v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
-        }
-        out[(size_t)gi * ldo + gj] = v;
-      }
-      continue;
-    }
-    if (gi >= out_rows) continue;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int gj = j0 + tx + 16 * c;
-      if (gj >= out_cols) continue;
-      double v;
-      if (GRAM && (gi >= na || gj >= nb)) {
-        v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
-      } else if (GRAM && gi == gj) {
-        // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
-        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
-        v = (base + s2);
-        if (alpha) v += alpha[gi];
-      } else {
-        const double s = kb_stationary<STAT>(acc[r][c]);
-        v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
-      }
-      out[(size_t)gi * ldo + gj] = v;
-    }
-  }
+  kb_epilogue<GRAM, STAT, FORM>(acc, na, nb, d, h, alpha, i0, j0, out, ldo, out_rows, out_cols, tx, ty);
 }
 
 template <int STAT, int FORM>
@@ -157,6 +172,128 @@ __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restr
                              out + (size_t)b * ostride, (size_t)ldo, m, n);
 }
 
+// ------------------------------------------------------------------------------------------
+// Pipelined Gram build (the LML and posterior paths).  kbuild_gram_kernel above loads, divides and transposes its
+// X tiles at the head of every tile with nothing to overlap (two workgroups per CU at 128 accumulator registers): it
+// ran at ~40 % of the fp64 VALU rate.  Here
+//   * xscale_kernel writes the walker's scaled inputs ONCE, k-major:  Xs[b][k][i] = X_b[i][k] / l_k  (rows >= n and
+//     dimensions >= d zero), so a tile operand for 16 dimensions is 16 contiguous 1 KB rows -- the LDS-DMA's
+//     lane-linear image, no transpose, no division in the tile loop (same quotient as before, bit for bit);
+//   * kbuild2_kernel gives every workgroup KB2_TPW consecutive tiles of one matrix and streams their (tile, 16
+//     dimensions) operand chunks through a two-stage LDS ring with `global_load_lds_dwordx4`: the chunk after the
+//     one being accumulated is always in flight.
+// Same accumulation order (dimension ascending) and the same epilogue as kbuild_tile: identical K.
+// ------------------------------------------------------------------------------------------
+#define KB2_TPW 4
+#define KB2_WAVES 4    // 256 threads, 8 x 8 pairs per thread.  (512 threads x 4 x 8 pairs -- twice the waves per SIMD --
+#define KB2_R 8        // measured no faster: 0.875 vs 0.86 ms at config C; the kernel is fp64-VALU bound, not latency bound)
+__global__ void __launch_bounds__(256) xscale_kernel(const double* __restrict__ X, size_t xstride,
+                                                      const double* __restrict__ H, double* __restrict__ Xs, int n, int d,
+                                                      int npad, int dpad) {
+  const int b = blockIdx.y;
+  const double* Xb = X + (size_t)b * xstride;
+  const double* h = H + (size_t)b * (d + 2);
+  double* out = Xs + (size_t)b * dpad * npad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (size_t)dpad * npad;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx / npad), i = (int)(idx - (size_t)k * npad);
+    out[idx] = (k < d && i < n) ? Xb[(size_t)i * d + k] / exp(h[1 + k]) : 0.0;
+  }
+}
+
+// one chunk = operands of tile (ti, tj) for dimensions [16 kb, 16 kb + 16): xi then xj, 16 KB each; wave w issues
+// its share of the 16 rows (dimensions) of both (a wave instruction = 64 lanes x 16 B = one 1 KB row)
+static __device__ __forceinline__ void kb2_issue(const double* Xs_b, int npad, int ti, int tj, int kb, unsigned lds_buf,
+                                                 int w, int lane) {
+#pragma unroll
+  for (int q = 0; q < KB_DK / KB2_WAVES; q++) {
+    const int k = (KB_DK / KB2_WAVES) * w + q;
+    const double* rowp = Xs_b + (size_t)(kb * KB_DK + k) * npad;
+    s4_glds(rowp + ti * 128, (unsigned)lane * 16u, lds_buf + (unsigned)(k * 1024));
+    s4_glds(rowp + tj * 128, (unsigned)lane * 16u, lds_buf + (unsigned)(KB_DK * 1024 + k * 1024));
+  }
+}
+
+template <int STAT, int FORM>
+__global__ void __launch_bounds__(64 * KB2_WAVES, 2) kbuild2_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha,
+                                                       const double* __restrict__ H, double* __restrict__ Kbuf,
+                                                       const double* __restrict__ y, double* __restrict__ yw, int n,
+                                                       int d, int npad, int dpad, int nblk, int B, int full, int ld,
+                                                       int use_alpha) {
+  const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
+  const int ngroups = (ntiles + KB2_TPW - 1) / KB2_TPW;
+  int b, g;
+  bgp_map_block(blockIdx.x, ngroups, B, b, g);
+  if (b >= B) return;
+  __shared__ __attribute__((aligned(1024))) double smem[2][2 * KB_DK * 128];  // [stage][xi | xj][k][128]
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&smem[0][0];
+  const int tid = threadIdx.x, lane = tid & 63, tx = tid & 15, ty = tid >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* h = H + (size_t)b * (d + 2);
+  const double* Xs_b = Xs + (size_t)b * dpad * npad;
+  double* out = Kbuf + (size_t)b * ld * ld;
+  const int t0 = g * KB2_TPW, t1 = min(t0 + KB2_TPW, ntiles), nkb = dpad / KB_DK;
+  const int nchunks = (t1 - t0) * nkb;
+  auto decode = [&](int t, int& ti, int& tj) {
+    if (full) {
+      ti = t / nblk;
+      tj = t - ti * nblk;
+    } else {
+      bgp_tri_decode(t, ti, tj);
+    }
+  };
+  int ti, tj;
+  decode(t0, ti, tj);
+  kb2_issue(Xs_b, npad, ti, tj, 0, lds0, w, lane);
+  double acc[KB2_R][8];
+  for (int c = 0; c < nchunks; c++) {
+    const int t = t0 + c / nkb, kb = c - (c / nkb) * nkb;
+    decode(t, ti, tj);
+    if (kb == 0) {
+#pragma unroll
+      for (int r = 0; r < KB2_R; r++)
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) acc[r][cc] = 0.0;
+      if (ti == tj && tid < 128) yw[(size_t)b * ld + ti * 128 + tid] = y[ti * 128 + tid];  // working right-hand side
+    }
+    S4_WAIT_VM0();                 // this wave's share of chunk c has landed
+    __builtin_amdgcn_s_barrier();  // ... everybody's has; everybody finished reading chunk c-1
+    if (c + 1 < nchunks) {
+      const int tn_ = t0 + (c + 1) / nkb, kbn = (c + 1) - ((c + 1) / nkb) * nkb;
+      int tin, tjn;
+      decode(tn_, tin, tjn);
+      kb2_issue(Xs_b, npad, tin, tjn, kbn, lds0 + (unsigned)(((c + 1) & 1) * 2 * KB_DK * 1024), w, lane);
+    }
+    const double* xi = &smem[c & 1][0];
+    const double* xj = &smem[c & 1][KB_DK * 128];
+#pragma unroll 4
+    for (int k = 0; k < KB_DK; k++) {
+      double a[KB2_R], bb[8];
+#pragma unroll
+      for (int r = 0; r < KB2_R; r++) a[r] = xi[k * 128 + ty + (128 / KB2_R) * r];
+#pragma unroll
+      for (int cc = 0; cc < 8; cc++) bb[cc] = xj[k * 128 + tx + 16 * cc];
+      // four differences, then their four squares: a subtract never feeds the very next instruction
+#pragma unroll
+      for (int r = 0; r < KB2_R; r++) {
+#pragma unroll
+        for (int c4 = 0; c4 < 8; c4 += 4) {
+          double df[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) df[cc] = a[r] - bb[c4 + cc];
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) acc[r][c4 + cc] = fma(df[cc], df[cc], acc[r][c4 + cc]);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+      }
+    }
+    if (kb == nkb - 1)
+      kb_epilogue<1, STAT, FORM, KB2_R>(acc, n, n, d, h, use_alpha ? alpha : nullptr, ti * 128, tj * 128, out, (size_t)ld, npad,
+                                 npad, tx, ty);
+  }
+}
+
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
   return bgp_launch_kbuild_slice(ctx, 0, B, ctx->stream, full_square, augmented, use_alpha);
 }
@@ -168,16 +305,42 @@ int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int fu
 
 int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented, int use_alpha,
                         const double* dXb, size_t xstride) {
-  const int nblk = ctx->nblk;
-  const size_t ldm = augmented ? 2 * (size_t)ctx->npad : (size_t)ctx->npad;
+  const int nblk = ctx->nblk, npad = ctx->npad, d = ctx->d;
+  const size_t ldm = augmented ? 2 * (size_t)npad : (size_t)npad;
   const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
-  const int grid = 8 * ((B + 7) / 8) * ntiles;
+  const int B8 = 8 * ((B + 7) / 8);
+  double* dKo = ctx->dK + (size_t)off * ldm * ldm;
+  const double* dH = ctx->dh + (size_t)off * (d + 2);
+  double* dywo = ctx->dyw + (size_t)off * ldm;
   bgp_tbegin(ctx, 0, st);
-  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-              hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(grid), dim3(256), 0, st, dXb, ctx->dalpha,
-                                 ctx->dh + (size_t)off * (ctx->d + 2), ctx->dK + (size_t)off * ldm * ldm, ctx->dy,
-                                 ctx->dyw + (size_t)off * ldm, ctx->n, ctx->d, ctx->npad, nblk, B, full_square,
-                                 (int)ldm, use_alpha, xstride));
+  // the pipelined build pays a second (tiny) launch and groups KB2_TPW tiles per workgroup: below ~2000 tiles the
+  // plain kernel is faster (n = 1024 x 32 walkers: 0.069 vs 0.10 ms)
+  if (ctx->use_kbuild1 || B8 * ntiles < 2048) {
+    KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+                hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(B8 * ntiles), dim3(256), 0, st, dXb, ctx->dalpha, dH,
+                                   dKo, ctx->dy, dywo, ctx->n, d, npad, nblk, B, full_square, (int)ldm, use_alpha,
+                                   xstride));
+  } else {
+    // scaled inputs of the walkers of this batch slice, k-major (grown on demand; one slot per walker of max_batch)
+    const int dpad = ((d + KB_DK - 1) / KB_DK) * KB_DK;
+    const size_t need = (size_t)ctx->max_batch * dpad * npad;
+    if (need > ctx->cap_xs) {
+      if (ctx->dXs) {
+        (void)hipDeviceSynchronize();  // (another walker group's launches may still read the old buffer)
+        (void)hipFree(ctx->dXs);
+      }
+      ctx->dXs = nullptr;
+      ctx->cap_xs = 0;
+      BGP_HIP(hipMalloc(&ctx->dXs, need * sizeof(double)));
+      ctx->cap_xs = need;
+    }
+    double* dXs = ctx->dXs + (size_t)off * dpad * npad;
+    hipLaunchKernelGGL(xscale_kernel, dim3(64, B), dim3(256), 0, st, dXb, xstride, dH, dXs, ctx->n, d, npad, dpad);
+    const int ngroups = (ntiles + KB2_TPW - 1) / KB2_TPW;
+    KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+                hipLaunchKernelGGL((kbuild2_kernel<S, F>), dim3(B8 * ngroups), dim3(64 * KB2_WAVES), 0, st, dXs, ctx->dalpha, dH, dKo,
+                                   ctx->dy, dywo, ctx->n, d, npad, dpad, nblk, B, full_square, (int)ldm, use_alpha));
+  }
   bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
   return BGP_OK;

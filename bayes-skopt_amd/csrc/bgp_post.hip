@@ -920,6 +920,7 @@ static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out) {
   }
   w->two_panel = c->two_panel;
   w->panels = c->panels;
+  w->panels_auto = c->panels_auto;
   w->use_syrk2 = c->use_syrk2;
   *out = w;
   return BGP_OK;

@@ -27,25 +27,12 @@
 #include "bgp_common.h"
 #include "bgp_device.h"
 #include "bgp_gemm.h"
+#include "bgp_ring.h"
 
 #include <cstdlib>
 
 #define S4_KC 16
 #define S4_ROWB (S4_KC * 8)  // bytes per LDS row
-
-// One LDS-DMA instruction: 64 lanes x 16 B from (wave-uniform base + per-lane byte offset) to LDS
-// [lds_addr, lds_addr + 1 KB).  hipcc neither counts it in its vmcnt bookkeeping nor waits for it: the kernel
-// places its own waits.  (M0 is compiler-reserved: saved and restored inside the statement,
-// cdna_hip_programming.md 5.7.)
-static __device__ __forceinline__ void s4_glds(const double* gbase, unsigned voff, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(gbase), "s"(lds_addr)
-      : "memory");
-}
-#define S4_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // Wave w stages rows [w T/4, (w+1) T/4) of one T x 16 operand chunk: T/32 instructions x 8 rows.  voff[i] is this
 // lane's (swizzled) byte offset for instruction i, the same for every operand panel and chunk: the panel origin
