@@ -172,9 +172,40 @@ static __host__ __device__ __forceinline__ int s4_ntile(int nt128, int colmode) 
   return (T == 128) ? nt : 2 * nt - 1;
 }
 
+// Tile order of a matrix's lower triangle (nt x nt tiles): column panels of S4_PW tile columns, each swept top to
+// bottom.  The tiles an XCD runs at any time then share ONE panel's B rows (S4_PW x 64 x K x 8 B = 2 MB at K = 512:
+// resident in the XCD's 4 MB L2) and stream the A rows once per panel -- row-major order re-fetched every B row
+// block for every tile row once the K = 512 panel (7 MB per matrix) had outgrown the L2 (rocprofv3: 1.25 GB per
+// launch against 0.45 GB of C traffic).  Placement only: results do not depend on the order.
+#define S4_PW 8
+static __device__ __forceinline__ void s4_panel_decode(int t, int nt, int& ti, int& tj, int pw = S4_PW) {
+  int p0 = 0;
+  for (;;) {  // (at most nt / S4_PW iterations)
+    const int rows = nt - p0;                       // tile rows of this panel
+    const int w = rows < pw ? rows : pw;            // its width
+    const int cnt = w * (w + 1) / 2 + (rows - w) * w;
+    if (t < cnt) {
+      const int head = w * (w + 1) / 2;             // triangular head (the panel's diagonal tiles), then full rows
+      int r, c;
+      if (t < head) {
+        bgp_tri_decode(t, r, c);
+      } else {
+        r = w + (t - head) / w;
+        c = (t - head) - (r - w) * w;
+      }
+      ti = p0 + r;
+      tj = p0 + c;
+      return;
+    }
+    t -= cnt;
+    p0 += pw;
+  }
+}
+
 template <int T>
 static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, double* Kbuf, const int* status, int ld,
-                                                   size_t mstride, int kp, int jstart, int colmode, int nt128, int B) {
+                                                   size_t mstride, int kp, int jstart, int colmode, int nt128, int B,
+                                                   int pw) {
   S4Tile d;
   d.XA = d.XB = nullptr;
   d.C = nullptr;
@@ -187,7 +218,7 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
     if (b >= B || status[b] != 0) break;  // padding slot / failed factorisation: nothing to update
     int ti, tj;
     if (!colmode) {
-      bgp_tri_decode(t, ti, tj);
+      s4_panel_decode(t, nt128 * (128 / T), ti, tj, pw);
     } else if (T == 128 || t < nt128 * 2) {
       ti = t;
       tj = 0;
@@ -210,7 +241,7 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
 template <int T, int VAR>
 __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
     syrk4_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp,
-                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace) {
+                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace, int pw) {
   constexpr unsigned STAGEB = 2 * T * S4_ROWB;
   constexpr int NRF = T / 32;  // MFMA tiles per wave and direction (each wave a T/2 x T/2 block)
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
@@ -219,7 +250,7 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
   const int nt128 = nblk - jstart;
   const S4Tile cur = s4_decode<T>(blockIdx.x, total, s4_ntile<T>(nt128, colmode), Kbuf, status, ld, mstride, kp, jstart,
-                                  colmode, nt128, B);
+                                  colmode, nt128, B, pw);
   if (cur.q >= total) return;
   unsigned voff[T / 32];
   s4_src<T>(voff, ld, w, lane);
@@ -245,8 +276,13 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
                       int K, int jstart, int colmode, int B) {
   const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
+  static int pw = 0;
+  if (!pw) {
+    const char* e = getenv("BGP_PANEL_WIDTH");  // tile columns per L2-resident column panel (s4_panel_decode)
+    pw = (e && atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : S4_PW;
+  }
   hipLaunchKernelGGL((syrk4_kernel<64, 0>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
-                     colmode, B, total, nullptr);
+                     colmode, B, total, nullptr, pw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -453,7 +489,7 @@ extern "C" int bgp_debug_launch_syrk4(int T, int var, hipStream_t st, int B8, do
 #define S4_CASE(TT, V)                                                                                               \
   if (T == TT && var == V) {                                                                                         \
     hipLaunchKernelGGL((syrk4_kernel<TT, V>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,    \
-                       jstart, colmode, B, total, trace);                                                            \
+                       jstart, colmode, B, total, trace, S4_PW);                                                     \
     return total;                                                                                                    \
   }
   S4_CASE(128, 0) S4_CASE(128, 4) S4_CASE(64, 0) S4_CASE(64, 1) S4_CASE(64, 2) S4_CASE(64, 3) S4_CASE(64, 4)
