@@ -15,8 +15,9 @@ every rank and the chain equals the single-GPU chain bit for bit.
 Backends (``BGP_DIST_BACKEND`` or the ``backend`` argument):
   ``rccl``  (default when this process sees a GPU) -- RCCL through libbgp's own C-ABI (``bgp_comm_*``,
             csrc/bgp_comm.hip): no PyTorch anywhere in the product path.  Rank 0 creates the ncclUniqueId and
-            hands its 128 bytes to the other ranks over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1)
-            (``BGP_COMM_PORT`` overrides; MASTER_PORT itself belongs to the launcher's rendezvous store).
+            hands its 128 bytes to the other ranks through a file under /tmp on a single node (MASTER_ADDR =
+            loopback) or over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1) otherwise (``BGP_COMM_TCP=1`` forces it,
+            ``BGP_COMM_PORT`` overrides the port; MASTER_PORT itself belongs to the launcher's rendezvous store).
   ``gloo`` / ``nccl`` -- ``torch.distributed`` process groups: the CPU tests (world size 2 over gloo) and an A/B
             path for the native one; torch is only imported when one of these is selected.
 ``BGP_DIST_FORCE=1`` joins a group even at world size 1 (the GPU test that runs real RCCL collectives on one GPU).
@@ -59,12 +60,37 @@ def _comm_endpoint():
     return host, port
 
 
+_T_START = time.time()
+
+
+def _uid_file():
+    tag = "%s_%s_%s_ws%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
+                             os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("WORLD_SIZE", "1"))
+    return os.path.join(os.environ.get("BGP_COMM_DIR", "/tmp"), "bgp_comm_uid_" + tag.replace("/", "_"))
+
+
 def _exchange_unique_id(rank, ws, timeout=120.0):
+    """Rank 0's ncclUniqueId on every rank.  Single node (MASTER_ADDR is this host's loopback, what the launcher
+    contract uses): rank 0 drops the bytes into /tmp/bgp_comm_uid_<addr>_<port>_<run id> (atomic rename) and the
+    other ranks poll for a file no older than their own start (rank 0 removes it at exit; a stale one left by a
+    crashed job with the same port and world size is ignored); no port beyond the launcher's own is needed.  Otherwise: a TCP socket on MASTER_ADDR:(MASTER_PORT+1)."""
     from . import _lib
 
+    local = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1") \
+        and os.environ.get("BGP_COMM_TCP") != "1"
     if rank == 0:
         uid = _lib.comm_unique_id()
         if ws == 1:
+            return uid
+        if local:
+            path = _uid_file()
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                f.write(uid)
+            os.replace(tmp, path)
+            import atexit
+
+            atexit.register(lambda p=path: os.path.exists(p) and os.remove(p))  # no stale id for the next job
             return uid
         host, port = _comm_endpoint()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
@@ -80,8 +106,22 @@ def _exchange_unique_id(rank, ws, timeout=120.0):
         finally:
             srv.close()
         return uid
-    host, port = _comm_endpoint()
     deadline = time.monotonic() + timeout
+    if local:
+        path = _uid_file()
+        while True:
+            try:
+                if os.path.getmtime(path) >= _T_START - 30.0:  # (ranks of one job start within seconds of each other)
+                    with open(path, "rb") as f:
+                        buf = f.read()
+                    if len(buf) == _lib.COMM_ID_BYTES:
+                        return buf
+            except OSError:
+                pass
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"rank {rank}: no ncclUniqueId file {path} from rank 0 within {timeout:.0f} s")
+            time.sleep(0.02)
+    host, port = _comm_endpoint()
     while True:
         try:
             with socket.create_connection((host, port), timeout=5.0) as s:

@@ -95,10 +95,14 @@ def test_single_process_helpers():
     assert d.rank_seed(0, 0) != d.rank_seed(0, 1)
 
 
-def test_unique_id_rendezvous_over_tcp(tmp_path):
-    """The native RCCL backend's rendezvous: rank 0 hands the 128-byte ncclUniqueId to the other ranks over a TCP
-    socket on MASTER_ADDR:(MASTER_PORT + 1).  (The id itself needs a GPU: patched to fixed bytes here; the real
-    ncclCommInitRank + collectives run in tests/test_gpu_distributed.py.)"""
+import pytest
+
+
+@pytest.mark.parametrize("tcp", ["0", "1"])
+def test_unique_id_rendezvous(tmp_path, tcp):
+    """The native RCCL backend's rendezvous: rank 0 hands the 128-byte ncclUniqueId to the other ranks through a file
+    under /tmp (single node) or over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1).  (The id itself needs a GPU:
+    patched to fixed bytes here; the real ncclCommInitRank + collectives run in tests/test_gpu_distributed.py.)"""
     code = (
         "import os, sys; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib, distributed;"
         "_lib.comm_unique_id = lambda: bytes(range(128));"
@@ -109,7 +113,8 @@ def test_unique_id_rendezvous_over_tcp(tmp_path):
     port = _free_port()
     procs = []
     for r in (2, 0, 1):  # start order must not matter: clients retry until rank 0 listens
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="3")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="3",
+                   BGP_COMM_TCP=tcp, BGP_COMM_DIR=str(tmp_path))
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
     for p in procs:
         assert p.wait(timeout=120) == 0
