@@ -108,7 +108,8 @@ def test_unique_id_rendezvous(tmp_path, tcp):
         "_lib.comm_unique_id = lambda: bytes(range(128));"
         "r = int(os.environ['RANK']); ws = int(os.environ['WORLD_SIZE']);"
         "uid = distributed._exchange_unique_id(r, ws, timeout=60.0);"
-        "open(os.path.join(%r, 'uid%%d.bin' %% r), 'wb').write(uid)"
+        "open(os.path.join(%r, 'uid%%d.bin' %% r), 'wb').write(uid);"
+        "import time; time.sleep(4.0 if r == 0 else 0.0)"  # (a real rank 0 stays alive in ncclCommInitRank; it removes the id file at exit)
     ) % (ROOT, str(tmp_path))
     port = _free_port()
     procs = []
