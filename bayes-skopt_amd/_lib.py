@@ -58,6 +58,7 @@ SIGNATURES = {
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
     "bgp_sample_y_batch": (C.c_int, [_vp, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_double, _dp, _ip]),
+    "bgp_comm_available": (C.c_int, []),
     "bgp_comm_unique_id": (C.c_int, [_vp]),
     "bgp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "bgp_comm_destroy": (None, [_vp]),
@@ -331,6 +332,11 @@ class Context:
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_available():
+    """True when librccl.so can be loaded (the native multi-GPU backend)."""
+    return bool(load().bgp_comm_available())
 
 
 def comm_unique_id():

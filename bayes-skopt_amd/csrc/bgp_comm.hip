@@ -88,6 +88,8 @@ static int comm_reserve(bgp_comm* c, size_t nsend, size_t nrecv) {
   return BGP_OK;
 }
 
+extern "C" int bgp_comm_available(void) { return load_rccl() == BGP_OK ? 1 : 0; }
+
 extern "C" int bgp_comm_unique_id(void* id128) {
   if (!id128) {
     bgp_set_error("bgp_comm_unique_id: NULL argument");

@@ -149,7 +149,10 @@ def init_process_group(backend=None, device=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = _lib.device_count()
-    name = backend or os.environ.get("BGP_DIST_BACKEND") or ("rccl" if ndev > 0 else "gloo")
+    name = backend or os.environ.get("BGP_DIST_BACKEND")
+    if not name:
+        # librccl loads (or not) identically on every rank of a node: a consistent choice without any exchange
+        name = ("rccl" if _lib.comm_available() else "nccl") if ndev > 0 else "gloo"
     if name == "rccl":
         if ndev < 1:
             raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")

@@ -224,6 +224,7 @@ int bgp_mfma_f64_layout(int device, int* rows, int* cols);
  */
 #define BGP_COMM_ID_BYTES 128
 typedef struct bgp_comm bgp_comm;
+int bgp_comm_available(void); /* 1 when librccl.so can be loaded in this process */
 int bgp_comm_unique_id(void* id128);
 int bgp_comm_init(int device, int rank, int world, const void* id128, bgp_comm** out);
 void bgp_comm_destroy(bgp_comm* comm);
