@@ -163,6 +163,8 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
     const char* envs = getenv("BGP_SYRK2");
     c->use_syrk2 = (envs && atoi(envs) != 0) ? 1 : 0;
+    const char* envss = getenv("BGP_SMALL_SPLIT");  // 1: n <= 128 through the two-launch path (A/B of the fused kernel)
+    c->use_small_split = (envss && atoi(envss) != 0) ? 1 : 0;
     const char* envk = getenv("BGP_KBUILD1");
     c->use_kbuild1 = (envk && atoi(envk) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");
@@ -319,9 +321,14 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       gsz = nb;
     }
     BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     int rc = BGP_OK;
-    if (warp) {
+    const bool fused_small = c->nblk == 1 && !warp && !c->left_looking && !c->use_small_split;
+    if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
+    if (fused_small) {
+      // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
+      rc = bgp_launch_lml_small(c, 0, nb, c->stream);
+      if (rc) return rc;
+    } else if (warp) {
       // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
       BGP_HIP(hipMemcpyAsync(c->dwarpB, warp + (size_t)off * 2 * c->d, (size_t)nb * 2 * c->d * sizeof(double),
                              hipMemcpyHostToDevice, c->stream));

@@ -188,17 +188,92 @@ static __device__ __forceinline__ void pf_wfinish(d4 acc, double* __restrict__ s
 #pragma unroll
     for (int r = 0; r < 4; r++) s[(J * 16 + lr) * PF_LD + I * 16 + lk + 4 * r] = wn[r];
   }
+  if (Wg) {
 #pragma unroll
-  for (int r = 0; r < 4; r++) Wg[(I * 16 + lk + 4 * r) * 128 + J * 16 + lr] = wn[r];
+    for (int r = 0; r < 4; r++) Wg[(I * 16 + lk + 4 * r) * 128 + J * 16 + lr] = wn[r];
+  }
 }
 
 #define PF_THREADS 512
+// GEN (fused small-n LML, n <= 128: SURVEY.md section 7 step 5): the workgroup GENERATES the jittered Gram matrix of
+// its walker straight into the LDS tile (same arithmetic, in the same order, as kbuild_tile: scaled inputs, squared
+// differences in dimension order, stationary kernel, exact diagonal, identity padding) instead of loading a tile
+// another launch wrote, takes y from the context and stores nothing but lml / status: ONE launch per LML batch, no
+// Gram matrix in HBM.  `gen` carries the extra inputs.
+struct PfGen {
+  const double* X;      // n x d training inputs (original or warped)
+  const double* alpha;  // n diagonal terms
+  const double* H;      // B x (d + 2) canonical hyper-parameters
+  const double* y;      // npad right-hand side (zero padded)
+  int d;
+};
+
+template <int STAT, int FORM>
+static __device__ __forceinline__ void pf_generate_tile(double* __restrict__ s, double* __restrict__ xs,
+                                                        const PfGen& g, const double* __restrict__ h, int n, int tid) {
+  // thread (tx, ty) of a 16 x 32 grid owns rows ty + 32 r (r < 4) and columns tx + 16 c (c < 8)
+  const int tx = tid & 15, ty = tid >> 4;
+  double acc[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+#pragma unroll
+    for (int c = 0; c < 8; c++) acc[r][c] = 0.0;
+  const int d = g.d;
+  for (int k0 = 0; k0 < d; k0 += 16) {
+    const int kc = min(16, d - k0);
+    __syncthreads();
+    for (int idx = tid; idx < kc * 128; idx += PF_THREADS) {
+      const int row = idx / kc, kk = idx - row * kc;
+      xs[kk * 128 + row] = (row < n) ? g.X[(size_t)row * d + k0 + kk] / exp(h[1 + k0 + kk]) : 0.0;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < kc; kk++) {
+      double a[4], bb[8];
+#pragma unroll
+      for (int r = 0; r < 4; r++) a[r] = xs[kk * 128 + ty + 32 * r];
+#pragma unroll
+      for (int c = 0; c < 8; c++) bb[c] = xs[kk * 128 + tx + 16 * c];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const double df = a[r] - bb[c];
+          acc[r][c] = fma(df, df, acc[r][c]);
+        }
+    }
+  }
+  {
+#pragma clang fp contract(off)
+  const double cst = exp(h[0]), s2 = exp(h[d + 1]);
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int gi = ty + 32 * r;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gj = tx + 16 * c;
+      double v;
+      if (gi >= n || gj >= n) {
+        v = (gi == gj) ? 1.0 : 0.0;
+      } else if (gi == gj) {
+        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+        v = (base + s2) + g.alpha[gi];
+      } else {
+        const double sv = kb_stationary<STAT>(acc[r][c]);
+        v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+      }
+      s[gi * PF_LD + gj] = v;
+    }
+  }
+}
+}
+
+template <int GEN, int STAT, int FORM>
 __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                      double* __restrict__ yw, double* __restrict__ accb,
                                                      double* __restrict__ lml, int* __restrict__ status, int n,
-                                                     int ld, size_t mstride, int ystride, int nblk, int k) {
+                                                     int ld, size_t mstride, int ystride, int nblk, int k, PfGen gen) {
   const int b = blockIdx.x;
-  if (status[b] != 0) return;
+  if (!GEN && status[b] != 0) return;
   __shared__ double s[128 * PF_LD];
   __shared__ double Minv[8 * 16 * PF_MLD];
   __shared__ double xrow[2][16 * PF_MLD];  // X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
@@ -212,7 +287,10 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   double* yk = yw + (size_t)b * ystride + k * 128;
   PF_T(0);
 
-  {
+  if (GEN) {
+    if (tid == 0) status[b] = 0;
+    pf_generate_tile<STAT, FORM>(s, Minv, gen, gen.H + (size_t)b * (gen.d + 2), n, tid);  // (Minv: scratch until step 0)
+  } else {
     // lower triangle of the tile -> LDS, all 16 16-byte loads of a thread in flight at once (the block is
     // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
     // (t >> 6) + 8 i; pairs entirely above the diagonal are never read.
@@ -229,7 +307,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
       *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
     }
   }
-  if (tid < 128) ylds[tid] = yk[tid];
+  if (tid < 128) ylds[tid] = GEN ? gen.y[tid] : yk[tid];
   double ld_prev = 0.0, zz_prev = 0.0;  // running log-det and z^T z of the earlier diagonal blocks
   if (tid == 0) {
     fail_lds = 0;
@@ -241,7 +319,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   __syncthreads();
   PF_T(1);
 
-  double* Wg = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
+  double* Wg = GEN ? nullptr : Wbuf + ((size_t)b * nblk + k) * (128 * 128);
   int failed = 0;
   d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written in place one step later (the update
                                         // waves still read the unscaled block T_{sb,sb-1} during this step)
@@ -356,7 +434,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
         pf_wfinish(acc, s, Minv, Wg, p, J, lane);
       }
       // row block sb-2 of L is final and visible: stream it out now (lower triangle, 16-byte pairs)
-      if (sb >= 2 && sb <= 6) {  // (the last step is the update waves' busiest: blocks 5..7 go out after the loop)
+      if (!GEN && sb >= 2 && sb <= 6) {  // (the last step is the update waves' busiest: blocks 5..7 go out after the loop)
         const int R = sb - 2, ut = u6 * 64 + lane;  // 384 update threads: 24 per row
         const int rr = ut / 24, c0 = ut - 24 * rr, row = R * 16 + rr;
         for (int seg = c0; seg < 8 * R + 8; seg += 24) {
@@ -383,7 +461,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   // ---- L_kk out.  Only the lower triangle is written (16-byte stores; the element right of the diagonal in
   // a straddling pair is junk nobody reads: every consumer of this tile masks j <= i).  Block (7, 6) is still
   // in the panel wave's registers and goes out from there.  The stores drain while row 7 of W is formed.
-  {
+  if (!GEN) {
     const int seg = tid & 63, rbase = tid >> 6;
 #pragma unroll
     for (int i = 10; i < 16; i++) {  // row blocks 5, 6 and 7 (0..4 went out inside the loop)
@@ -394,8 +472,10 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   }
   // ---- row 7 of W: last term (K = 6) and the multiplication by -M_7
   if (w == 0) {
+    if (!GEN) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) T[(size_t)(7 * 16 + lr) * ld + 6 * 16 + lk + 4 * r] = xpend[r];
+      for (int r = 0; r < 4; r++) T[(size_t)(7 * 16 + lr) * ld + 6 * 16 + lk + 4 * r] = xpend[r];
+    }
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
     acc = pf_wsum(acc, s, Minv, xrow[1], 7, 6, 6, 7, lane);
     pf_wfinish(acc, s, Minv, Wg, 7, 6, lane);
@@ -426,7 +506,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   double zv = 0.0;
   if (tid < 128) {
     zv = (zpart[tid] + zpart[128 + tid]) + (zpart[256 + tid] + zpart[384 + tid]);
-    yk[tid] = zv;
+    if (!GEN) yk[tid] = zv;
   }
   double zz = zv * zv;
   for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
@@ -437,8 +517,10 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
     double zzt = red[8] + red[9];
     ldt += ld_prev;
     zzt += zz_prev;
-    accb[b * 4 + 0] = ldt;
-    accb[b * 4 + 1] = zzt;
+    if (!GEN) {
+      accb[b * 4 + 0] = ldt;
+      accb[b * 4 + 1] = zzt;
+    }
     if (k == nblk - 1) {
       double v = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
       if (!(v > -INFINITY && v < INFINITY)) {  // overflow somewhere on the way: report like a failed factorisation
@@ -705,8 +787,27 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
-  hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
-                     ystride, ctx->nblk, k);
+  hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld,
+                     mstride, ystride, ctx->nblk, k, PfGen());
+}
+
+// Fused LML of a batch at n <= 128: ONE launch (Gram generation + factorisation + forward substitution + LML in the
+// walker's workgroup).  dXb / xstride: per-walker warped inputs or the shared training set (xstride == 0 only).
+int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st) {
+  PfGen g;
+  g.X = ctx->dXeff;
+  g.alpha = ctx->dalpha;
+  g.H = ctx->dh + (size_t)off * (ctx->d + 2);
+  g.y = ctx->dy;
+  g.d = ctx->d;
+  bgp_tbegin(ctx, 1, st);
+  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+              hipLaunchKernelGGL((potrf_kernel<1, S, F>), dim3(B), dim3(PF_THREADS), 0, st, (double*)nullptr,
+                                 (double*)nullptr, (double*)nullptr, (double*)nullptr, ctx->dlml + off, ctx->dstatus + off,
+                                 ctx->n, 128, (size_t)0, 0, 1, 0, g));
+  bgp_tend(ctx, st);
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
 }
 
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
@@ -741,8 +842,8 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
       const int np = std::min(P, nblk - k);
       for (int j = 0; j < np; j++) {
         bgp_tbegin(ctx, 1, st);
-        hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld,
-                           mstride, ystride, nblk, k + j);
+        hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus,
+                           ctx->n, ld, mstride, ystride, nblk, k + j, PfGen());
         bgp_tend(ctx, st);
         if (k + j + 1 >= nblk) break;
         bgp_tbegin(ctx, 2, st);
@@ -776,8 +877,8 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
   }
   for (int k = 0; k < nblk; k++) {
     bgp_tbegin(ctx, 1, st);
-    hipLaunchKernelGGL(potrf_kernel, dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n, ld, mstride,
-                       ystride, nblk, k);
+    hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n,
+                       ld, mstride, ystride, nblk, k, PfGen());
     bgp_tend(ctx, st);
     const int nlow = nblk - k - 1;
     const int nact = augmented ? nblk : nlow;

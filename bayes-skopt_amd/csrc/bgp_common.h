@@ -60,6 +60,7 @@ struct bgp_ctx {
   int has_warp = 0;
   double* dXs = nullptr;     // scaled inputs of the current batch, k-major: max_batch * dpad * npad (bgp_kbuild.hip)
   size_t cap_xs = 0;
+  int use_small_split = 0;   // env BGP_SMALL_SPLIT=1: no fused n <= 128 kernel (A/B measurements)
   int use_kbuild1 = 0;       // env BGP_KBUILD1=1: the unpipelined Gram build (A/B measurements)
   double* dy = nullptr;      // npad (zero padded)
   double* dalpha = nullptr;  // npad
@@ -161,6 +162,8 @@ int bgp_launch_kcross_batch(bgp_ctx* ctx, int nb, const double* dH, int m, const
 int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* dW, double* dout, int n, int B,
                     size_t ostride);
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
+// n <= 128: K-build + factorisation + LML of the slice [off, off+B) in ONE launch (bgp_chol.hip, potrf_kernel<1,..>)
+int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st);
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);
 // LML path: left-looking update with fused kernel-matrix generation (bgp_llchol.hip); replaces
 // bgp_launch_kbuild_slice + bgp_launch_cholesky_slice(augmented = 0)

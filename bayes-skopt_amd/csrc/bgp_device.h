@@ -44,8 +44,11 @@ static __device__ __forceinline__ void bgp_tri_decode(int t, int& ti, int& tj) {
 
 // Compile-time stationary kernel (same operation order as sklearn/kernels.py:1553-1560, 1713-1733;
 // the Matern-5/2 term K**2/3.0 is evaluated as t*t*(1/3): <= 1 ulp from the reference's division).
+// No implicit fused multiply-add here (hipcc's default contraction is decided per call site by the backend: two
+// kernels inlining this function could otherwise round the Matern polynomial differently).
 template <int STAT>
 static __device__ __forceinline__ double kb_stationary(double r2) {
+#pragma clang fp contract(off)
   if (STAT == BGP_RBF) return exp(-0.5 * r2);
   const double dist = sqrt(r2);
   if (STAT == BGP_MATERN12) return exp(-dist);

@@ -23,6 +23,7 @@ static __device__ __forceinline__ void kb_epilogue(double (&acc)[R][8], int na, 
                                                    const double* __restrict__ h, const double* __restrict__ alpha,
                                                    int i0, int j0, double* __restrict__ out, size_t ldo, int out_rows,
                                                    int out_cols, int tx, int ty) {
+#pragma clang fp contract(off)
   const double cst = exp(h[0]);
   const bool interior = (i0 + 128 <= na) && (j0 + 128 <= nb) && (i0 + 128 <= out_rows) && (j0 + 128 <= out_cols) &&
                         !(GRAM && i0 == j0);

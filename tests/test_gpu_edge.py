@@ -204,3 +204,39 @@ def test_walker_group_streams_bit_identical():
         ctx.set_streams(ns)
         np.testing.assert_array_equal(ctx.lml(H), auto)
     ctx.close()
+
+
+def test_pipelined_gram_build_matches_plain_build_and_oracle(lib, O):
+    """Launches of >= 2048 tiles take the pipelined Gram build (xscale_kernel + kbuild2_kernel on the LDS-DMA ring,
+    full-square and lower-triangular tile lists); smaller ones the plain kernel.  Same K bit for bit (BGP_KBUILD1=1
+    forces the plain kernel) and within 1e-12 of the oracle, every kernel family, ragged n, d > 16 (two k-blocks)."""
+    import os
+    import subprocess
+    import sys
+
+    n, d = 2100, 19
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1))
+    h = np.concatenate([[0.2], np.log(0.5) + 0.2 * rng.randn(d), [np.log(0.03)]])
+    alpha = 10.0 ** rng.uniform(-8, -3, size=n)
+    for stat, form in (("matern52", "product"), ("rbf", "sum"), ("matern12", "product")):
+        ctx = lib.Context(X, y, alpha, form=form, stationary=stat, max_batch=2)
+        K = ctx.kernel_matrix(h)  # full square: 8 x 17^2 tiles -> pipelined build
+        Ko = O.gram_with_jitter(X, alpha, h, stationary=stat, form=form)
+        np.testing.assert_allclose(K, Ko, rtol=1e-12, atol=1e-300)
+        ctx.close()
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib;"
+        "rng=np.random.RandomState(3); n,d=2100,19; X=rng.uniform(size=(n,d)); y=np.sin(3*X.sum(1));"
+        "h=np.concatenate([[0.2],np.log(0.5)+0.2*rng.randn(d),[np.log(0.03)]]);"
+        "c=_lib.Context(X,y,1e-10,max_batch=16); K=c.kernel_matrix(h);"
+        "H=h+0.05*np.random.RandomState(4).randn(16,d+2); l=c.lml(H);"
+        "print(repr([float(K.sum()), float(np.abs(K).max()), float(K[5,1999]), float(K[2099,2098])] + l.tolist()))"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"BGP_KBUILD1": "1"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
+    np.testing.assert_array_equal(outs[0], outs[1])
