@@ -54,6 +54,8 @@ SIGNATURES = {
     "bgp_kernel_matrix": (C.c_int, [_vp, _dp, _dp]),
     "bgp_posterior_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp, _ip]),
     "bgp_predict_batch": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp]),
+    "bgp_acq_batch": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _ip, _dp, C.c_int, _dp]),
+    "bgp_acq_values": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, C.c_int, _ip, _dp, C.c_int, _dp]),
     "bgp_pvrs": (C.c_int, [_vp, _dp, C.c_int, _dp, C.c_int, _dp, _dp]),
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
@@ -113,6 +115,10 @@ def _p(a):
 
 def device_count():
     return int(load().bgp_device_count())
+
+
+ACQ_EI, ACQ_MEAN, ACQ_LCB, ACQ_STD = 0, 1, 2, 3  # include/bgp.h BGP_ACQ_*
+ACQ_MAX = 8
 
 
 class Context:
@@ -270,6 +276,29 @@ class Context:
         _check(self._lib.bgp_predict_batch(self._h, B, _p(H), m, _p(Xq), _p(mean), _p(var),
                                            _p(cov) if return_cov else nul), "bgp_predict_batch")
         return (mean, var, cov) if return_cov else (mean, var)
+
+    def acq(self, H_kernel, Xq, y_mean, y_std, kinds, params, n_samples):
+        """Closed-form acquisitions (ACQ_EI / ACQ_MEAN / ACQ_LCB / ACQ_STD) of the resident posteriors at Xq, averaged
+        over the draws on the device (bgp_acq_batch): (len(kinds), m)."""
+        H = self._H(H_kernel)
+        Xq = _c(np.atleast_2d(Xq))
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        params = _c(np.asarray(params, dtype=np.float64))
+        out = np.empty((len(kinds), Xq.shape[0]))
+        _check(self._lib.bgp_acq_batch(self._h, H.shape[0], _p(H), Xq.shape[0], _p(Xq), float(y_mean), float(y_std),
+                                       len(kinds), _p(kinds), _p(params), int(n_samples), _p(out)), "bgp_acq_batch")
+        return out
+
+    def acq_values(self, mu, std, kinds, params, n_samples):
+        """The same closed forms on given (B, m) mean / standard deviation rows (bgp_acq_values)."""
+        mu = _c(np.atleast_2d(mu))
+        std = _c(np.atleast_2d(std))
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        params = _c(np.asarray(params, dtype=np.float64))
+        out = np.empty((len(kinds), mu.shape[1]))
+        _check(self._lib.bgp_acq_values(self._h, mu.shape[0], mu.shape[1], _p(mu), _p(std), len(kinds), _p(kinds),
+                                        _p(params), int(n_samples), _p(out)), "bgp_acq_values")
+        return out
 
     def pvrs_prepare(self, h_kernel, has_alpha_vec):
         H = self._H(h_kernel)

@@ -64,6 +64,27 @@ class FullGPAcquisition(Acquisition, ABC):
         pass
 
 
+# Closed forms with a device implementation (include/bgp.h BGP_ACQ_*).  Set to False to keep the means / standard
+# deviations of all draws on the host and call the acquisition objects one draw at a time (tests compare both).
+DEVICE_ACQUISITIONS = True
+_ACQ_EI, _ACQ_MEAN, _ACQ_LCB, _ACQ_STD = 0, 1, 2, 3
+_ACQ_MAX = 8
+
+
+def _device_acq_spec(acq, kwargs):
+    """(kind, parameter) of an acquisition the device evaluates itself, else None.  Exact types only: a subclass
+    may redefine ``__call__``."""
+    if type(acq) is ExpectedImprovement:
+        y_opt = kwargs.get("y_opt")
+        return _ACQ_EI, (np.nan if y_opt is None else float(y_opt))
+    if type(acq) is Expectation:
+        return _ACQ_MEAN, 0.0
+    if type(acq) is LCB:
+        alpha = kwargs.get("alpha", 1.96)
+        return (_ACQ_STD, 0.0) if isinstance(alpha, str) and alpha == "inf" else (_ACQ_LCB, float(alpha))
+    return None
+
+
 def evaluate_acquisitions(X, gpr, acquisition_functions=None, n_samples=10, progress=False, random_state=None,
                           **kwargs):
     """Evaluate a set of acquisition functions on candidate points X (m, d).
@@ -92,16 +113,29 @@ def evaluate_acquisitions(X, gpr, acquisition_functions=None, n_samples=10, prog
     has_unc = any(isinstance(a, UncertaintyAcquisition) for a in acqs)
     has_smp = any(isinstance(a, SampleAcquisition) for a in acqs)
     rows = gpr.chain_[trace_i]
+    on_device = {}
     if len(trace_i) > 0 and has_unc:
-        # ONE batched posterior build + ONE batched predict for all hyper-posterior draws
-        mus, stds = gpr._predict_hyper_samples(rows, X, noise_zero=True)
+        specs = [(j, _device_acq_spec(a, kwargs)) for j, a in enumerate(acqs) if isinstance(a, UncertaintyAcquisition)]
+        if (DEVICE_ACQUISITIONS and not getattr(gpr, "warp_inputs", False) and hasattr(gpr, "_acq_hyper_samples")
+                and len(specs) <= _ACQ_MAX and all(sp is not None for _, sp in specs)):
+            # build, predict, acquisition closed forms and the average over the draws in one device pass: the
+            # (draws x candidates) means and variances stay in HBM
+            vals = gpr._acq_hyper_samples(rows, X, [sp[0] for _, sp in specs], [sp[1] for _, sp in specs], n_samples)
+            on_device = {j: vals[k] for k, (j, _) in enumerate(specs)}
+        else:
+            # ONE batched posterior build + ONE batched predict for all hyper-posterior draws
+            mus, stds = gpr._predict_hyper_samples(rows, X, noise_zero=True)
     samples = None
     if len(trace_i) > 0 and has_smp:
         # one function realisation per draw, each from a chain row chosen by sample_y itself (bask/acquisition.py:132-136
         # -> bask/bayesgpr.py:679), with that row's kernel parameters and -- with input warping -- its own warp
         samples = gpr._sample_hyper_rows(len(trace_i), X, random_state)
+    for j, vals in on_device.items():
+        out[j] = vals
     for pos in range(len(trace_i)):
         for j, acq in enumerate(acqs):
+            if j in on_device:
+                continue
             if isinstance(acq, UncertaintyAcquisition):
                 tmp = acq(mus[pos], stds[pos], **kwargs)
             elif isinstance(acq, SampleAcquisition):

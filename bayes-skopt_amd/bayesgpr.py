@@ -652,6 +652,15 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
         if self.warp_inputs:
             return self._predict_hyper_samples_warped(np.atleast_2d(thetas), X, noise_zero)
+        Hk = self._build_hyper_samples(thetas).copy()
+        if noise_zero:
+            Hk[:, -1] = -np.inf
+        mean, var = self._ctx.predict(Hk, X)
+        mu = self.y_train_std_ * mean + self.y_train_mean_
+        return mu, np.sqrt(var * self.y_train_std_**2)
+
+    def _build_hyper_samples(self, thetas):
+        """One batched device posterior build for a set of chain rows; returns the canonical hyper-parameters."""
         H = self._canonical(np.atleast_2d(thetas))
         res = self._ctx.posterior(H, want_alpha=False)
         if np.any(res["status"] != 0):
@@ -660,12 +669,18 @@ class BayesGPR(RegressorMixin, BaseEstimator):
                 _PD_MESSAGE % self.kernel_,
                 "%d-th leading minor of the array is not positive definite" % res["status"][b],
             )
-        Hk = H.copy()
+        return H
+
+    def _acq_hyper_samples(self, thetas, X, kinds, params, n_samples, noise_zero=True):
+        """Closed-form acquisition values averaged over a batch of hyper-posterior draws, entirely on the device:
+        batched posterior build, batched predict and the acquisition / averaging pass of
+        ``evaluate_acquisitions`` (``bask/acquisition.py:112-139``) -- only (len(kinds), m) numbers come back."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        Hk = self._build_hyper_samples(thetas).copy()
         if noise_zero:
             Hk[:, -1] = -np.inf
-        mean, var = self._ctx.predict(Hk, X)
-        mu = self.y_train_std_ * mean + self.y_train_mean_
-        return mu, np.sqrt(var * self.y_train_std_**2)
+        y_mean, y_std = float(np.ravel(self.y_train_mean_)[0]), float(np.ravel(self.y_train_std_)[0])
+        return self._ctx.acq(Hk, X, y_mean, y_std, kinds, params, n_samples)
 
     def _predict_hyper_samples_warped(self, rows, X, noise_zero):
         """With input warping every hyper-posterior draw carries its own warp, i.e. its own training

@@ -358,12 +358,19 @@ __global__ void add_diag_batch_kernel(double* __restrict__ C, int ld, size_t sC,
 // Posteriors are processed in chunks of `nb` items whose scratch slices sit side by side: every launch covers the
 // whole chunk (grid.y = item), nothing synchronises inside a chunk, and the host waits once at the end of the call.
 // Results per item are the same bits as an item-by-item loop (each item's tiles are reduced in the same order).
-extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double* mean,
-                                 double* var, double* cov) {
-  if (!c || !h_kernel || !Xq || !mean || !var || m <= 0 || B <= 0) {
-    bgp_set_error("bgp_predict_batch: bad argument");
-    return BGP_ERR_INVALID;
-  }
+struct AcqPlan {  // closed-form acquisitions evaluated on the device-resident mean / variance (bgp_acq_batch)
+  int n_acq = 0;
+  const int* kinds = nullptr;
+  const double* params = nullptr;
+  double y_mean = 0.0, y_std = 1.0;
+  int n_samples = 1;
+  double* out = nullptr;  // host, n_acq * m
+};
+static int acq_run(bgp_ctx* c, hipStream_t st, int B, int m, int mpad, const double* dmean, const double* dvar,
+                   const AcqPlan& ap, double* dT, int* dbad, double* dmumin, double* dacc);
+
+static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double* mean, double* var,
+                       double* cov, const AcqPlan* ap) {
   if (B > c->post_B) {
     bgp_set_error("bgp_predict_batch: %d posteriors requested but %d resident (call bgp_posterior_batch first)", B,
                   c->post_B);
@@ -373,17 +380,20 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
   const int npad = c->npad, n = c->n, d = c->d, mpad = pad128(m);
   const size_t p = d + 2;
   const size_t per_item = (size_t)mpad * npad + 2 * (size_t)mpad + (cov ? (size_t)mpad * npad + (size_t)mpad * mpad : 0);
-  const size_t budget = (size_t)1 << 29;  // doubles of scratch per chunk (4 GiB)
+  const size_t budget = (size_t)1 << 30;  // doubles of scratch per chunk (8 GiB of the 288 GB)
   int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, budget / per_item));
-  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * per_item + 64;
+  if (chunk >= 8 && chunk < B) chunk &= ~7;  // whole rounds of the item -> XCD pinning (rowquad4_kernel)
+  const int n_acq = ap ? ap->n_acq : 0;
+  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * per_item + 2 * (size_t)B * mpad + 64 +
+                (size_t)n_acq * ((size_t)B * mpad + (size_t)B + mpad) + 2 * (size_t)B + 64;
   int rc = bgp_ensure_scratch(c, need);
   if (rc) return rc;
   Scratch s{c->dscratch, 0};
   double* dXq = s.take((size_t)m * d);
   double* dH = s.take((size_t)B * p);
   double* dKs = s.take((size_t)chunk * mpad * npad);
-  double* dq = s.take((size_t)chunk * mpad);
-  double* dout = s.take((size_t)chunk * mpad);
+  double* dqB = s.take((size_t)B * mpad);    // variance of every item (stays on the device for the acquisitions)
+  double* doutB = s.take((size_t)B * mpad);  // mean of every item
   double *dP = nullptr, *dCov = nullptr;
   if (cov) {
     dP = s.take((size_t)chunk * mpad * npad);
@@ -401,14 +411,16 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
     const double* dHc = dH + (size_t)off * p;
     const double* Kinv = c->dKinv + (size_t)off * npad * npad;  // items off .. off+nb-1 are posteriors off .. off+nb-1
     const double* al = c->dalpha_sol + (size_t)off * npad;
+    double *dq = dqB + (size_t)off * mpad, *dout = doutB + (size_t)off * mpad;
     GemmBatch gb;
     gb.nb = nb;
     rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
     if (rc) return rc;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, al,
                        (size_t)npad, (const int*)nullptr, n, m, dout, (size_t)mpad);
-    BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
-                             (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    if (mean)
+      BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
+                               (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     // q_i = k_i^T K^-1 k_i  (= rowsum((K_* K^-1) o K_*), evaluated on the lower block triangle of K^-1)
     gb.sA = sKs, gb.sB = (size_t)npad * npad, gb.sC = 0, gb.sE = sKs;
     rc = launch_rowquad(c, dKs, npad, sKs, Kinv, npad, (size_t)npad * npad, nullptr, mpad, npad, nb, dq);
@@ -435,10 +447,196 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
     hipLaunchKernelGGL(finish_var_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dq, (size_t)mpad, dHc, d,
                        c->ks.form, m, dq, (size_t)mpad);  // in place
     BGP_HIP(hipGetLastError());
-    BGP_HIP(hipMemcpy2DAsync(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
-                             (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    if (var)
+      BGP_HIP(hipMemcpy2DAsync(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
+                               (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     // (the next chunk reuses the scratch slices: stream order keeps its launches behind these copies)
   }
+  if (n_acq) {
+    double* dT = s.take((size_t)n_acq * B * mpad);
+    double* dacc = s.take((size_t)n_acq * mpad);
+    double* dmumin = s.take((size_t)B + BGP_ACQ_MAX);
+    int* dbad = reinterpret_cast<int*>(s.take((size_t)n_acq * B / 2 + BGP_ACQ_MAX));
+    rc = acq_run(c, c->stream, B, m, mpad, doutB, dqB, *ap, dT, dbad, dmumin, dacc);
+    if (rc) return rc;
+  }
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  return BGP_OK;
+}
+
+extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double* mean,
+                                 double* var, double* cov) {
+  if (!c || !h_kernel || !Xq || !mean || !var || m <= 0 || B <= 0) {
+    bgp_set_error("bgp_predict_batch: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  return predict_run(c, B, h_kernel, m, Xq, mean, var, cov, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------
+// Closed-form acquisition functions on the device (bask/acquisition.py:154-172 ExpectedImprovement, :197-201
+// Expectation, :204-216 LCB), averaged over the hyper-posterior draws exactly like evaluate_acquisitions
+// (:112-139): per draw b  tmp = acq(mu_b, std_b);  a draw whose values are not all finite contributes nothing;
+// out = sum_b tmp_b / n_samples in draw order (one thread per candidate walks the draws: no atomics on doubles).
+// mu = y_std * mean + y_mean, std = sqrt(var * y_std^2) as BayesGPR.predict returns them (skopt predict).
+// ------------------------------------------------------------------------------------------
+static __device__ __forceinline__ double acq_ndtr(double a) {
+  // Phi(a) the way scipy.special.ndtr (cephes) evaluates it: erf near 0, erfc in the tails
+  const double x = a * 0.70710678118654752440, z = fabs(x);
+  if (z < 0.70710678118654752440) return 0.5 + 0.5 * erf(x);
+  double y = 0.5 * erfc(z);
+  if (x > 0) y = 1.0 - y;
+  return y;
+}
+
+static __device__ __forceinline__ double acq_value(int kind, double param, double mu, double sd, double mumin) {
+#pragma clang fp contract(off)
+  if (kind == BGP_ACQ_MEAN) return -mu;
+  if (kind == BGP_ACQ_STD) return sd;
+  if (kind == BGP_ACQ_LCB) return param * sd - mu;
+  // expected improvement over y_opt (default: this draw's lowest mean); zero where std is not positive
+  if (!(sd > 0.0)) return 0.0;
+  const double y_opt = isnan(param) ? mumin : param;
+  const double x = (y_opt - mu) / sd;
+  const double f = x * acq_ndtr(x) + exp(-(x * x) / 2.0) / 2.5066282746310002;  // sqrt(2 pi)
+  return f * sd;
+}
+
+// np.min over one draw's means (NaN if any is NaN)
+__global__ void __launch_bounds__(256) acq_mumin_kernel(const double* __restrict__ mean, size_t smean, int m,
+                                                         double y_mean, double y_std, double* __restrict__ mumin) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double best = INFINITY;
+  int nan = 0;
+  for (int i = tid; i < m; i += 256) {
+    const double mu = y_std * mean[(size_t)b * smean + i] + y_mean;
+    if (isnan(mu)) nan = 1;
+    best = fmin(best, mu);
+  }
+  __shared__ double sb[256];
+  __shared__ int sn[256];
+  sb[tid] = best, sn[tid] = nan;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sb[tid] = fmin(sb[tid], sb[tid + o]), sn[tid] |= sn[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) mumin[b] = sn[0] ? NAN : sb[0];
+}
+
+__global__ void __launch_bounds__(256) acq_values_kernel(const double* __restrict__ mean, const double* __restrict__ var,
+                                                          size_t sm, int m, int B, double y_mean, double y_std, int n_acq,
+                                                          const int* __restrict__ kinds,
+                                                          const double* __restrict__ params,
+                                                          const double* __restrict__ mumin, double* __restrict__ T,
+                                                          int* __restrict__ bad) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= m) return;
+  const double mu = y_std * mean[(size_t)b * sm + i] + y_mean;
+  const double sd = sqrt(var[(size_t)b * sm + i] * (y_std * y_std));
+  for (int k = 0; k < n_acq; k++) {
+    const double v = acq_value(kinds[k], params[k], mu, sd, mumin[b]);
+    T[((size_t)k * B + b) * sm + i] = v;
+    if (!isfinite(v)) atomicOr(&bad[k * B + b], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) acq_sum_kernel(const double* __restrict__ T, const int* __restrict__ bad, size_t sm,
+                                                       int m, int B, int n_samples, double* __restrict__ acc) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+  if (i >= m) return;
+  double s = 0.0;
+  const double ns = (double)n_samples;
+  for (int b = 0; b < B; b++)
+    if (!bad[k * B + b]) s += T[((size_t)k * B + b) * sm + i] / ns;
+  acc[(size_t)k * sm + i] = s;
+}
+
+__global__ void acq_square_kernel(double* __restrict__ v, size_t sv, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i < m) v[(size_t)b * sv + i] *= v[(size_t)b * sv + i];
+}
+
+static int acq_run(bgp_ctx* c, hipStream_t st, int B, int m, int mpad, const double* dmean, const double* dvar,
+                   const AcqPlan& ap, double* dT, int* dbad, double* dmumin, double* dacc) {
+  // kinds / params ride in the tail of the draws' scratch (a few words)
+  int* dkinds = dbad + (size_t)ap.n_acq * B;
+  (void)c;
+  double* dparams = dmumin + B;  // (mumin slice was taken with B + slack below)
+  BGP_HIP(hipMemcpyAsync(dkinds, ap.kinds, (size_t)ap.n_acq * sizeof(int), hipMemcpyHostToDevice, st));
+  BGP_HIP(hipMemcpyAsync(dparams, ap.params, (size_t)ap.n_acq * sizeof(double), hipMemcpyHostToDevice, st));
+  BGP_HIP(hipMemsetAsync(dbad, 0, (size_t)ap.n_acq * B * sizeof(int), st));
+  hipLaunchKernelGGL(acq_mumin_kernel, dim3(B), dim3(256), 0, st, dmean, (size_t)mpad, m, ap.y_mean, ap.y_std, dmumin);
+  hipLaunchKernelGGL(acq_values_kernel, dim3((m + 255) / 256, B), dim3(256), 0, st, dmean, dvar, (size_t)mpad, m, B,
+                     ap.y_mean, ap.y_std, ap.n_acq, dkinds, dparams, dmumin, dT, dbad);
+  hipLaunchKernelGGL(acq_sum_kernel, dim3((m + 255) / 256, ap.n_acq), dim3(256), 0, st, dT, dbad, (size_t)mpad, m, B,
+                     ap.n_samples, dacc);
+  BGP_HIP(hipGetLastError());
+  BGP_HIP(hipMemcpy2DAsync(ap.out, (size_t)m * sizeof(double), dacc, (size_t)mpad * sizeof(double),
+                           (size_t)m * sizeof(double), ap.n_acq, hipMemcpyDeviceToHost, st));
+  return BGP_OK;
+}
+
+static int acq_check(const char* who, int n_acq, const int* kinds, const double* params, int n_samples, const double* out) {
+  if (n_acq <= 0 || n_acq > BGP_ACQ_MAX || !kinds || !params || !out || n_samples <= 0) {
+    bgp_set_error("%s: bad argument (1 <= n_acq <= %d)", who, BGP_ACQ_MAX);
+    return BGP_ERR_INVALID;
+  }
+  for (int k = 0; k < n_acq; k++)
+    if (kinds[k] < BGP_ACQ_EI || kinds[k] > BGP_ACQ_STD) {
+      bgp_set_error("%s: unknown acquisition kind %d", who, kinds[k]);
+      return BGP_ERR_INVALID;
+    }
+  return BGP_OK;
+}
+
+extern "C" int bgp_acq_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double y_mean,
+                             double y_std, int n_acq, const int* kinds, const double* params, int n_samples,
+                             double* out) {
+  if (!c || !h_kernel || !Xq || m <= 0 || B <= 0) {
+    bgp_set_error("bgp_acq_batch: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  int rc = acq_check("bgp_acq_batch", n_acq, kinds, params, n_samples, out);
+  if (rc) return rc;
+  AcqPlan ap;
+  ap.n_acq = n_acq, ap.kinds = kinds, ap.params = params, ap.y_mean = y_mean, ap.y_std = y_std, ap.n_samples = n_samples;
+  ap.out = out;
+  return predict_run(c, B, h_kernel, m, Xq, nullptr, nullptr, nullptr, &ap);
+}
+
+// The same closed forms on caller-supplied (mu, std) rows: B x m each, already in y units (y_mean = 0, y_std = 1).
+extern "C" int bgp_acq_values(bgp_ctx* c, int B, int m, const double* mu, const double* std_, int n_acq, const int* kinds,
+                              const double* params, int n_samples, double* out) {
+  if (!c || !mu || !std_ || m <= 0 || B <= 0) {
+    bgp_set_error("bgp_acq_values: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  int rc = acq_check("bgp_acq_values", n_acq, kinds, params, n_samples, out);
+  if (rc) return rc;
+  BGP_HIP(hipSetDevice(c->device));
+  const int mpad = pad128(m);
+  rc = bgp_ensure_scratch(c, 2 * (size_t)B * mpad + (size_t)n_acq * ((size_t)B * mpad + B + mpad) + 2 * (size_t)B + 64);
+  if (rc) return rc;
+  Scratch s{c->dscratch, 0};
+  double* dmu = s.take((size_t)B * mpad);
+  double* dvar = s.take((size_t)B * mpad);
+  double* dT = s.take((size_t)n_acq * B * mpad);
+  double* dacc = s.take((size_t)n_acq * mpad);
+  double* dmumin = s.take((size_t)B + BGP_ACQ_MAX);
+  int* dbad = reinterpret_cast<int*>(s.take((size_t)n_acq * B / 2 + BGP_ACQ_MAX));
+  BGP_HIP(hipMemcpy2DAsync(dmu, (size_t)mpad * sizeof(double), mu, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
+                           B, hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemcpy2DAsync(dvar, (size_t)mpad * sizeof(double), std_, (size_t)m * sizeof(double),
+                           (size_t)m * sizeof(double), B, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(acq_square_kernel, dim3((m + 255) / 256, B), dim3(256), 0, c->stream, dvar, (size_t)mpad, m);
+  AcqPlan ap;
+  ap.n_acq = n_acq, ap.kinds = kinds, ap.params = params, ap.n_samples = n_samples, ap.out = out;
+  rc = acq_run(c, c->stream, B, m, mpad, dmu, dvar, ap, dT, dbad, dmumin, dacc);
+  if (rc) return rc;
   BGP_HIP(hipStreamSynchronize(c->stream));
   return BGP_OK;
 }

@@ -384,16 +384,46 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 template <int T>
 __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
     rowquad4_kernel(const double* __restrict__ A, int lda, size_t sA, const double* __restrict__ Sbase, int lds_,
-                    size_t sS, const int* __restrict__ pidx, int tn, int M, double* __restrict__ part) {
+                    size_t sS, const int* __restrict__ pidx, int tn, int M, int nitems, double* __restrict__ part) {
   constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
   constexpr int NRF = T / 32;
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int b = blockIdx.y;
-  // heavy column tiles (large tj: long k range) first
-  const int tj = tn - 1 - (int)(blockIdx.x % tn), ti = blockIdx.x / tn;
+  // XCD-aware order (placement only, results unchanged).  The dispatcher puts block id on XCD id % 8: with >= 8 items
+  // item b is pinned to XCD b % 8, otherwise every item's tiles are cut into 8 contiguous runs.  Within an item the
+  // tiles go by PANELS of 256 columns of P (tj), heavy (long k range) panels first; inside a panel row tile by row
+  // tile: the S panel (<= 2 MB) stays in that XCD's L2 for all row tiles and the 256/T workgroups sharing a row tile
+  // of A run together (A streams from HBM once per panel instead of once per column tile and XCD).
+  constexpr int PWQ = 256 / T;
+  const int tm = M / T, tiles = tm * tn;
+  int b, t;
+  {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    if (nitems >= 8) {
+      const int mrow = q / tiles;
+      t = q - mrow * tiles;
+      b = 8 * mrow + x;
+    } else {
+      const int chunk = (tiles + 7) / 8;
+      b = q / chunk;
+      t = x * chunk + (q - b * chunk);
+    }
+    if (b >= nitems || t >= tiles) return;
+  }
+  int ti, tj;
+  {
+    const int np = (tn + PWQ - 1) / PWQ, wl = tn - PWQ * (np - 1);  // the last panel may be narrower
+    if (t < tm * wl) {
+      ti = t / wl;
+      tj = tn - 1 - (t - ti * wl);
+    } else {
+      const int u = t - tm * wl, pp = u / (PWQ * tm), rem = u - pp * (PWQ * tm);
+      ti = rem / PWQ;
+      tj = PWQ * (np - 2 - pp) + (PWQ - 1) - (rem - ti * PWQ);
+    }
+  }
   const double* Ab = A + (size_t)b * sA + (size_t)(ti * T) * lda;
   const double* Sb = Sbase + (size_t)(pidx ? pidx[b] : b) * sS + (size_t)(tj * T) * lds_;
   unsigned voffA[T / 32], voffS[T / 32];
@@ -469,15 +499,12 @@ int bgp_rowquad_tile() {
 }
 void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
                         const int* pidx, int M, int n, int nb, double* part) {
-  if (bgp_rowquad_tile() == 64) {
-    const int tn = n / 64, tm = M / 64;
-    hipLaunchKernelGGL(rowquad4_kernel<64>, dim3(tm * tn, nb), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M,
-                       part);
-  } else {
-    const int tn = n / 128, tm = M / 128;
-    hipLaunchKernelGGL(rowquad4_kernel<128>, dim3(tm * tn, nb), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M,
-                       part);
-  }
+  const int T = bgp_rowquad_tile(), tn = n / T, tm = M / T, tiles = tm * tn;
+  const int grid = (nb >= 8) ? 8 * ((nb + 7) / 8) * tiles : 8 * ((tiles + 7) / 8) * nb;
+  if (T == 64)
+    hipLaunchKernelGGL(rowquad4_kernel<64>, dim3(grid), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M, nb, part);
+  else
+    hipLaunchKernelGGL(rowquad4_kernel<128>, dim3(grid), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M, nb, part);
 }
 
 #ifdef S4_BENCH  // ablation / trace instantiations for tools/syrk4_bench.hip (not in the product library)

@@ -151,6 +151,26 @@ int bgp_predict_batch(bgp_ctx* ctx, int B, const double* h_kernel, int m, const 
                       double* var, double* cov);
 
 /*
+ * Closed-form acquisition functions averaged over the B resident posteriors (hyper-posterior draws), evaluated
+ * on the device right behind the batched predict so that the B*m means and variances never cross PCIe.
+ * For acquisition k (kinds[k], params[k]) and draw b, with mu = y_std * mean + y_mean, std = sqrt(var * y_std^2):
+ *   BGP_ACQ_EI    std * (x Phi(x) + phi(x)), x = (y_opt - mu) / std, 0 where std <= 0; y_opt = params[k], or the
+ *                 draw's lowest mu when params[k] is NaN          (bask/acquisition.py:154-172)
+ *   BGP_ACQ_MEAN  -mu                                              (Expectation, :197-201)
+ *   BGP_ACQ_LCB   params[k] * std - mu                             (LCB, :204-216)
+ *   BGP_ACQ_STD   std                                              (LCB with alpha = "inf")
+ * out[k*m + i] = sum over the draws, in order, of value / n_samples; a draw whose values are not all finite
+ * contributes nothing (evaluate_acquisitions, bask/acquisition.py:112-139).  h_kernel as in bgp_predict_batch.
+ * bgp_acq_values applies the same closed forms to caller-supplied mu / std (B*m each, y units).
+ */
+enum { BGP_ACQ_EI = 0, BGP_ACQ_MEAN = 1, BGP_ACQ_LCB = 2, BGP_ACQ_STD = 3 };
+#define BGP_ACQ_MAX 8
+int bgp_acq_batch(bgp_ctx* ctx, int B, const double* h_kernel, int m, const double* Xq, double y_mean, double y_std,
+                  int n_acq, const int* kinds, const double* params, int n_samples, double* out);
+int bgp_acq_values(bgp_ctx* ctx, int B, int m, const double* mu, const double* std_, int n_acq, const int* kinds,
+                   const double* params, int n_samples, double* out);
+
+/*
  * PVRS inner loop with the resident posterior built by bgp_pvrs_prepare (K without the candidate
  * row):  for every candidate i
  *   covs[i] = sum_t k_t,aug^T K_aug,i^-1 k_t,aug ,   K_aug,i = kernel([X_train; x_i])
