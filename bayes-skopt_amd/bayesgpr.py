@@ -312,25 +312,36 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         """Vectorised ``_log_prob_fn`` (``bask/bayesgpr.py:351-379``): sum of priors (host) + LML
         (device) for a (Ns, p) block; non-finite -> -inf.  With ``warp_inputs`` the last 2d columns are
         the Beta-CDF parameters of each walker's own input warp (``:353-365``)."""
+        return self._log_prob_finish(self._log_prob_begin(Theta, priors, warp_priors))
+
+    def _log_prob_begin(self, Theta, priors, warp_priors=None):
+        """First half of ``_log_prob_batch``: put the block's LML batch on the device and return at once with the
+        priors of the same block (evaluated while the device factorises)."""
         Theta = np.atleast_2d(Theta)
         if self.warp_inputs:
             d = self._X_train_.shape[1]
             Tgp, W = Theta[:, : Theta.shape[1] - 2 * d], Theta[:, Theta.shape[1] - 2 * d :]
-            lp = _eval_priors(priors, Tgp) + _eval_warp_priors(warp_priors, W, d)
-            with np.errstate(invalid="ignore"):
-                lp = lp + self._ctx.lml_warped(self._canonical(Tgp), W)
+            return _eval_priors(priors, Tgp) + _eval_warp_priors(warp_priors, W, d), (self._canonical(Tgp), W), False
+        H = self._canonical(Theta)
+        submitted = self._ctx.lml_submit(H)
+        try:
+            lp = _eval_priors(priors, Theta)
+        except BaseException:
+            if submitted:
+                self._ctx.lml_wait()
+            raise
+        return lp, H, submitted
+
+    def _log_prob_finish(self, token):
+        lp, H, submitted = token
+        if submitted:
+            lml = self._ctx.lml_wait()
+        elif self.warp_inputs:
+            lml = self._ctx.lml_warped(*H)
         else:
-            # the device factorises while the host evaluates the priors of the same block
-            H = self._canonical(Theta)
-            submitted = self._ctx.lml_submit(H)
-            try:
-                lp = _eval_priors(priors, Theta)
-            finally:
-                lml = self._ctx.lml_wait() if submitted else None
-            if lml is None:
-                lml = self._ctx.lml(H)
-            with np.errstate(invalid="ignore"):
-                lp = lp + lml
+            lml = self._ctx.lml(H)
+        with np.errstate(invalid="ignore"):
+            lp = lp + lml
         lp[~np.isfinite(lp)] = -np.inf
         return lp
 
@@ -414,7 +425,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             nwalkers=n_walkers,
             ndim=n_dim,
             log_prob_fn=distributed.shard_log_prob(self._log_prob_batch) if self.shard_ensemble
-            else self._log_prob_batch,
+            else _AsyncLogProb(self),
             kwargs=dict(priors=priors, warp_priors=warp_priors),
             threads=n_threads,
             **kwargs,
@@ -834,6 +845,23 @@ def _eval_warp_priors(warp_priors, W, d):
         for k in range(d):
             lp += np.array([float(warp_priors(a, b)) for a, b in zip(A[:, k], Bm[:, k])])
     return lp
+
+
+class _AsyncLogProb:
+    """``log_prob_fn`` of the ensemble sampler: callable like ``_log_prob_batch`` and, for the sampler's overlap of
+    its own bookkeeping with the device, split into ``begin`` (enqueue) / ``finish`` (collect)."""
+
+    def __init__(self, gp):
+        self._gp = gp
+
+    def __call__(self, Theta, priors, warp_priors=None):
+        return self._gp._log_prob_batch(Theta, priors, warp_priors)
+
+    def begin(self, Theta, priors, warp_priors=None):
+        return self._gp._log_prob_begin(Theta, priors, warp_priors)
+
+    def finish(self, token):
+        return self._gp._log_prob_finish(token)
 
 
 def _vec_call(fn, col):

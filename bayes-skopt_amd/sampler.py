@@ -78,22 +78,49 @@ class EnsembleSampler:
         self.naccepted = np.zeros(self.nwalkers, dtype=np.int64)
         self.n_log_prob_evals = 0
 
-    def compute_log_prob(self, coords):
+    def _check_coords(self, coords):
         p = np.asarray(coords, dtype=np.float64)
-        if np.any(np.isinf(p)):
-            raise ValueError("At least one parameter value was infinite")
-        if np.any(np.isnan(p)):
+        if not np.all(np.isfinite(p)):
+            if np.any(np.isinf(p)):
+                raise ValueError("At least one parameter value was infinite")
             raise ValueError("At least one parameter value was NaN")
-        if self.vectorize:
-            lp = np.asarray(self.log_prob_fn(p, *self.args, **self.kwargs), dtype=np.float64)
-        else:
-            lp = np.array([float(self.log_prob_fn(row, *self.args, **self.kwargs)) for row in p])
-        if lp.shape != (p.shape[0],):
-            raise ValueError(f"log_prob_fn returned shape {lp.shape}, expected ({p.shape[0]},)")
+        return p
+
+    def _check_log_prob(self, lp, n):
+        lp = np.asarray(lp, dtype=np.float64)
+        if lp.shape != (n,):
+            raise ValueError(f"log_prob_fn returned shape {lp.shape}, expected ({n},)")
         if np.any(np.isnan(lp)):
             raise ValueError("Probability function returned NaN")
-        self.n_log_prob_evals += p.shape[0]
+        self.n_log_prob_evals += n
         return lp
+
+    def compute_log_prob(self, coords):
+        p = self._check_coords(coords)
+        if self.vectorize:
+            lp = self.log_prob_fn(p, *self.args, **self.kwargs)
+        else:
+            lp = np.array([float(self.log_prob_fn(row, *self.args, **self.kwargs)) for row in p])
+        return self._check_log_prob(lp, p.shape[0])
+
+    def _half_step_plans(self, nsteps):
+        """Everything of a half-step that comes from the generator alone, in emcee's stream order: per step the move
+        selection and the red/blue shuffle, per half-step the stretch factors and the partner draw.  None of it depends
+        on a log-probability, so run_mcmc pulls the next plan while the device still works on the current block."""
+        rng, a = self._random, self.a
+        all_inds = np.arange(self.nwalkers)
+        for _ in range(nsteps):
+            rng.choice(1, p=[1.0])  # move selection among a single StretchMove
+            inds = all_inds % 2
+            rng.shuffle(inds)
+            for split in (0, 1):
+                movers = np.flatnonzero(inds == split)
+                others = np.flatnonzero(inds != split)
+                Ns, Nc = movers.shape[0], others.shape[0]
+                zz = ((a - 1.0) * rng.rand(Ns) + 1.0) ** 2.0 / a
+                factors = (self.ndim - 1.0) * np.log(zz)
+                partners = others[rng.randint(Nc, size=(Ns,))]
+                yield movers, partners, zz[:, None], factors
 
     def run_mcmc(self, initial_state, nsteps, progress=False, skip_initial_state_check=False, log_prob0=None):
         coords = np.array(initial_state, dtype=np.float64, copy=True)
@@ -116,29 +143,34 @@ class EnsembleSampler:
         chain = np.empty((nsteps, self.nwalkers, self.ndim))
         lps = np.empty((nsteps, self.nwalkers))
         rng = self._random
-        all_inds = np.arange(self.nwalkers)
-        a = self.a
+        # a log_prob_fn with begin()/finish() takes the block asynchronously (BayesGPR: the device factorises while
+        # the host goes on); any other callable is evaluated in place.  The generator is consumed in the same order
+        # either way: proposal draws, accept draws, next half-step's draws.
+        begin = getattr(self.log_prob_fn, "begin", None) if self.vectorize else None
+        finish = getattr(self.log_prob_fn, "finish", None) if begin is not None else None
+        plans = self._half_step_plans(nsteps)
+        plan = next(plans, None)
         pbar = _progress(progress, nsteps)
         for step in range(nsteps):
-            rng.choice(1, p=[1.0])  # move selection among a single StretchMove
-            inds = all_inds % 2
-            rng.shuffle(inds)
-            for split in (0, 1):
-                S1 = inds == split
-                s = coords[S1]
-                c = coords[~S1]
-                Ns, Nc = s.shape[0], c.shape[0]
-                zz = ((a - 1.0) * rng.rand(Ns) + 1.0) ** 2.0 / a
-                factors = (self.ndim - 1.0) * np.log(zz)
-                rint = rng.randint(Nc, size=(Ns,))
-                cr = c[rint]
-                q = cr - (cr - s) * zz[:, None]
-                new_lp = self.compute_log_prob(q)  # <- one batched device call
-                lnpdiff = factors + new_lp - log_prob[S1]
-                with np.errstate(divide="ignore"):
-                    logu = np.log(rng.rand(Ns))  # same stream as Ns scalar draws
-                acc = lnpdiff > logu
-                idx = all_inds[S1][acc]
+            for _split in (0, 1):
+                movers, partners, zz, factors = plan
+                Ns = movers.shape[0]
+                s = coords[movers]
+                cr = coords[partners]
+                q = cr - (cr - s) * zz
+                if finish is not None:
+                    token = begin(self._check_coords(q), *self.args, **self.kwargs)  # <- one batched device call
+                else:
+                    new_lp = self.compute_log_prob(q)
+                try:
+                    with np.errstate(divide="ignore"):
+                        logu = np.log(rng.rand(Ns))  # same stream as Ns scalar draws
+                    plan = next(plans, None)
+                finally:
+                    if finish is not None:
+                        new_lp = self._check_log_prob(finish(token), Ns)
+                acc = factors + new_lp - log_prob[movers] > logu
+                idx = movers[acc]
                 coords[idx] = q[acc]
                 log_prob[idx] = new_lp[acc]
                 self.naccepted[idx] += 1

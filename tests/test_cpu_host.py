@@ -177,6 +177,31 @@ def test_sampler_matches_oracle_sampler_bitwise(bask):
     coords, log_prob, rstate = st
     assert coords.shape == (12, p) and log_prob.shape == (12,)
 
+    # a log_prob_fn with begin()/finish() (BayesGPR's device batch) gets the block asynchronously: the sampler draws the
+    # accept uniforms and the NEXT half-step's stretch factors / partners in between -- same stream order, same chain,
+    # and the generator ends in the same state (nothing drawn past the last half-step)
+    class Split:
+        calls = 0
+
+        def __call__(self, Xb):
+            return lp_vec(Xb)
+
+        def begin(self, Xb):
+            Split.calls += 1
+            return np.array(Xb)
+
+        def finish(self, token):
+            return lp_vec(token)
+
+    s2 = bask.sampler.EnsembleSampler(12, p, Split())
+    s2.random_state = np.random.RandomState(5).get_state()
+    st2 = s2.run_mcmc(p0, 30)
+    st2 = s2.run_mcmc(st2.coords, 20, log_prob0=st2.log_prob)  # resumed like BayesGPR.sample with pos_
+    assert Split.calls == 100
+    np.testing.assert_array_equal(s2.get_chain(), chain_o)
+    np.testing.assert_array_equal(s2.naccepted, nacc)
+    assert s2._random.rand() == s._random.rand()
+
 
 def test_sampler_preconditions(bask):
     s = bask.sampler.EnsembleSampler(4, 3, lambda X: np.zeros(len(X)))
