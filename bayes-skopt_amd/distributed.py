@@ -153,20 +153,35 @@ def init_process_group(backend=None, device=None):
     if not name:
         # librccl loads (or not) identically on every rank of a node: a consistent choice without any exchange
         name = ("rccl" if _lib.comm_available() else "nccl") if ndev > 0 else "gloo"
+    explicit = bool(backend or os.environ.get("BGP_DIST_BACKEND"))
     if name == "rccl":
         if ndev < 1:
             raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")
         dev = (local_rank % ndev) if device is None else int(device)
-        uid = _exchange_unique_id(rank, ws)
-        _state["comm"] = _lib.Comm(dev, rank, ws, uid)
-    else:
+        try:
+            uid = _exchange_unique_id(rank, ws)
+            _state["comm"] = _lib.Comm(dev, rank, ws, uid)
+        except Exception as exc:
+            # ncclCommInitRank is collective: it fails on every rank or on none.  When the backend was not asked for
+            # by name, the job goes on with the launcher's own store and gloo (the only exchange is the final gather of
+            # the chains: host memory either way); an explicit BGP_DIST_BACKEND=rccl fails loudly.
+            if explicit:
+                raise
+            import sys
+
+            print(f"[bayes_skopt_amd.distributed] rank {rank}: native RCCL group failed ({exc}); using gloo",
+                  file=sys.stderr, flush=True)
+            name = "gloo"
+    if name != "rccl":
+        import datetime
+
         import torch
 
         dist = _torch_dist()
         if not dist.is_initialized():
             if name == "nccl":
                 torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-            dist.init_process_group(backend=name, rank=rank, world_size=ws)
+            dist.init_process_group(backend=name, rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=300))
     _state.update(backend=name, rank=rank, world=ws)
     return rank, local_rank, ws
 
