@@ -20,6 +20,9 @@ Backends (``BGP_DIST_BACKEND`` or the ``backend`` argument):
             ``BGP_COMM_PORT`` overrides the port; MASTER_PORT itself belongs to the launcher's rendezvous store).
   ``gloo`` / ``nccl`` -- ``torch.distributed`` process groups: the CPU tests (world size 2 over gloo) and an A/B
             path for the native one; torch is only imported when one of these is selected.
+When no backend is named and the native group cannot be formed (librccl missing, id exchange timed out,
+ncclCommInitRank refused the group) every rank reports it on stderr and the job continues over gloo: the only exchange
+on the default path is the final gather of host-resident chains.  A backend asked for by name fails loudly instead.
 ``BGP_DIST_FORCE=1`` joins a group even at world size 1 (the GPU test that runs real RCCL collectives on one GPU).
 """
 import os

@@ -121,3 +121,35 @@ def test_unique_id_rendezvous(tmp_path, tcp):
         assert p.wait(timeout=120) == 0
     for r in range(3):
         assert open(tmp_path / f"uid{r}.bin", "rb").read() == bytes(range(128))
+
+
+def test_group_falls_back_to_gloo_when_the_native_group_cannot_form(tmp_path):
+    """No backend named and the native RCCL communicator cannot be created (here: patched to raise on both ranks, as
+    ncclCommInitRank does collectively): the ranks say so on stderr and form a gloo group over the launcher's store;
+    with BGP_DIST_BACKEND=rccl the same failure is an error."""
+    code = (
+        "import os, sys, json; sys.path.insert(0, %r); import numpy as np; import bayes_skopt_amd;"
+        "from bayes_skopt_amd import _lib, distributed;"
+        "_lib.device_count = lambda: 1; _lib.comm_available = lambda: True;\n"
+        "def boom(*a, **k): raise RuntimeError('ncclCommInitRank failed: invalid usage')\n"
+        "distributed._exchange_unique_id = boom\n"
+        "r, lr, ws = distributed.init_process_group()\n"
+        "out = distributed.gather_chains(np.full((3, 2), float(r)))\n"
+        "json.dump({'backend': distributed.backend(), 'rows': out[:, 0].tolist()}, open(os.path.join(%r, 'fb%%d.json' %% r), 'w'))\n"
+        "distributed.barrier(); distributed.destroy_process_group()\n"
+    ) % (ROOT, str(tmp_path))
+    script = tmp_path / "fallback_worker.py"
+    script.write_text(code)
+    base = {k: v for k, v in os.environ.items() if k != "BGP_DIST_BACKEND"}
+    base.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    res = subprocess.run(cmd, env=base, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stderr.count("native RCCL group failed") == 2
+    for k in range(2):
+        d = json.load(open(tmp_path / f"fb{k}.json"))
+        assert d["backend"] == "gloo" and d["rows"] == [0.0] * 3 + [1.0] * 3
+    res = subprocess.run(cmd[:-1] + [str(script)], env=dict(base, BGP_DIST_BACKEND="rccl"), capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode != 0 and "invalid usage" in res.stderr
