@@ -392,37 +392,31 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
   // XCD-aware order (placement only, results unchanged).  The dispatcher puts block id on XCD id % 8: with >= 8 items
-  // item b is pinned to XCD b % 8, otherwise every item's tiles are cut into 8 contiguous runs.  Within an item the
-  // tiles go by PANELS of 256 columns of P (tj), heavy (long k range) panels first; inside a panel row tile by row
-  // tile: the S panel (<= 2 MB) stays in that XCD's L2 for all row tiles and the 256/T workgroups sharing a row tile
-  // of A run together (A streams from HBM once per panel instead of once per column tile and XCD).
+  // item b is pinned to XCD b % 8 and that XCD walks all of its row tiles; with fewer items XCD x takes the row tiles
+  // ti = x (mod 8) of every item (equal work per XCD).  Within that set the tiles go by PANELS of 256 columns of P
+  // (tj), heavy (long k range) panels first; inside a panel row tile by row tile: the S panel (<= 2 MB) stays in the
+  // XCD's L2 for all row tiles and the 256/T workgroups sharing a row tile of A run together (A streams from HBM once
+  // per panel instead of once per column tile and XCD).
   constexpr int PWQ = 256 / T;
-  const int tm = M / T, tiles = tm * tn;
-  int b, t;
+  const int tm = M / T;
+  int b, ti, tj;
   {
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    if (nitems >= 8) {
-      const int mrow = q / tiles;
-      t = q - mrow * tiles;
-      b = 8 * mrow + x;
-    } else {
-      const int chunk = (tiles + 7) / 8;
-      b = q / chunk;
-      t = x * chunk + (q - b * chunk);
-    }
-    if (b >= nitems || t >= tiles) return;
-  }
-  int ti, tj;
-  {
+    const int tmx = (nitems >= 8) ? tm : (tm + 7) / 8;  // row tiles in this XCD's share of an item
+    const int tiles = tmx * tn;
+    const int mrow = q / tiles, t = q - mrow * tiles;
+    b = (nitems >= 8) ? 8 * mrow + x : mrow;
     const int np = (tn + PWQ - 1) / PWQ, wl = tn - PWQ * (np - 1);  // the last panel may be narrower
-    if (t < tm * wl) {
+    if (t < tmx * wl) {
       ti = t / wl;
       tj = tn - 1 - (t - ti * wl);
     } else {
-      const int u = t - tm * wl, pp = u / (PWQ * tm), rem = u - pp * (PWQ * tm);
+      const int u = t - tmx * wl, pp = u / (PWQ * tmx), rem = u - pp * (PWQ * tmx);
       ti = rem / PWQ;
       tj = PWQ * (np - 2 - pp) + (PWQ - 1) - (rem - ti * PWQ);
     }
+    if (nitems < 8) ti = 8 * ti + x;
+    if (b >= nitems || ti >= tm) return;
   }
   const double* Ab = A + (size_t)b * sA + (size_t)(ti * T) * lda;
   const double* Sb = Sbase + (size_t)(pidx ? pidx[b] : b) * sS + (size_t)(tj * T) * lds_;
@@ -500,7 +494,7 @@ int bgp_rowquad_tile() {
 void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
                         const int* pidx, int M, int n, int nb, double* part) {
   const int T = bgp_rowquad_tile(), tn = n / T, tm = M / T, tiles = tm * tn;
-  const int grid = (nb >= 8) ? 8 * ((nb + 7) / 8) * tiles : 8 * ((tiles + 7) / 8) * nb;
+  const int grid = (nb >= 8) ? 8 * ((nb + 7) / 8) * tiles : 8 * ((tm + 7) / 8) * tn * nb;
   if (T == 64)
     hipLaunchKernelGGL(rowquad4_kernel<64>, dim3(grid), dim3(256), 0, st, A, lda, sA, S, lds_, sS, pidx, tn, M, nb, part);
   else
