@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
-"""Timeline of the last N kernels of a rocprofv3 results .db: name, duration, gap to the previous kernel's end.
-Usage: rocprof_gaps.py <results.db> [N]"""
+"""Idle time between consecutive kernels of a rocprofv3 --kernel-trace results .db:
+rocprof_gaps.py <results.db> [last-N-kernels]  ->  span, busy (union of kernel intervals), per-kernel-name gap BEFORE it."""
 import sqlite3
 import sys
+from collections import defaultdict
 
-db = sys.argv[1]
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-cur = sqlite3.connect(db).cursor()
-cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-rows = cur.execute(f"select {name_col}, start, end from kernels order by start").fetchall()
-rows = rows[-N:]
-prev_end = None
-tot_k = tot_gap = 0
+con = sqlite3.connect(sys.argv[1])
+rows = con.execute("select name, start, end from kernels order by start").fetchall()
+n = int(sys.argv[2]) if len(sys.argv) > 2 else len(rows)
+rows = rows[-n:]
+span = rows[-1][2] - rows[0][1]
+busy, cur_end = 0, rows[0][1]
+gap_by = defaultdict(lambda: [0, 0.0])
+dur_by = defaultdict(lambda: [0, 0.0])
 for name, s, e in rows:
-    gap = (s - prev_end) / 1e3 if prev_end is not None else 0.0
-    print(f"{name.split('(')[0][-40:]:40s} dur {(e - s) / 1e3:8.2f} us   gap {gap:8.2f} us")
-    tot_k += e - s
-    if prev_end is not None and gap < 200:
-        tot_gap += max(s - prev_end, 0)
-    prev_end = e
-print(f"sum kernel {tot_k / 1e3:.1f} us, sum gaps(<200us) {tot_gap / 1e3:.1f} us, span {(rows[-1][2] - rows[0][1]) / 1e3:.1f} us")
+    short = name.split("(")[0].split("<")[0][-28:]
+    if s > cur_end:
+        g = gap_by[short]
+        g[0] += 1
+        g[1] += s - cur_end
+    busy += max(0, e - max(s, cur_end))
+    cur_end = max(cur_end, e)
+    d = dur_by[short]
+    d[0] += 1
+    d[1] += e - s
+print(f"kernels {len(rows)}  span {span/1e3:.1f} us  busy {busy/1e3:.1f} us  idle {(span-busy)/1e3:.1f} us")
+for k in sorted(dur_by, key=lambda k: -dur_by[k][1]):
+    g = gap_by.get(k, [0, 0.0])
+    print(f"{k:30s} calls {dur_by[k][0]:6d}  time {dur_by[k][1]/1e3:10.1f} us  gap before: {g[1]/1e3:9.1f} us over {g[0]} "
+          f"({(g[1]/g[0]/1e3 if g[0] else 0):.2f} us each)")
