@@ -167,6 +167,8 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->use_small_split = (envss && atoi(envss) != 0) ? 1 : 0;
     const char* envk = getenv("BGP_KBUILD1");
     c->use_kbuild1 = (envk && atoi(envk) != 0) ? 1 : 0;
+    const char* envf = getenv("BGP_FUSED_GRAM");
+    c->fused_gram = (envf && atoi(envf) != 0) ? 1 : 0;
     const char* envt = getenv("BGP_TWO_PANEL");
     c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
     c->panels = c->two_panel ? 2 : 1;
@@ -323,6 +325,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = BGP_OK;
     const bool fused_small = c->nblk == 1 && !warp && !c->left_looking && !c->use_small_split;
+    const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->left_looking && !c->use_syrk2 && !c->use_kbuild1;
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {
       // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
@@ -334,13 +337,25 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
                              hipMemcpyHostToDevice, c->stream));
       rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
       if (rc) return rc;
-      rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
-      if (rc) return rc;
-      rc = bgp_launch_cholesky(c, nb, 0);
+      if (fused_gram) {
+        S4Gen gen;
+        rc = bgp_launch_kbuild_col0(c, 0, nb, c->stream, 1, c->dXwB, nd, &gen);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky_gen(c, 0, nb, c->stream, 0, &gen);
+      } else {
+        rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky(c, nb, 0);
+      }
       if (rc) return rc;
     } else if (ng == 1) {
       if (c->left_looking) {
         rc = bgp_launch_cholesky_ll_slice(c, 0, nb, c->stream, 1);
+      } else if (fused_gram) {
+        S4Gen gen;
+        rc = bgp_launch_kbuild_col0(c, 0, nb, c->stream, 1, c->dXeff, 0, &gen);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky_gen(c, 0, nb, c->stream, 0, &gen);
       } else {
         rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
         if (rc) return rc;
@@ -355,6 +370,11 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
         if (c->left_looking) {
           rc = bgp_launch_cholesky_ll_slice(c, o, gb, st, 1);
+        } else if (fused_gram) {
+          S4Gen gen;
+          rc = bgp_launch_kbuild_col0(c, o, gb, st, 1, c->dXeff, 0, &gen);
+          if (rc) return rc;
+          rc = bgp_launch_cholesky_gen(c, o, gb, st, 0, &gen);
         } else {
           rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
           if (rc) return rc;

@@ -779,7 +779,7 @@ extern "C" void bgp_debug_launch_syrk2(hipStream_t st, int B8, int ntile, double
 
 // LDS-DMA pipelined trailing update (bgp_syrk4.hip): the default of the LML path; BGP_SYRK2=1 selects syrk2_kernel
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
-                      int K, int jstart, int colmode, int B);
+                      int K, int jstart, int colmode, int B, const S4Gen* gen);
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
@@ -815,6 +815,12 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
 }
 
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
+  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr);
+}
+
+// gen != nullptr (LML path only): the matrices hold block column 0 only (bgp_launch_kbuild_col0); the trailing updates
+// of the FIRST group of block columns -- the first launches to touch any other tile -- generate the Gram entries.
+int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -857,7 +863,7 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
           if (ctx->use_syrk2)
             launch_syrk2(st, B8, nblk - (k + j + 1), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
           else
-            bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
+            bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
           bgp_tend(ctx, st);
         }
       }
@@ -867,7 +873,7 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
         if (ctx->use_syrk2)
           launch_syrk2(st, B8, nt * (nt + 1) / 2, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         else
-          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
+          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B, k == 0 ? gen : nullptr);
         bgp_tend(ctx, st);
       }
       k += np;

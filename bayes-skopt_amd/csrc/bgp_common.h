@@ -62,6 +62,7 @@ struct bgp_ctx {
   size_t cap_xs = 0;
   int use_small_split = 0;   // env BGP_SMALL_SPLIT=1: no fused n <= 128 kernel (A/B measurements)
   int use_kbuild1 = 0;       // env BGP_KBUILD1=1: the unpipelined Gram build (A/B measurements)
+  int fused_gram = 0;        // env BGP_FUSED_GRAM=1: Gram tiles generated inside the first trailing update that touches them
   double* dy = nullptr;      // npad (zero padded)
   double* dalpha = nullptr;  // npad
   size_t cap_n = 0;          // capacity (rows) of the three buffers above
@@ -144,7 +145,20 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
 
 // ---- kernels launched across translation units ----
 // K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).
+// Gram generation inside the first trailing update that touches a tile (bgp_syrk4.hip): everything a tile needs to
+// produce its own K entries instead of loading them.  Xs = k-major scaled inputs of the batch slice (xscale_kernel).
+struct S4Gen {
+  const double* Xs = nullptr;     // B x dpad x npad
+  const double* alpha = nullptr;  // n diagonal terms (or nullptr)
+  const double* H = nullptr;      // B x (d + 2) canonical hyper-parameters
+  int n = 0, d = 0, npad = 0, dpad = 0;
+  int stat = 0, form = 0;         // kernel family (template dispatch)
+};
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha);
+// scaled inputs + block column 0 of the Gram matrices only; fills `gen` for the trailing updates that generate the rest
+int bgp_launch_kbuild_col0(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha, const double* dXb, size_t xstride,
+                           S4Gen* gen);
+int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen);
 // same for the slice [off, off+B) of the current batch on an explicit stream
 int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
                             int use_alpha);

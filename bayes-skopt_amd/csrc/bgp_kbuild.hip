@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64 * KB2_WAVES, 2) kbuild2_kernel(const double
                                                        const double* __restrict__ y, double* __restrict__ yw, int n,
                                                        int d, int npad, int dpad, int nblk, int B, int full, int ld,
                                                        int use_alpha) {
-  const int ntiles = full ? nblk * nblk : nblk * (nblk + 1) / 2;
+  const int ntiles = (full == 2) ? nblk : full ? nblk * nblk : nblk * (nblk + 1) / 2;  // full == 2: block column 0 only
   const int ngroups = (ntiles + KB2_TPW - 1) / KB2_TPW;
   int b, g;
   bgp_map_block(blockIdx.x, ngroups, B, b, g);
@@ -236,7 +236,10 @@ __global__ void __launch_bounds__(64 * KB2_WAVES, 2) kbuild2_kernel(const double
   const int t0 = g * KB2_TPW, t1 = min(t0 + KB2_TPW, ntiles), nkb = dpad / KB_DK;
   const int nchunks = (t1 - t0) * nkb;
   auto decode = [&](int t, int& ti, int& tj) {
-    if (full) {
+    if (full == 2) {
+      ti = t;
+      tj = 0;
+    } else if (full) {
       ti = t / nblk;
       tj = t - ti * nblk;
     } else {
@@ -255,7 +258,8 @@ __global__ void __launch_bounds__(64 * KB2_WAVES, 2) kbuild2_kernel(const double
       for (int r = 0; r < KB2_R; r++)
 #pragma unroll
         for (int cc = 0; cc < 8; cc++) acc[r][cc] = 0.0;
-      if (ti == tj && tid < 128) yw[(size_t)b * ld + ti * 128 + tid] = y[ti * 128 + tid];  // working right-hand side
+      if ((ti == tj || full == 2) && tid < 128)
+        yw[(size_t)b * ld + ti * 128 + tid] = y[ti * 128 + tid];  // working right-hand side
     }
     S4_WAIT_VM0();                 // this wave's share of chunk c has landed
     __builtin_amdgcn_s_barrier();  // ... everybody's has; everybody finished reading chunk c-1
@@ -295,6 +299,21 @@ __global__ void __launch_bounds__(64 * KB2_WAVES, 2) kbuild2_kernel(const double
   }
 }
 
+static int ensure_xs(bgp_ctx* ctx, int dpad) {
+  const size_t need = (size_t)ctx->max_batch * dpad * ctx->npad;
+  if (need > ctx->cap_xs) {
+    if (ctx->dXs) {
+      (void)hipDeviceSynchronize();  // (another walker group's launches may still read the old buffer)
+      (void)hipFree(ctx->dXs);
+    }
+    ctx->dXs = nullptr;
+    ctx->cap_xs = 0;
+    BGP_HIP(hipMalloc(&ctx->dXs, need * sizeof(double)));
+    ctx->cap_xs = need;
+  }
+  return BGP_OK;
+}
+
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha) {
   return bgp_launch_kbuild_slice(ctx, 0, B, ctx->stream, full_square, augmented, use_alpha);
 }
@@ -324,16 +343,9 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   } else {
     // scaled inputs of the walkers of this batch slice, k-major (grown on demand; one slot per walker of max_batch)
     const int dpad = ((d + KB_DK - 1) / KB_DK) * KB_DK;
-    const size_t need = (size_t)ctx->max_batch * dpad * npad;
-    if (need > ctx->cap_xs) {
-      if (ctx->dXs) {
-        (void)hipDeviceSynchronize();  // (another walker group's launches may still read the old buffer)
-        (void)hipFree(ctx->dXs);
-      }
-      ctx->dXs = nullptr;
-      ctx->cap_xs = 0;
-      BGP_HIP(hipMalloc(&ctx->dXs, need * sizeof(double)));
-      ctx->cap_xs = need;
+    {
+      const int rcx = ensure_xs(ctx, dpad);
+      if (rcx) return rcx;
     }
     double* dXs = ctx->dXs + (size_t)off * dpad * npad;
     hipLaunchKernelGGL(xscale_kernel, dim3(64, B), dim3(256), 0, st, dXb, xstride, dH, dXs, ctx->n, d, npad, dpad);
@@ -344,6 +356,35 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   }
   bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
+  return BGP_OK;
+}
+
+// LML path with Gram generation fused into the trailing updates: only block column 0 (what potrf(0) / trsm(0) read) is
+// built here; every other tile is produced by the first trailing update that touches it (bgp_syrk4.hip, S4Gen).
+int bgp_launch_kbuild_col0(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha, const double* dXb, size_t xstride,
+                           S4Gen* gen) {
+  const int nblk = ctx->nblk, npad = ctx->npad, d = ctx->d;
+  const int B8 = 8 * ((B + 7) / 8);
+  const int dpad = ((d + KB_DK - 1) / KB_DK) * KB_DK;
+  int rc = ensure_xs(ctx, dpad);
+  if (rc) return rc;
+  double* dKo = ctx->dK + (size_t)off * npad * npad;
+  const double* dH = ctx->dh + (size_t)off * (d + 2);
+  double* dywo = ctx->dyw + (size_t)off * npad;
+  double* dXs = ctx->dXs + (size_t)off * dpad * npad;
+  bgp_tbegin(ctx, 0, st);
+  hipLaunchKernelGGL(xscale_kernel, dim3(64, B), dim3(256), 0, st, dXb, xstride, dH, dXs, ctx->n, d, npad, dpad);
+  const int ngroups = (nblk + KB2_TPW - 1) / KB2_TPW;
+  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+              hipLaunchKernelGGL((kbuild2_kernel<S, F>), dim3(B8 * ngroups), dim3(64 * KB2_WAVES), 0, st, dXs, ctx->dalpha,
+                                 dH, dKo, ctx->dy, dywo, ctx->n, d, npad, dpad, nblk, B, 2, npad, use_alpha));
+  bgp_tend(ctx, st);
+  BGP_HIP(hipGetLastError());
+  gen->Xs = dXs;
+  gen->alpha = use_alpha ? ctx->dalpha : nullptr;
+  gen->H = dH;
+  gen->n = ctx->n, gen->d = d, gen->npad = npad, gen->dpad = dpad;
+  gen->stat = ctx->ks.stationary, gen->form = ctx->ks.form;
   return BGP_OK;
 }
 

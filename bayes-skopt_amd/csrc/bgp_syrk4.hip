@@ -106,6 +106,7 @@ struct S4Tile {
   const double* XA;  // rows of block I, panel columns
   const double* XB;  // rows of block J
   double* C;
+  int b, gi0, gj0;  // batch slot, first matrix row / column of the tile (Gram generation)
   int q;      // position in the launch's tile list (>= total: none)
   int diag;   // I == J: X_I is both operands; only the lower triangle is updated
   int label;  // I * 1000 + J (bench timeline)
@@ -121,11 +122,83 @@ struct S4Tile {
     }                                                                    \
   } while (0)
 
+// Gram entries of a wave's NR x NC block, produced in the accumulator layout instead of being loaded: the FIRST trailing
+// update that touches a tile of K builds it (scaled inputs Xs are k-major and L2-resident: 256 KB per matrix at
+// config C), so the Gram matrix is never written and read back except for block column 0.  Same arithmetic as the
+// Gram kernels (bgp_kbuild.hip: differences squared and summed in dimension order with one fma each, then
+// kb_epilogue's expressions without implicit contraction): bit-identical K.  OPT-IN (BGP_FUSED_GRAM=1): measured on
+// MI355X the generation is NOT hidden under the other workgroups' MFMAs -- a VALU instruction costs the fp64 MFMA its
+// issue slots (tools/mfma_interleave_probe.hip) -- so only the saved HBM round trip of K shows: 15.6 vs 15.9 ms per step
+// at config C, while the trailing update's own launches get 11 % longer; small batches lose 2-5 %.
+template <int NR, int NC, int CREL, int STAT, int FORM>
+static __device__ __forceinline__ void s4_gen_c(const S4Gen& g, const S4Tile& cur, d4 (&acc)[NR][NC], int r0, int c0,
+                                                int lane) {
+  const double* Xs_b = g.Xs + (size_t)cur.b * g.dpad * g.npad;
+  const double* h = g.H + (size_t)cur.b * (g.d + 2);
+#pragma unroll
+  for (int i = 0; i < NR; i++)
+#pragma unroll
+    for (int j = 0; j < NC; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* pa = Xs_b + cur.gi0 + r0 + (lane >> 4);
+  const double* pb = Xs_b + cur.gj0 + c0 + (lane & 15);
+#pragma unroll 2
+  for (int k = 0; k < g.d; k++) {
+    double a[NR][4], bb[NC];
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) a[i][r] = pa[16 * i + 4 * r];
+#pragma unroll
+    for (int j = 0; j < NC; j++) bb[j] = pb[16 * j];
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        if (j + CREL > i) continue;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const double df = a[i][r] - bb[j];
+          acc[i][j][r] = fma(df, df, acc[i][j][r]);
+        }
+      }
+    pa += g.npad;
+    pb += g.npad;
+  }
+  {
+#pragma clang fp contract(off)
+    const double cst = exp(h[0]), s2 = exp(h[g.d + 1]);
+    const bool interior = !cur.diag && cur.gi0 + 64 <= g.n && cur.gj0 + 64 <= g.n;  // (T <= 64 rows / columns per wave block)
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        if (j + CREL > i) continue;
+        const int gj = cur.gj0 + GK_COLB(c0, j, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = cur.gi0 + GK_ROWB(r0, i, lane, r);
+          double v;
+          if (!interior && (gi >= g.n || gj >= g.n)) {
+            v = (gi == gj) ? 1.0 : 0.0;  // identity padding
+          } else if (!interior && gi == gj) {
+            const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+            v = base + s2;
+            if (g.alpha) v += g.alpha[gi];
+          } else {
+            const double sv = kb_stationary<STAT>(acc[i][j][r]);
+            v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+          }
+          acc[i][j][r] = v;
+        }
+      }
+  }
+}
+
 // One tile for a wave's NR x NC block at (r0, c0) of the T x T workgroup tile.
-template <int T, int NR, int NC, int CREL, int VAR>
+template <int T, int NR, int NC, int CREL, int VAR, int GEN = 0, int STAT = 0, int FORM = 0>
 static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsigned lds0, const S4Tile& cur,
                                                const unsigned (&voff)[T / 32], int ld, int K, int r0, int c0, int w,
-                                               int lane) {
+                                               int lane, const S4Gen& gen) {
   constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
   unsigned pa[4], pb[4];
   s4_frag_addr(pa, lds0, r0, lane);
@@ -138,7 +211,10 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
   }
   // The empty asm makes hipcc wait for its C loads HERE (its in-order vmcnt wait also covers chunk 0, needed
   // next anyway) instead of at their first use inside the loop, where such a wait would drain the LDS-DMA queue.
-  gk_load_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
+  if (GEN)
+    s4_gen_c<NR, NC, CREL, STAT, FORM>(gen, cur, acc, r0, c0, lane);
+  else
+    gk_load_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
 #pragma unroll
   for (int i = 0; i < NR; i++)
 #pragma unroll
@@ -210,6 +286,7 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
   d.XA = d.XB = nullptr;
   d.C = nullptr;
   d.diag = 0;
+  d.b = d.gi0 = d.gj0 = 0;
   d.label = 0;
   d.q = total;
   do {
@@ -232,16 +309,20 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
     d.XB = M + rowJ * ld + kp * 128;
     d.C = M + rowI * ld + rowJ;
     d.diag = (ti == tj);
+    d.b = b;
+    d.gi0 = (int)rowI;
+    d.gj0 = (int)rowJ;
     d.label = ti * 1000 + tj;
     d.q = q;
   } while (0);
   return d;
 }
 
-template <int T, int VAR>
+template <int T, int VAR, int GEN = 0, int STAT = 0, int FORM = 0>
 __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
     syrk4_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp,
-                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace, int pw) {
+                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace, int pw,
+                 S4Gen gen) {
   constexpr unsigned STAGEB = 2 * T * S4_ROWB;
   constexpr int NRF = T / 32;  // MFMA tiles per wave and direction (each wave a T/2 x T/2 block)
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
@@ -261,28 +342,34 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
   }
   S4_STAMP(0);
   if (!cur.diag) {
-    s4_tile<T, NRF, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane);
+    s4_tile<T, NRF, NRF, -64, VAR, GEN, STAT, FORM>(trace, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane, gen);
   } else if (w < 2) {
     // Diagonal tile: only its lower triangle is ever read again.  Waves 0 / 1: the two (T/2)^2 triangles on the
     // diagonal; waves 2 / 3: the square below the diagonal cut into two row halves (3/3/2/2 MFMA tiles at T = 64).
-    s4_tile<T, NRF, NRF, 0, VAR>(trace, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane);
+    s4_tile<T, NRF, NRF, 0, VAR, GEN, STAT, FORM>(trace, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane, gen);
   } else {
-    s4_tile<T, NRF / 2, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane);
+    s4_tile<T, NRF / 2, NRF, -64, VAR, GEN, STAT, FORM>(trace, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane, gen);
   }
   S4_STAMP(3);
   if ((VAR & 4) && trace && threadIdx.x == 0) trace[(size_t)cur.q * 8 + 7] = wall_clock64();
 }
 
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
-                      int K, int jstart, int colmode, int B) {
+                      int K, int jstart, int colmode, int B, const S4Gen* gen) {
   const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
   static int pw = 0;
   if (!pw) {
     const char* e = getenv("BGP_PANEL_WIDTH");  // tile columns per L2-resident column panel (s4_panel_decode)
     pw = (e && atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : S4_PW;
   }
+  if (gen) {  // first touch of these tiles: they generate their Gram entries instead of loading them
+    KB_DISPATCH(gen->stat, gen->form,
+                hipLaunchKernelGGL((syrk4_kernel<64, 0, 1, S, F>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                                   nblk, kp, K, jstart, colmode, B, total, nullptr, pw, *gen));
+    return;
+  }
   hipLaunchKernelGGL((syrk4_kernel<64, 0>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
-                     colmode, B, total, nullptr, pw);
+                     colmode, B, total, nullptr, pw, S4Gen());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -510,7 +597,7 @@ extern "C" int bgp_debug_launch_syrk4(int T, int var, hipStream_t st, int B8, do
 #define S4_CASE(TT, V)                                                                                               \
   if (T == TT && var == V) {                                                                                         \
     hipLaunchKernelGGL((syrk4_kernel<TT, V>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,    \
-                       jstart, colmode, B, total, trace, S4_PW);                                                     \
+                       jstart, colmode, B, total, trace, S4_PW, S4Gen());                                            \
     return total;                                                                                                    \
   }
   S4_CASE(128, 0) S4_CASE(128, 4) S4_CASE(64, 0) S4_CASE(64, 1) S4_CASE(64, 2) S4_CASE(64, 3) S4_CASE(64, 4)

@@ -212,7 +212,7 @@ int bgp_sample_y_batch(bgp_ctx* ctx, int B, const int* pidx, const double* h_ker
  * chain is as long as the whole batch's, nothing to gain).  This call, or the environment variable
  * BGP_STREAMS read at context creation, forces a fixed group count.  Other environment switches read at
  * context creation: BGP_PANELS (block columns per trailing update; default 4 from n = 1536, else 2), and the experimental
- * BGP_TWO_PANEL=0, BGP_SYRK2=1, BGP_LEFT_LOOKING=1, BGP_KBUILD1=1, BGP_SMALL_SPLIT=1. */
+ * BGP_TWO_PANEL=0, BGP_SYRK2=1, BGP_LEFT_LOOKING=1, BGP_KBUILD1=1, BGP_SMALL_SPLIT=1, BGP_FUSED_GRAM=1. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */

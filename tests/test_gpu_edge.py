@@ -129,8 +129,9 @@ def test_predict_interpolates_smooth_training_points_with_tiny_noise(lib):
 
 
 def test_left_looking_and_single_panel_variants_agree(lib, O):
-    """The experimental left-looking update (fused K-generation, 4x4x4 MFMA) and the single-panel
-    right-looking schedule must give the same LML as the default two-panel schedule."""
+    """The experimental left-looking update (fused K-generation, 4x4x4 MFMA), the single-panel right-looking schedule,
+    other group / panel counts, round 1's kernels and the Gram generation fused into the trailing update must give
+    the same LML as the default schedule."""
     import os
     import subprocess
     import sys
@@ -143,12 +144,15 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
-                {"BGP_PANELS": "4"}, {"BGP_SYRK2": "1"}):
+                {"BGP_PANELS": "4"}, {"BGP_SYRK2": "1"}, {"BGP_FUSED_GRAM": "1"}, {"BGP_FUSED_GRAM": "1", "BGP_PANELS": "4"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
     for o in outs[1:]:
         np.testing.assert_allclose(o, outs[0], rtol=1e-9)
+    # Gram tiles generated inside the first trailing update that touches them: the same K bits, hence the same LML bits
+    np.testing.assert_array_equal(outs[7], outs[0])
+    np.testing.assert_array_equal(outs[8], outs[5])
     rng = np.random.RandomState(5)
     X = rng.uniform(size=(700, 6))
     y = np.sin(3 * X.sum(1))
