@@ -48,6 +48,48 @@ def trailing_flops_per_launch(n, nb=NB):
     return [nb * (n - j * nb) * (n - j * nb + 1) for j in range(1, n // nb)]
 
 
+def live_pmc_traffic(kernel_sub="syrk4_kernel", timeout_s=240):
+    """HBM bytes per launch of the trailing-update kernel, collected NOW: two child runs of this script's hot path
+    (`--steps 1 --warmup 1 --no-extras`, one stream) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `... --pmc WRITE_SIZE` (separate passes, MI355X_MICROARCH.md section HBM), FETCH_SIZE x 2 (gfx950 correction for
+    wide coalesced reads) + WRITE_SIZE, counters in KiB.  None when rocprofv3 is missing or a pass fails."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None
+    per_launch = {}
+    env = dict(os.environ, BGP_STREAMS="1", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bgp_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras"]
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+            if res.returncode != 0 or not dbs:
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                               "group by kernel_name", (counter,)).fetchall()
+            cnt = sum(c for name, c, _ in rows if kernel_sub in name)
+            tot = sum(v for name, _, v in rows if kernel_sub in name)
+            if cnt == 0:
+                return None
+            per_launch[counter] = (tot / cnt, cnt)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    fetch_kb, write_kb = per_launch["FETCH_SIZE"][0], per_launch["WRITE_SIZE"][0]
+    return {"traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0, "fetch_size_kb_raw": fetch_kb,
+            "write_size_kb_raw": write_kb, "launches_averaged": per_launch["FETCH_SIZE"][1]}
+
+
 def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -224,6 +266,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the config C hot path (no fit(), no config D, no CPU baselines): what the rocprofv3 "
                     "passes of tools/profile_round.sh run, so that their per-kernel numbers are config C's alone")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect roofline.traffic with two rocprofv3 --pmc child passes (~25 s); use the "
+                    "committed profiles/r02_pmc_traffic.json instead")
     ap.add_argument("--shard", choices=("chains", "ensemble"), default="chains",
                     help="chains (default): independent 256-walker sub-ensemble per GPU, weak scaling, no collective in "
                     "the loop; ensemble: ONE 256-walker ensemble, each half-step's 128 proposals split over the GPUs + "
@@ -323,11 +368,20 @@ def main():
     syrk_ms, syrk_launches = acc["syrk"]
     flops_per_call = float(sum(fl)) * B
     achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC passes (cannot be collected without rocprofv3)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["traffic_bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_source = None, None
+    if rank == 0 and ws == 1 and not args.no_extras and not args.no_live_pmc:
+        live = live_pmc_traffic()
+        if live:
+            traffic = live["traffic_bytes_per_launch"]
+            traffic_source = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this run "
+                              "(%d launches; FETCH_SIZE %.0f KiB raw x 2 + WRITE_SIZE %.0f KiB)"
+                              % (live["launches_averaged"], live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
+    if traffic is None:
+        try:  # the committed PMC passes of tools/profile_round.sh
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["traffic_bytes_per_launch"]
+            traffic_source = "profiles/r02_pmc_traffic.json (committed passes of tools/profile_round.sh)"
+        except Exception:
+            pass
     # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated
     mfma_measured = None
     if not args.no_extras:  # (the rocprofv3 passes run --no-extras: their kernel tables hold the hot path only)
@@ -347,14 +401,15 @@ def main():
         "unit": "TFLOP/s",
         "frac": achieved / peak,
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
         "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
         "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
         "peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
-        "MI355X_MICROARCH.md has no fp64 row; traffic = bytes per launch from profiles/r02_pmc_traffic.json "
-        "(rocprofv3 FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes)",
+        "MI355X_MICROARCH.md has no fp64 row; traffic = HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
+        "+ WRITE_SIZE, separate passes; see traffic_source)",
     }
 
     evals = W * args.steps * (1 if ensemble else ws)

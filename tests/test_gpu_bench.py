@@ -44,6 +44,9 @@ def test_bench_single_gpu_line():
     # peak = min(datasheet, measured on the box), both stated
     assert r["peak"] == min(r["peak_spec"], r["mfma_peak_measured"]) and 60.0 < r["mfma_peak_measured"] < 90.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    # HBM bytes per launch: collected by two rocprofv3 --pmc child passes of this very run when the profiler is there
+    # (else the committed passes); the algorithmic C round trip alone is 0.45 GB per launch
+    assert r["traffic_source"].startswith(("live", "profiles/")) and 0.45e9 < r["traffic"] < 2.0e9
     assert "workload" in d["config"] and "model" not in d["config"]
     n4 = d["roofline_n4096"]  # the north star's own target: >= 40 % of fp64 peak on the trailing update at n = 4096
     assert n4["lml_finite"] and n4["peak"] == r["peak"] and 0.4 < n4["frac"] < 1.0
