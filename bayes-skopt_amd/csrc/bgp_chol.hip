@@ -7,16 +7,20 @@
 // using  y^T K^-1 y = z^T z  with  z = L^-1 y  (one forward substitution, fused into the panel
 // kernels; the back substitution is only needed for posterior builds, bgp_post.hip).
 //
-// Per outer step k (block size NB = 128), three launches batched over the B walkers:
+// Block size NB = 128; per block column k, batched over the B walkers:
 //   potrf_kernel  one workgroup per walker: diagonal block in LDS -> L_kk, W_kk = L_kk^-1,
-//                 z_k = W_kk y_k, running log-det and z^T z                         (LDS-bound)
-//   trsm_kernel   one workgroup per 128-row panel block:  X_i = A_ik W_kk^T  (fp64 MFMA),
-//                 y_i -= X_i z_k                                                   (MFMA)
-//   syrk_kernel   one workgroup per trailing 128x128 tile: A_ij -= X_i X_j^T   (fp64 MFMA;
-//                 the n^3/3 bulk -- the kernel the roofline fraction is quoted on)
-// All three share one NT tile GEMM on v_mfma_f64_16x16x4_f64: 4 waves as 2x2, each wave a 64x64
-// sub-tile = 4x4 MFMA tiles (128 accumulator VGPRs), operands staged through LDS in 128x32
-// chunks with leading dimension 34 (conflict-free ds_read_b64 for the 16-row x 2-k lane pattern).
+//                 z_k = W_kk y_k, running log-det and z^T z                    (latency: 128 sequential pivots)
+//   panel solve   X_i = A_ik W_kk^T  (fp64 MFMA),  y_i -= X_i z_k
+//   trailing upd. A_ij -= X_i X_j^T  (fp64 MFMA; the n^3/3 bulk -- the kernel the roofline fraction is quoted on)
+// Two generations of the last two live here:
+//   * LML path (bgp_lml_batch; the MCMC hot loop): trsm4_kernel / syrk4_kernel on the LDS-DMA ring (bgp_syrk4.hip),
+//     scheduled in groups of P block columns by bgp_launch_cholesky_gen below (BGP_SYRK2=1: round 1's syrk2_kernel +
+//     trsm8_kernel, kept as the bit-identical A/B reference);
+//   * posterior builds on the augmented matrix (bgp_post.hip; once per sample(), per hyper-posterior draw of an
+//     acquisition and per gradient evaluation): trsm_kernel / syrk_kernel of this file -- one NT tile GEMM on
+//     v_mfma_f64_16x16x4_f64, 4 waves as 2x2, each wave a 64x64 sub-tile = 4x4 MFMA tiles (128 accumulator VGPRs),
+//     operands staged through LDS in 128x32 chunks with leading dimension 34 (conflict-free ds_read_b64 for the
+//     16-row x 2-k lane pattern), single-panel right-looking steps with the active-row remap of bgp_rowblk.
 #include "bgp_common.h"
 #include "bgp_device.h"
 
