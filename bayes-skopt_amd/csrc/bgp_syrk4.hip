@@ -408,17 +408,19 @@ __global__ void __launch_bounds__(256, 3)
   d4 acc[1][8];
 #pragma unroll
   for (int j = 0; j < 8; j++) acc[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  s4_issue<64>(A, voffA, 0, lds0, w);
-  s4_issue<128>(W, voffW, 0, lds0 + AOPB, w);
+  if (!(VAR & 1)) {
+    s4_issue<64>(A, voffA, 0, lds0, w);
+    s4_issue<128>(W, voffW, 0, lds0 + AOPB, w);
+  }
   for (int c = 0; c < 8; c += 2) {
 #pragma unroll
     for (int s = 0; s < 2; s++) {
       S4_WAIT_VM0();
       __builtin_amdgcn_s_barrier();
-      if (c + s + 1 < 8) {
+      if (!(VAR & 1) && c + s + 1 < 8) {
         const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
         s4_issue<64>(A, voffA, (c + s + 1) * S4_KC, nb, w);
-        s4_issue<128>(W, voffW, (c + s + 1) * S4_KC, nb + AOPB, w);
+        if (!(VAR & 16)) s4_issue<128>(W, voffW, (c + s + 1) * S4_KC, nb + AOPB, w);
       }
       s4_mma<1, 8, -64, VAR, 0>(pa, pb, s * STAGEB, acc, c + s);
       __builtin_amdgcn_sched_barrier(0);
@@ -439,7 +441,7 @@ __global__ void __launch_bounds__(256, 3)
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const double x = acc[0][j][r];
-      A[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
+      if (!(VAR & 8)) A[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
       part += x * zc[j];
     }
     part += __shfl_xor(part, 1);
@@ -589,6 +591,20 @@ void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, con
 }
 
 #ifdef S4_BENCH  // ablation / trace instantiations for tools/syrk4_bench.hip (not in the product library)
+// trsm4 ablations (tools/trsm4_bench.hip): var bit 0 = no LDS-DMA, 1 = no MFMA, 3 = no stores, 4 = W staged once only
+extern "C" int bgp_debug_launch_trsm4(int var, hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus,
+                                      int ld, size_t mstride, int ystride, int nblk, int k) {
+  const int B8 = 8 * ((B + 7) / 8);
+  const dim3 grid(B8 * 2 * (nblk - k - 1));
+#define T4_CASE(V)                                                                                                  \
+  if (var == V) {                                                                                                   \
+    hipLaunchKernelGGL(trsm4_kernel<V>, grid, dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, B); \
+    return (int)grid.x;                                                                                             \
+  }
+  T4_CASE(0) T4_CASE(1) T4_CASE(2) T4_CASE(3) T4_CASE(8) T4_CASE(16) T4_CASE(10) T4_CASE(11)
+  return 0;
+}
+
 extern "C" int bgp_debug_launch_syrk4(int T, int var, hipStream_t st, int B8, double* dK, const int* dstatus, int ld,
                                       size_t mstride, int nblk, int kp, int K, int jstart, int colmode, int B,
                                       unsigned long long* trace) {
