@@ -171,6 +171,8 @@ int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq
 // the same for nb hyper-vectors dH (nb x (d+2)) into dout + b * ostride
 int bgp_launch_kcross_batch(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
                             double* dout, int ldo, size_t ostride);
+int bgp_launch_kcross_matvec(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
+                             double* dout, int ldo, size_t ostride, const double* vec, size_t svec, double* dpart);
 // Blocked Cholesky of the B matrices in dK (in place) + forward substitution + LML.
 // Beta-CDF warp of n x d inputs for B parameter sets (bgp_warp.hip)
 int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* dW, double* dout, int n, int B,

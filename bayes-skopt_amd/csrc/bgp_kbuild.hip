@@ -34,7 +34,9 @@ static __device__ __forceinline__ void kb_epilogue(double (&acc)[R][8], int na, 
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         const double s = kb_stationary<STAT>(acc[r][c]);
-        orow[16 * c] = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+        const double v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
+        orow[16 * c] = v;
+        if (!GRAM) acc[r][c] = v;  // (cross builds: the caller may go on with the values, see kbuild_cross_kernel)
       }
     }
     return;
@@ -55,6 +57,7 @@ static __device__ __forceinline__ void kb_epilogue(double (&acc)[R][8], int na, 
           v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
         }
         out[(size_t)gi * ldo + gj] = v;
+        acc[r][c] = v;
       }
       continue;
     }
@@ -88,13 +91,12 @@ static __device__ __forceinline__ void kbuild_tile(const double* __restrict__ A,
                                                    const double* __restrict__ Bm, int nb, int d,
                                                    const double* __restrict__ h, const double* __restrict__ alpha,
                                                    int i0, int j0, double* __restrict__ out, size_t ldo, int out_rows,
-                                                   int out_cols) {
+                                                   int out_cols, double (&acc)[8][8]) {
   __shared__ double xi[KB_DK][BGP_TILE_LD];
   __shared__ double xj[KB_DK][BGP_TILE_LD];
   __shared__ double ell[KB_DK];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  double acc[8][8];
 #pragma unroll
   for (int r = 0; r < 8; r++)
 #pragma unroll
@@ -158,19 +160,48 @@ __global__ void __launch_bounds__(256) kbuild_gram_kernel(const double* __restri
   // working right-hand side of walker b (becomes z = L^-1 y during the factorisation)
   if (ti == tj && threadIdx.x < 128) yw[(size_t)b * ld + ti * 128 + threadIdx.x] = y[ti * 128 + threadIdx.x];
   const double* Xb = X + (size_t)b * xstride;  // per-walker warped inputs (xstride == 0: shared)
+  double acc[8][8];
   kbuild_tile<1, STAT, FORM>(Xb, n, Xb, n, d, h, use_alpha ? alpha : nullptr, ti * 128, tj * 128, out, (size_t)ld, npad,
-                             npad);
+                             npad, acc);
 }
 
-// blockIdx.y = item of a batch: hyper-parameters h + b (d+2), output out + b ostride (the inputs are shared)
+// blockIdx.y = item of a batch: hyper-parameters h + b (d+2), output out + b ostride (the inputs are shared).
+// vec != nullptr: the tile also contributes to the matrix-vector product  out_b vec_b  (the posterior mean K_* alpha
+// of BayesGPR.predict) while its values are still in registers: dpart[(b tiles_j + tj) mpad + row] = the tile's 128-column
+// share of the row's dot product (16 lanes share a row: fixed shuffle order); the caller adds the column tiles in
+// order (rowdot_reduce_kernel) -- no second pass over K_*, no floating-point atomics.
 template <int STAT, int FORM>
 __global__ void __launch_bounds__(256) kbuild_cross_kernel(const double* __restrict__ Xq, int m,
                                                             const double* __restrict__ Xt, int n, int d,
                                                             const double* __restrict__ h, double* __restrict__ out,
-                                                            int ldo, int tiles_j, size_t ostride) {
+                                                            int ldo, int tiles_j, size_t ostride,
+                                                            const double* __restrict__ vec, size_t svec,
+                                                            double* __restrict__ dpart, int mpad) {
   const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j, b = blockIdx.y;
+  double acc[8][8];
   kbuild_tile<0, STAT, FORM>(Xq, m, Xt, n, d, h + (size_t)b * (d + 2), nullptr, ti * 128, tj * 128,
-                             out + (size_t)b * ostride, (size_t)ldo, m, n);
+                             out + (size_t)b * ostride, (size_t)ldo, m, n, acc);
+  if (vec) {
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const double* vb = vec + (size_t)b * svec;
+    double vv[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const int gj = tj * 128 + tx + 16 * c;
+      vv[c] = (gj < n) ? vb[gj] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) s += acc[r][c] * vv[c];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      if (tx == 0) dpart[((size_t)b * tiles_j + tj) * mpad + ti * 128 + ty + 16 * r] = s;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -395,10 +426,16 @@ int bgp_launch_kcross(bgp_ctx* ctx, const double* dh_b, int m, const double* dXq
 
 int bgp_launch_kcross_batch(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
                             double* dout, int ldo, size_t ostride) {
+  return bgp_launch_kcross_matvec(ctx, nb, dH, m, dXq, nx, dXt, dout, ldo, ostride, nullptr, 0, nullptr);
+}
+
+// ... and, with vec, the column-tile partials of  out_b vec_b  into dpart (nb x tiles_j x pad128(m))
+int bgp_launch_kcross_matvec(bgp_ctx* ctx, int nb, const double* dH, int m, const double* dXq, int nx, const double* dXt,
+                             double* dout, int ldo, size_t ostride, const double* vec, size_t svec, double* dpart) {
   const int tiles_i = (m + 127) / 128, tiles_j = (nx + 127) / 128;
   KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
               hipLaunchKernelGGL((kbuild_cross_kernel<S, F>), dim3(tiles_i * tiles_j, nb), dim3(256), 0, ctx->stream, dXq,
-                                 m, dXt, nx, ctx->d, dH, dout, ldo, tiles_j, ostride));
+                                 m, dXt, nx, ctx->d, dH, dout, ldo, tiles_j, ostride, vec, svec, dpart, tiles_i * 128));
   BGP_HIP(hipGetLastError());
   return BGP_OK;
 }

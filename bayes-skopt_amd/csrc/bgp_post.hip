@@ -384,7 +384,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
   int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, budget / per_item));
   if (chunk >= 8 && chunk < B) chunk &= ~7;  // whole rounds of the item -> XCD pinning (rowquad4_kernel)
   const int n_acq = ap ? ap->n_acq : 0;
-  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * per_item + 2 * (size_t)B * mpad + 64 +
+  size_t need = (size_t)m * d + 2 + (size_t)B * p + 2 + (size_t)chunk * per_item + 2 * (size_t)B * mpad + 64 + (size_t)chunk * (npad / 128) * mpad +
                 (size_t)n_acq * ((size_t)B * mpad + (size_t)B + mpad) + 2 * (size_t)B + 64;
   int rc = bgp_ensure_scratch(c, need);
   if (rc) return rc;
@@ -392,6 +392,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
   double* dXq = s.take((size_t)m * d);
   double* dH = s.take((size_t)B * p);
   double* dKs = s.take((size_t)chunk * mpad * npad);
+  double* dmpart = s.take((size_t)chunk * (npad / 128) * mpad);  // column-tile partials of the means
   double* dqB = s.take((size_t)B * mpad);    // variance of every item (stays on the device for the acquisitions)
   double* doutB = s.take((size_t)B * mpad);  // mean of every item
   double *dP = nullptr, *dCov = nullptr;
@@ -414,10 +415,11 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
     double *dq = dqB + (size_t)off * mpad, *dout = doutB + (size_t)off * mpad;
     GemmBatch gb;
     gb.nb = nb;
-    rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
+    // K_* and, from the same registers, the column-tile partials of the mean K_* alpha (added in tile order below)
+    rc = bgp_launch_kcross_matvec(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs, al, (size_t)npad, dmpart);
     if (rc) return rc;
-    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, al,
-                       (size_t)npad, (const int*)nullptr, n, m, dout, (size_t)mpad);
+    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((mpad + 255) / 256, nb), dim3(256), 0, c->stream, dmpart, npad / 128, mpad,
+                       dout);
     if (mean)
       BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
                                (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
