@@ -91,6 +91,9 @@ struct bgp_ctx {
   size_t cap_rowpart = 0;
   size_t cap_scratch = 0;
   // asynchronous LML batch (bgp_lml_batch_submit / _wait): pinned result buffers and the pending batch size
+  double* hstage = nullptr;  // pinned staging of the training set (bgp_ctx_update_data)
+  size_t cap_stage = 0;
+  double* hh = nullptr;      // pinned copy of the submitted hyper-parameter block
   double* hlml = nullptr;
   int* hstatus = nullptr;
   size_t cap_pinned = 0;

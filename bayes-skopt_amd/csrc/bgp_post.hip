@@ -106,6 +106,7 @@ struct GemmBatch {  // per-item strides (doubles) of a batched launch; pidxB map
   size_t sA = 0, sB = 0, sC = 0, sE = 0;
   const int* pidxB = nullptr;
   int nb = 1;
+  int lower_only = 0;  // square outputs that only a Cholesky reads: tiles above the diagonal are skipped
 };
 
 template <int EPI>
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__
                                                        const double* __restrict__ E, int lde,
                                                        double* __restrict__ rowdot, int tiles_n, GemmBatch gb) {
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
+  if (gb.lower_only && tj > ti) return;
   {
     const int b = blockIdx.y;
     A += (size_t)b * gb.sA;
@@ -1047,8 +1049,10 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, dKss, mpad, 0))) break;
     hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dKss, mpad, m,
                        std::exp(h_kernel[d + 1]));
-    // cov = K_** - P K_*^T straight into the child's matrix
-    if ((rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, dKss, mpad, nullptr))) break;
+    // cov = K_** - P K_*^T straight into the child's matrix (lower tiles: all the factorisation reads)
+    GemmBatch gl;
+    gl.lower_only = 1;
+    if ((rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, dKss, mpad, nullptr, gl))) break;
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
     SY(hipMemsetAsync(w->dyw, 0, (size_t)mpad * sizeof(double), c->stream));
     SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
@@ -1196,7 +1200,7 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, w->dK, mpad, sCv, m, dHc,
                        d);
     GemmBatch gc;
-    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv;
+    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv, gc.lower_only = 1;
     rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, w->dK, mpad, nullptr, gc);
     if (rc) return rc;
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(256, nb), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
