@@ -990,6 +990,36 @@ static void free_child(bgp_ctx* w) {
 
 static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out);
 
+// out[r] = mean + L z[r] for ALL draws r of one posterior: one wave per row of the lower factor, which is read once
+// (the draws' normal vectors stay in L2); rows of z / out have stride ldz.  Fixed order: bitwise reproducible.
+#define TRI_MAXD 16
+__global__ void __launch_bounds__(256) tri_matmul_draws_kernel(const double* __restrict__ L, int mpad,
+                                                                const double* __restrict__ z, int ldz, int n_draws,
+                                                                const double* __restrict__ mean, int m,
+                                                                double* __restrict__ out) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const double* Lr = L + (size_t)row * mpad;
+  for (int r0 = 0; r0 < n_draws; r0 += TRI_MAXD) {
+    const int nd = min(TRI_MAXD, n_draws - r0);
+    double acc[TRI_MAXD];
+#pragma unroll
+    for (int r = 0; r < TRI_MAXD; r++) acc[r] = 0.0;
+    for (int j = lane; j <= row; j += 64) {
+      const double l = Lr[j];
+#pragma unroll
+      for (int r = 0; r < TRI_MAXD; r++)
+        if (r < nd) acc[r] += l * z[(size_t)(r0 + r) * ldz + j];
+    }
+#pragma unroll
+    for (int r = 0; r < TRI_MAXD; r++) {
+      double s = acc[r];
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (r < nd && lane == 0) out[(size_t)(r0 + r) * ldz + row] = s + mean[row];
+    }
+  }
+}
+
 extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                             const double* z, double jitter, double* out) {
   if (!c || !h_kernel || !Xq || !z || !out || m <= 0 || n_draws <= 0 || b < 0) {
@@ -1065,11 +1095,9 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
       rc = BGP_ERR_NOTPD;
       break;
     }
-    hipLaunchKernelGGL(zero_upper_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, mpad);
-    // out = Z L^T (+ mean)
-    if ((rc = launch_gemm_nt<0>(c, dZ, mpad, w->dK, mpad, rpad, mpad, mpad, dO, mpad, nullptr, 0, nullptr))) break;
-    hipLaunchKernelGGL(add_mean_rows_kernel, dim3((m + 255) / 256, n_draws), dim3(256), 0, c->stream, dO, mpad, dmean,
-                       m, n_draws);
+    // out = mean + L z for every draw (the factor's strict upper triangle is never read)
+    hipLaunchKernelGGL(tri_matmul_draws_kernel, dim3((m + 3) / 4), dim3(256), 0, c->stream, w->dK, mpad, dZ, mpad, n_draws,
+                       dmean, m, dO);
     SY(hipGetLastError());
     SY(hipMemcpy2DAsync(out, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
                         (size_t)m * sizeof(double), n_draws, hipMemcpyDeviceToHost, c->stream));
