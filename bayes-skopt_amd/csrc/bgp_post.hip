@@ -106,7 +106,6 @@ struct GemmBatch {  // per-item strides (doubles) of a batched launch; pidxB map
   size_t sA = 0, sB = 0, sC = 0, sE = 0;
   const int* pidxB = nullptr;
   int nb = 1;
-  int lower_only = 0;  // square outputs that only a Cholesky reads: tiles above the diagonal are skipped
 };
 
 template <int EPI>
@@ -116,7 +115,6 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__
                                                        const double* __restrict__ E, int lde,
                                                        double* __restrict__ rowdot, int tiles_n, GemmBatch gb) {
   const int ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
-  if (gb.lower_only && tj > ti) return;
   {
     const int b = blockIdx.y;
     A += (size_t)b * gb.sA;
@@ -216,6 +214,9 @@ __global__ void add_diag_kernel(double* __restrict__ C, int ld, int m, double v)
 
 void bgp_launch_rowquad(hipStream_t st, const double* A, int lda, size_t sA, const double* S, int lds_, size_t sS,
                         const int* pidx, int M, int n, int nb, double* part);
+// NT products on the LDS-DMA ring (bgp_syrk4.hip): mode 0: C = A B^T; mode 1: C -= A B^T on the lower tiles of a square C
+void bgp_launch_gemm4(hipStream_t st, int mode, const double* A, const double* Bm, int ldx, int M, int N, int K, double* C,
+                      int ldc, int nb, size_t sA, size_t sB, size_t sC, const int* pidxB);
 int bgp_rowquad_tile();
 
 // out[b][i] = a_i^T S_b a_i for the rows of A_b (M x n, zero padded; S symmetric): half-product on the LDS-DMA ring
@@ -1042,8 +1043,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   w->npad = mpad;
   w->nblk = mpad / 128;
   do {
-    size_t need = (size_t)m * d + p + 2 * (size_t)mpad * npad + (size_t)mpad * mpad + 2 * (size_t)mpad +
-                  2 * (size_t)rpad * mpad + 64;
+    size_t need = (size_t)m * d + p + 2 * (size_t)mpad * npad + 2 * (size_t)mpad + 2 * (size_t)rpad * mpad + 64;
     rc = bgp_ensure_scratch(c, need);
     if (rc) break;
     Scratch s{c->dscratch, 0};
@@ -1051,7 +1051,6 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     double* dhk = s.take(p);
     double* dKs = s.take((size_t)mpad * npad);
     double* dP = s.take((size_t)mpad * npad);
-    double* dKss = s.take((size_t)mpad * mpad);
     double* dmean = s.take(mpad);
     double* dZ = s.take((size_t)rpad * mpad);
     double* dO = s.take((size_t)rpad * mpad);
@@ -1068,21 +1067,19 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     SY(hipMemcpyAsync(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (c->has_warp && (rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0))) break;
     SY(hipMemsetAsync(dKs, 0, (size_t)mpad * npad * sizeof(double), c->stream));
-    SY(hipMemsetAsync(dKss, 0, (size_t)mpad * mpad * sizeof(double), c->stream));
     SY(hipMemsetAsync(dZ, 0, (size_t)rpad * mpad * sizeof(double), c->stream));
     SY(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
                         n_draws, hipMemcpyHostToDevice, c->stream));
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0))) break;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, 1), dim3(256), 0, c->stream, dKs, npad, (size_t)0, al,
                        (size_t)0, (const int*)nullptr, n, m, dmean, (size_t)0);
-    if ((rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr))) break;
-    if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, dKss, mpad, 0))) break;
-    hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dKss, mpad, m,
+    // P = K_* K^-1, then cov = K_** - P K_*^T in the child's matrix, lower tiles only (all the factorisation reads):
+    // both products on the LDS-DMA ring (gemm4_kernel)
+    bgp_launch_gemm4(c->stream, 0, dKs, Kinv, npad, mpad, npad, npad, dP, npad, 1, 0, 0, 0, nullptr);
+    if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, w->dK, mpad, 0))) break;
+    hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, w->dK, mpad, m,
                        std::exp(h_kernel[d + 1]));
-    // cov = K_** - P K_*^T straight into the child's matrix (lower tiles: all the factorisation reads)
-    GemmBatch gl;
-    gl.lower_only = 1;
-    if ((rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, dKss, mpad, nullptr, gl))) break;
+    bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, 1, 0, 0, 0, nullptr);
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
     SY(hipMemsetAsync(w->dyw, 0, (size_t)mpad * sizeof(double), c->stream));
     SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
@@ -1220,17 +1217,15 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
                        (size_t)npad, dpc, n, m, dmean, (size_t)mpad);
     GemmBatch gp;  // P = K_* K^-1
     gp.nb = nb, gp.sA = sKs, gp.sB = (size_t)npad * npad, gp.sC = sKs, gp.pidxB = dpc;
-    rc = launch_gemm_nt<0>(c, dKs, npad, c->dKinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr, gp);
-    if (rc) return rc;
+    bgp_launch_gemm4(c->stream, 0, dKs, c->dKinv, npad, mpad, npad, npad, dP, npad, nb, gp.sA, gp.sB, gp.sC, gp.pidxB);
     // cov = K_** - P K_*^T in place in the child's matrices, + jitter, identity padding
     rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, w->dK, mpad, sCv);
     if (rc) return rc;
     hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, w->dK, mpad, sCv, m, dHc,
                        d);
     GemmBatch gc;
-    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv, gc.lower_only = 1;
-    rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, w->dK, mpad, w->dK, mpad, nullptr, gc);
-    if (rc) return rc;
+    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv;
+    bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, nb, gc.sA, gc.sB, gc.sC, nullptr);
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(256, nb), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
     BGP_HIP(hipMemsetAsync(w->dyw, 0, (size_t)nb * mpad * sizeof(double), c->stream));
     BGP_HIP(hipMemsetAsync(w->dstatus, 0, (size_t)nb * sizeof(int), c->stream));

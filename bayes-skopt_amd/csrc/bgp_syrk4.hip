@@ -195,10 +195,13 @@ static __device__ __forceinline__ void s4_gen_c(const S4Gen& g, const S4Tile& cu
 }
 
 // One tile for a wave's NR x NC block at (r0, c0) of the T x T workgroup tile.
-template <int T, int NR, int NC, int CREL, int VAR, int GEN = 0, int STAT = 0, int FORM = 0>
+// NEGA = 1: C -= A B^T (the factorisation's update), 0: C += A B^T; ZEROC: C is not loaded (starts from zero); ldc = leading
+// dimension of C when it is not the operands' (gemm4_kernel).
+template <int T, int NR, int NC, int CREL, int VAR, int GEN = 0, int STAT = 0, int FORM = 0, int NEGA = 1, int ZEROC = 0>
 static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsigned lds0, const S4Tile& cur,
                                                const unsigned (&voff)[T / 32], int ld, int K, int r0, int c0, int w,
-                                               int lane, const S4Gen& gen) {
+                                               int lane, const S4Gen& gen, int ldc = 0) {
+  if (ldc == 0) ldc = ld;
   constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
   unsigned pa[4], pb[4];
   s4_frag_addr(pa, lds0, r0, lane);
@@ -211,10 +214,16 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
   }
   // The empty asm makes hipcc wait for its C loads HERE (its in-order vmcnt wait also covers chunk 0, needed
   // next anyway) instead of at their first use inside the loop, where such a wait would drain the LDS-DMA queue.
-  if (GEN)
+  if (GEN) {
     s4_gen_c<NR, NC, CREL, STAT, FORM>(gen, cur, acc, r0, c0, lane);
-  else
-    gk_load_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
+  } else if (ZEROC) {
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+  } else {
+    gk_load_c<NR, NC, CREL>(cur.C, (size_t)ldc, acc, r0, c0, lane);
+  }
 #pragma unroll
   for (int i = 0; i < NR; i++)
 #pragma unroll
@@ -231,12 +240,12 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
         s4_issue<T>(cur.XA, voff, (c + s + 1) * S4_KC, nb, w);
         if (!cur.diag) s4_issue<T>(cur.XB, voff, (c + s + 1) * S4_KC, nb + OPB, w);
       }
-      s4_mma<NR, NC, CREL, VAR>(pa, pb, s * STAGEB, acc);
+      s4_mma<NR, NC, CREL, VAR, NEGA>(pa, pb, s * STAGEB, acc);
       __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs of this chunk above the next wait + barrier
     }
   }
   S4_STAMP(2);
-  gk_store_c<NR, NC, CREL>(cur.C, (size_t)ld, acc, r0, c0, lane);
+  gk_store_c<NR, NC, CREL>(cur.C, (size_t)ldc, acc, r0, c0, lane);
 }
 
 // Tile list of one launch, in blocks of T rows:  nt128 = trailing 128-row blocks, colmode 0: every tile with
@@ -457,6 +466,62 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
   const int B8 = 8 * ((B + 7) / 8);
   hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * (nblk - k - 1)), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride,
                      ystride, nblk, k, B);
+}
+
+// ------------------------------------------------------------------------------------------
+// General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):
+//     MODE 0:  C  = A B^T          (C not read)             P = K_* K^-1
+//     MODE 1:  C -= A B^T  on the tiles with ti >= tj only   cov = K_** - P K_*^T when only a Cholesky reads it
+// A (M x K) and B (N x K) share the leading dimension ldx, C (M x N) has ldc; M, N multiples of 64, K of 16.
+// 64 x 64 tiles, four waves of 32 x 32; blockIdx.y = item of a batch (strides sA, sB, sC; pidxB maps item -> B slot).
+// Tiles go by column panels of 8 (the B rows of the running tiles stay in L2, A streams once per panel).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256, 4)
+    gemm4_kernel(const double* __restrict__ A, const double* __restrict__ Bm, int ldx, int K, double* __restrict__ C,
+                 int ldc, int tm, int tn, size_t sA, size_t sB, size_t sC, const int* __restrict__ pidxB) {
+  constexpr int T = 64;
+  constexpr unsigned STAGEB = 2 * T * S4_ROWB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int b = blockIdx.y;
+  int ti, tj;
+  if (MODE == 1) {
+    s4_panel_decode((int)blockIdx.x, tm, ti, tj);  // lower triangle of a square tile grid (tm == tn)
+  } else {
+    const int t = blockIdx.x, per = S4_PW * tm, p = t / per, r = t - p * per;
+    const int wdt = min(S4_PW, tn - p * S4_PW);  // (the last panel may be narrower)
+    ti = r / wdt;
+    tj = p * S4_PW + (r - ti * wdt);
+    if (ti >= tm) return;
+  }
+  S4Tile cur;
+  cur.XA = A + (size_t)b * sA + (size_t)(ti * T) * ldx;
+  cur.XB = Bm + (size_t)(pidxB ? pidxB[b] : b) * sB + (size_t)(tj * T) * ldx;
+  cur.C = C + (size_t)b * sC + (size_t)(ti * T) * ldc + tj * T;
+  cur.diag = 0;
+  cur.b = b, cur.gi0 = ti * T, cur.gj0 = tj * T;
+  cur.q = 0, cur.label = 0;
+  unsigned voff[T / 32];
+  s4_src<T>(voff, ldx, w, lane);
+  s4_tile<T, 2, 2, -64, 0, 0, 0, 0, (MODE == 1) ? 1 : 0, (MODE == 0) ? 1 : 0>(nullptr, lds0, cur, voff, ldx, K, wr * (T / 2),
+                                                                        wc * (T / 2), w, lane, S4Gen(), ldc);
+}
+
+// mode 0: C = A B^T (all tiles); mode 1: C -= A B^T on the lower tiles of a square C.  nb items (blockIdx.y).
+void bgp_launch_gemm4(hipStream_t st, int mode, const double* A, const double* Bm, int ldx, int M, int N, int K, double* C,
+                      int ldc, int nb, size_t sA, size_t sB, size_t sC, const int* pidxB) {
+  const int tm = M / 64, tn = N / 64;
+  if (mode == 1) {
+    hipLaunchKernelGGL(gemm4_kernel<1>, dim3(tm * (tm + 1) / 2, nb), dim3(256), 0, st, A, Bm, ldx, K, C, ldc, tm, tn, sA, sB,
+                       sC, pidxB);
+  } else {
+    const int npanel = (tn + S4_PW - 1) / S4_PW;
+    hipLaunchKernelGGL(gemm4_kernel<0>, dim3(npanel * S4_PW * tm, nb), dim3(256), 0, st, A, Bm, ldx, K, C, ldc, tm, tn, sA,
+                       sB, sC, pidxB);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
