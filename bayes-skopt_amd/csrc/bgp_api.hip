@@ -286,10 +286,20 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
 
 static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status);
 
+extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h);
+extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status);
+
 extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, int* status) {
   if (!c || !h || !lml || B < 0) {
     bgp_set_error("bgp_lml_batch: bad argument");
     return BGP_ERR_INVALID;
+  }
+  // one chunk, no per-launch timing: the pinned submit / wait path (uploads and downloads that do not lock pageable
+  // memory around every call: 0.079 -> 0.06 ms for 50 proposals at n = 128)
+  if (B > 0 && B <= c->max_batch && !c->timing && c->pending_B == 0) {
+    const int rc = bgp_lml_batch_submit(c, B, h);
+    if (rc) return rc;
+    return bgp_lml_batch_wait(c, lml, status);
   }
   return lml_batch_impl(c, B, h, nullptr, lml, status);
 }
