@@ -368,6 +368,15 @@ def main():
     syrk_ms, syrk_launches = acc["syrk"]
     flops_per_call = float(sum(fl)) * B
     achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated.  Run
+    # right behind the instrumented pass: the chip is power-limited under fp64 MFMA load, so numerator and denominator
+    # should see the same clocks
+    mfma_measured = None
+    if not args.no_extras:  # (the rocprofv3 passes run --no-extras: their kernel tables hold the hot path only)
+        try:
+            mfma_measured = float(_lib.bench_mfma_f64(device))
+        except Exception:
+            mfma_measured = None
     traffic, traffic_source = None, None
     if rank == 0 and ws == 1 and not args.no_extras and not args.no_live_pmc:
         live = live_pmc_traffic()
@@ -382,13 +391,6 @@ def main():
             traffic_source = "profiles/r02_pmc_traffic.json (committed passes of tools/profile_round.sh)"
         except Exception:
             pass
-    # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated
-    mfma_measured = None
-    if not args.no_extras:  # (the rocprofv3 passes run --no-extras: their kernel tables hold the hot path only)
-        try:
-            mfma_measured = float(_lib.bench_mfma_f64(device))
-        except Exception:
-            mfma_measured = None
     peak = min(FP64_MFMA_PEAK_TFLOPS, mfma_measured) if mfma_measured else FP64_MFMA_PEAK_TFLOPS
     roofline = {
         "bound": "mfma",
