@@ -126,8 +126,28 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
   return BGP_OK;
 }
 
+// A/B measurements depend on the BGP_* switches: a misspelt one would silently measure the default twice.
+extern char** environ;
+static void warn_unknown_env_once() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
+                                "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_LEFT_LOOKING", "BGP_PANELS", "BGP_PANEL_WIDTH",
+                                "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_SYRK2", "BGP_TWO_PANEL"};
+  for (char** e = environ; e && *e; e++) {
+    if (strncmp(*e, "BGP_", 4) != 0) continue;
+    const char* eq = strchr(*e, '=');
+    const size_t len = eq ? (size_t)(eq - *e) : strlen(*e);
+    bool ok = false;
+    for (const char* k : known) ok = ok || (strlen(k) == len && strncmp(k, *e, len) == 0);
+    if (!ok) fprintf(stderr, "libbgp: warning: environment variable %.*s is not one this library reads\n", (int)len, *e);
+  }
+}
+
 extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const double* y, const double* alpha_diag,
                               const bgp_kernel_spec* ks, int max_batch, bgp_ctx** out) {
+  warn_unknown_env_once();
   if (!out || !ks) {
     bgp_set_error("bgp_ctx_create: NULL argument");
     return BGP_ERR_INVALID;

@@ -244,3 +244,19 @@ def test_pipelined_gram_build_matches_plain_build_and_oracle(lib, O):
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_unknown_switch_is_reported():
+    """A/B measurements hang on the BGP_* switches: one the library does not read (a typo, a switch of an older round)
+    must not pass silently as 'the variant'."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib;"
+            "c=_lib.Context(np.random.RandomState(0).rand(40,2), np.zeros(40), 1e-6, max_batch=2); print('ok')"
+            ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BGP_SYRK4="1", BGP_PANELS="2"), capture_output=True,
+                       text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+    assert "BGP_SYRK4 is not one this library reads" in r.stderr and "BGP_PANELS" not in r.stderr
