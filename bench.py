@@ -462,7 +462,7 @@ def main():
         del gp2
         line["roofline_n4096"] = config_d_roofline(_lib, device, peak)
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and ws == 1:  # (the CPU legs run at N = 1 only: the N > 1 runs time the GPUs)
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
             line["speedup_vs_cpu_baseline"] = value / (1 if ensemble else ws) / line["cpu_baseline"]["value"]
             if ws == 1:
