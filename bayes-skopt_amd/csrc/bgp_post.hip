@@ -94,82 +94,8 @@ __global__ void finish_var_kernel(const double* __restrict__ q, size_t sq, const
   var[(size_t)b * so + i] = v < 0.0 ? 0.0 : v;
 }
 
-// ------------------------------------------------------------------------------------------
-// General NT tile GEMM: C (M x N) = A (M x K) * B (N x K)^T, all row-major, M, N multiples of 128,
-// K a multiple of 32 (buffers are zero padded).  Epilogues:
-//   EPI 0: C = acc                         (ldc)
-//   EPI 1: rowdot[tj][i] = sum_{j in column tile tj} acc[i][j] * E[i][j]  (E: M x N, lde) -- predictive
-//          variance; the launcher then sums the column tiles in a fixed order (no fp atomics to global)
-//   EPI 2: C = E - acc                                    -- predictive covariance
-// ------------------------------------------------------------------------------------------
-struct GemmBatch {  // per-item strides (doubles) of a batched launch; pidxB maps item -> B-operand slot
-  size_t sA = 0, sB = 0, sC = 0, sE = 0;
-  const int* pidxB = nullptr;
-  int nb = 1;
-};
-
-template <int EPI>
-__global__ void __launch_bounds__(256) gemm_nt_kernel(const double* __restrict__ A, int lda,
-                                                       const double* __restrict__ Bm, int ldb, int K,
-                                                       double* __restrict__ C, int ldc,
-                                                       const double* __restrict__ E, int lde,
-                                                       double* __restrict__ rowdot, int tiles_n, GemmBatch gb) {
-  const int ti = blockIdx.x / tiles_n, tj = blockIdx.x - ti * tiles_n;
-  {
-    const int b = blockIdx.y;
-    A += (size_t)b * gb.sA;
-    Bm += (size_t)(gb.pidxB ? gb.pidxB[b] : b) * gb.sB;
-    if (C) C += (size_t)b * gb.sC;
-    if (E) E += (size_t)b * gb.sE;
-    if (EPI == 1) rowdot += (size_t)b * tiles_n * ((size_t)gridDim.x / tiles_n * 128);
-  }
-  __shared__ GemmSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-  const double* At = A + (size_t)(ti * 128) * lda;
-  const double* Bt = Bm + (size_t)(tj * 128) * ldb;
-  d4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  if (EPI == 1 && tid < 128) sm.ypart[tid] = 0.0;
-  for (int k0 = 0; k0 < K; k0 += GK_KC) {
-    __syncthreads();
-    gk_load_chunk(sm.A, At + k0, (size_t)lda, tid);
-    gk_load_chunk(sm.B, Bt + k0, (size_t)ldb, tid);
-    __syncthreads();
-    gk_mma_chunk<0, 0>(sm.A, sm.B, acc, wr, wc, lane, k0);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = GK_ROW(wr, i, lane, r);
-      const size_t grow = (size_t)(ti * 128 + row);
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const size_t gcol = (size_t)(tj * 128 + GK_COL(wc, j, lane));
-        const double x = acc[i][j][r];
-        if (EPI == 0) C[grow * ldc + gcol] = x;
-        if (EPI == 1) part += x * E[grow * lde + gcol];
-        if (EPI == 2) C[grow * ldc + gcol] = E[grow * lde + gcol] - x;
-      }
-      if (EPI == 1) {
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);
-        part += __shfl_xor(part, 8);
-        if ((lane & 15) == 0) atomicAdd(&sm.ypart[row], part);
-      }
-    }
-  }
-  if (EPI == 1) {
-    __syncthreads();
-    if (tid < 128) rowdot[(size_t)tj * ((size_t)gridDim.x / tiles_n * 128) + ti * 128 + tid] = sm.ypart[tid];
-  }
-}
-
+// Ordered sum of the column-tile partials of a batched row reduction (row dots of rowquad4_kernel, means of
+// kbuild_cross_kernel): out[b][i] = sum_t part[(b tn + t) M + i], t ascending -- no floating-point atomics.
 __global__ void rowdot_reduce_kernel(const double* __restrict__ part, int tn, int M, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (i >= M) return;
@@ -186,26 +112,6 @@ static int ensure_rowpart(bgp_ctx* c, size_t doubles) {
     c->cap_rowpart = 0;
     BGP_HIP(hipMalloc(&c->drowpart, doubles * sizeof(double)));
     c->cap_rowpart = doubles;
-  }
-  return BGP_OK;
-}
-
-template <int EPI>
-static int launch_gemm_nt(bgp_ctx* c, const double* A, int lda, const double* Bm, int ldb, int M, int N, int K,
-                          double* C, int ldc, const double* E, int lde, double* rowdot, GemmBatch gb = GemmBatch()) {
-  const int tm = M / 128, tn = N / 128;
-  double* rd = rowdot;
-  if (EPI == 1) {
-    int rc = ensure_rowpart(c, (size_t)gb.nb * tn * M);
-    if (rc) return rc;
-    rd = c->drowpart;
-  }
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tm * tn, gb.nb), dim3(256), 0, c->stream, A, lda, Bm, ldb, K, C, ldc, E,
-                     lde, rd, tn, gb);
-  BGP_HIP(hipGetLastError());
-  if (EPI == 1) {
-    hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((M + 255) / 256, gb.nb), dim3(256), 0, c->stream, rd, tn, M, rowdot);
-    BGP_HIP(hipGetLastError());
   }
   return BGP_OK;
 }
@@ -416,8 +322,6 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
     const double* Kinv = c->dKinv + (size_t)off * npad * npad;  // items off .. off+nb-1 are posteriors off .. off+nb-1
     const double* al = c->dalpha_sol + (size_t)off * npad;
     double *dq = dqB + (size_t)off * mpad, *dout = doutB + (size_t)off * mpad;
-    GemmBatch gb;
-    gb.nb = nb;
     // K_* and, from the same registers, the column-tile partials of the mean K_* alpha (added in tile order below)
     rc = bgp_launch_kcross_matvec(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs, al, (size_t)npad, dmpart);
     if (rc) return rc;
@@ -427,23 +331,17 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
       BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
                                (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     // q_i = k_i^T K^-1 k_i  (= rowsum((K_* K^-1) o K_*), evaluated on the lower block triangle of K^-1)
-    gb.sA = sKs, gb.sB = (size_t)npad * npad, gb.sC = 0, gb.sE = sKs;
     rc = launch_rowquad(c, dKs, npad, sKs, Kinv, npad, (size_t)npad * npad, nullptr, mpad, npad, nb, dq);
     if (rc) return rc;
     if (cov) {
-      gb.sC = sKs, gb.sE = 0;
-      rc = launch_gemm_nt<0>(c, dKs, npad, Kinv, npad, mpad, npad, npad, dP, npad, nullptr, 0, nullptr, gb);
-      if (rc) return rc;
+      bgp_launch_gemm4(c->stream, 0, dKs, Kinv, npad, mpad, npad, npad, dP, npad, nb, sKs, (size_t)npad * npad, sKs, nullptr);
       // K_** (no white noise off the diagonal; the diagonal gets c(+1) + s2 like kernel_(X)); then cov = K_** - P K_*^T
       // in place (every element is read and written by the same lane)
       rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, dCov, mpad, sCv);
       if (rc) return rc;
       hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dCov, mpad, sCv, m,
                          dHc, d);
-      GemmBatch gc;
-      gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv, gc.sE = sCv;
-      rc = launch_gemm_nt<2>(c, dP, npad, dKs, npad, mpad, mpad, npad, dCov, mpad, dCov, mpad, nullptr, gc);
-      if (rc) return rc;
+      bgp_launch_gemm4(c->stream, 2, dP, dKs, npad, mpad, mpad, npad, dCov, mpad, nb, sKs, sKs, sCv, nullptr);
       for (int b = 0; b < nb; b++)
         BGP_HIP(hipMemcpy2DAsync(cov + (size_t)(off + b) * m * m, (size_t)m * sizeof(double), dCov + (size_t)b * sCv,
                                  (size_t)mpad * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost,
@@ -914,14 +812,12 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   rc = bgp_launch_kcross(c, dhk, m, dXc, T, dXt, dKti, Tpad, 0);
   if (rc) return rc;
   // P_T = K_T Kinv ; s_t = rowsum(P_T o K_T) ; u_i = rowsum((K_c Kinv) o K_c) ; G = K_c P_T^T
-  rc = launch_gemm_nt<0>(c, dKT, npad, Kinv, npad, Tpad, npad, npad, dPT, npad, nullptr, 0, nullptr);
-  if (rc) return rc;
+  bgp_launch_gemm4(c->stream, 0, dKT, Kinv, npad, Tpad, npad, npad, dPT, npad, 1, 0, 0, 0, nullptr);
   rc = launch_rowquad(c, dKT, npad, 0, Kinv, npad, 0, nullptr, Tpad, npad, 1, dst);
   if (rc) return rc;
   rc = launch_rowquad(c, dKc, npad, 0, Kinv, npad, 0, nullptr, mpad, npad, 1, du);
   if (rc) return rc;
-  rc = launch_gemm_nt<0>(c, dKc, npad, dPT, npad, mpad, Tpad, npad, dG, Tpad, nullptr, 0, nullptr);
-  if (rc) return rc;
+  bgp_launch_gemm4(c->stream, 0, dKc, dPT, npad, mpad, Tpad, npad, dG, Tpad, 1, 0, 0, 0, nullptr);
   hipLaunchKernelGGL(pvrs_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dG, Tpad, dKti, Tpad, du,
                      dst, kernel_diag_value(c, h_kernel), m, T, dcov);
   BGP_HIP(hipGetLastError());
@@ -1215,17 +1111,14 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     if (rc) return rc;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, c->dalpha_sol,
                        (size_t)npad, dpc, n, m, dmean, (size_t)mpad);
-    GemmBatch gp;  // P = K_* K^-1
-    gp.nb = nb, gp.sA = sKs, gp.sB = (size_t)npad * npad, gp.sC = sKs, gp.pidxB = dpc;
-    bgp_launch_gemm4(c->stream, 0, dKs, c->dKinv, npad, mpad, npad, npad, dP, npad, nb, gp.sA, gp.sB, gp.sC, gp.pidxB);
+    // P = K_* K^-1
+    bgp_launch_gemm4(c->stream, 0, dKs, c->dKinv, npad, mpad, npad, npad, dP, npad, nb, sKs, (size_t)npad * npad, sKs, dpc);
     // cov = K_** - P K_*^T in place in the child's matrices, + jitter, identity padding
     rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, m, dXq, w->dK, mpad, sCv);
     if (rc) return rc;
     hipLaunchKernelGGL(add_diag_batch_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, w->dK, mpad, sCv, m, dHc,
                        d);
-    GemmBatch gc;
-    gc.nb = nb, gc.sA = sKs, gc.sB = sKs, gc.sC = sCv;
-    bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, nb, gc.sA, gc.sB, gc.sC, nullptr);
+    bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, nb, sKs, sKs, sCv, nullptr);
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(256, nb), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
     BGP_HIP(hipMemsetAsync(w->dyw, 0, (size_t)nb * mpad * sizeof(double), c->stream));
     BGP_HIP(hipMemsetAsync(w->dstatus, 0, (size_t)nb * sizeof(int), c->stream));

@@ -472,6 +472,7 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):
 //     MODE 0:  C  = A B^T          (C not read)             P = K_* K^-1
 //     MODE 1:  C -= A B^T  on the tiles with ti >= tj only   cov = K_** - P K_*^T when only a Cholesky reads it
+//     MODE 2:  C -= A B^T  on every tile                     the full predictive covariance of predict(return_cov)
 // A (M x K) and B (N x K) share the leading dimension ldx, C (M x N) has ldc; M, N multiples of 64, K of 16.
 // 64 x 64 tiles, four waves of 32 x 32; blockIdx.y = item of a batch (strides sA, sB, sC; pidxB maps item -> B slot).
 // Tiles go by column panels of 8 (the B rows of the running tiles stay in L2, A streams once per panel).
@@ -506,11 +507,12 @@ __global__ void __launch_bounds__(256, 4)
   cur.q = 0, cur.label = 0;
   unsigned voff[T / 32];
   s4_src<T>(voff, ldx, w, lane);
-  s4_tile<T, 2, 2, -64, 0, 0, 0, 0, (MODE == 1) ? 1 : 0, (MODE == 0) ? 1 : 0>(nullptr, lds0, cur, voff, ldx, K, wr * (T / 2),
+  s4_tile<T, 2, 2, -64, 0, 0, 0, 0, (MODE != 0) ? 1 : 0, (MODE == 0) ? 1 : 0>(nullptr, lds0, cur, voff, ldx, K, wr * (T / 2),
                                                                         wc * (T / 2), w, lane, S4Gen(), ldc);
 }
 
-// mode 0: C = A B^T (all tiles); mode 1: C -= A B^T on the lower tiles of a square C.  nb items (blockIdx.y).
+// mode 0: C = A B^T (all tiles); mode 1: C -= A B^T on the lower tiles of a square C; mode 2: C -= A B^T on all tiles.
+// nb items (blockIdx.y).
 void bgp_launch_gemm4(hipStream_t st, int mode, const double* A, const double* Bm, int ldx, int M, int N, int K, double* C,
                       int ldc, int nb, size_t sA, size_t sB, size_t sC, const int* pidxB) {
   const int tm = M / 64, tn = N / 64;
@@ -519,8 +521,12 @@ void bgp_launch_gemm4(hipStream_t st, int mode, const double* A, const double* B
                        sC, pidxB);
   } else {
     const int npanel = (tn + S4_PW - 1) / S4_PW;
-    hipLaunchKernelGGL(gemm4_kernel<0>, dim3(npanel * S4_PW * tm, nb), dim3(256), 0, st, A, Bm, ldx, K, C, ldc, tm, tn, sA,
-                       sB, sC, pidxB);
+    if (mode == 2)
+      hipLaunchKernelGGL(gemm4_kernel<2>, dim3(npanel * S4_PW * tm, nb), dim3(256), 0, st, A, Bm, ldx, K, C, ldc, tm, tn,
+                         sA, sB, sC, pidxB);
+    else
+      hipLaunchKernelGGL(gemm4_kernel<0>, dim3(npanel * S4_PW * tm, nb), dim3(256), 0, st, A, Bm, ldx, K, C, ldc, tm, tn,
+                         sA, sB, sC, pidxB);
   }
 }
 
