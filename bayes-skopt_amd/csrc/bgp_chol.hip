@@ -545,9 +545,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
 // [[K, .], [I, 0]], which starts at block row `aug`.  Running the same three kernels on the
 // augmented matrix for nblk steps leaves L (top-left), L^-T (bottom-left), the Schur complement
 // -K^-1 (bottom-right) and -alpha = -(K^-1 y) in the lower half of the working right-hand side.
-static __device__ __forceinline__ int bgp_rowblk(int t, int k, int nlow, int aug) {
-  return (t < nlow) ? (k + 1 + t) : (aug + (t - nlow));
-}
+// (bgp_rowblk: bgp_device.h)
 
 __global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf,
                                                     double* __restrict__ yw, const int* __restrict__ status,
@@ -787,7 +785,7 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
 void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
-                      int ystride, int nblk, int k);
+                      int ystride, int nblk, int k, int augmented);
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
@@ -860,7 +858,7 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
         if (ctx->use_syrk2)
           bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
         else
-          bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
+          bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 3, st);
@@ -893,13 +891,22 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     const int nlow = nblk - k - 1;
     const int nact = augmented ? nblk : nlow;
     if (nact > 0) {
+      // posterior builds (augmented) run the ring kernels with the active-row remap; BGP_SYRK2=1 keeps round 1's
+      // trsm_kernel / syrk_kernel as the A/B reference (they also serve a non-augmented single-panel call)
+      const bool ring = augmented && !ctx->use_syrk2;
       bgp_tbegin(ctx, 2, st);
-      hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride,
-                         nblk, k, nact, nblk, B);
+      if (ring)
+        bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, 1);
+      else
+        hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride,
+                           nblk, k, nact, nblk, B);
       bgp_tend(ctx, st);
       bgp_tbegin(ctx, 3, st);
-      hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
-                         nblk, k, nact, nblk, B);
+      if (ring)
+        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128, 0, 2, B, nullptr);
+      else
+        hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                           nblk, k, nact, nblk, B);
       bgp_tend(ctx, st);
     }
   }

@@ -34,6 +34,12 @@ static __device__ __forceinline__ void bgp_map_block(int id, int tiles, int B, i
   b = 8 * m + x;
 }
 
+// Active row block t at step k of a factorisation: the nlow = nblk-k-1 remaining blocks of K, then (posterior builds on
+// the augmented matrix [[K, .], [I, 0]]) the first k+1 block rows of the identity part, which starts at block row aug.
+static __device__ __forceinline__ int bgp_rowblk(int t, int k, int nlow, int aug) {
+  return (t < nlow) ? (k + 1 + t) : (aug + (t - nlow));
+}
+
 static __device__ __forceinline__ void bgp_tri_decode(int t, int& ti, int& tj) {
   int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
   while (r * (r + 1) / 2 > t) r--;

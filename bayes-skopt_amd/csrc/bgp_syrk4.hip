@@ -303,7 +303,25 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
     bgp_map_block(q, ntile, B, b, t);
     if (b >= B || status[b] != 0) break;  // padding slot / failed factorisation: nothing to update
     int ti, tj;
-    if (!colmode) {
+    if (colmode == 2) {
+      // posterior build on the augmented matrix: the trailing set is the nblk ACTIVE block rows of bgp_rowblk (what is
+      // left of K, then the first kp+1 block rows of the identity part); single panel kp, K = 128
+      s4_panel_decode(t, nt128 * (128 / T), ti, tj, pw);
+      const int nlow = nt128 - kp - 1;
+      const size_t rI = (size_t)bgp_rowblk((ti * T) >> 7, kp, nlow, nt128) * 128 + ((ti * T) & 127);
+      const size_t rJ = (size_t)bgp_rowblk((tj * T) >> 7, kp, nlow, nt128) * 128 + ((tj * T) & 127);
+      double* M2 = Kbuf + (size_t)b * mstride;
+      d.XA = M2 + rI * ld + kp * 128;
+      d.XB = M2 + rJ * ld + kp * 128;
+      d.C = M2 + rI * ld + rJ;
+      d.diag = (ti == tj);
+      d.b = b;
+      d.gi0 = (int)rI;
+      d.gj0 = (int)rJ;
+      d.label = ti * 1000 + tj;
+      d.q = q;
+      break;
+    } else if (!colmode) {
       s4_panel_decode(t, nt128 * (128 / T), ti, tj, pw);
     } else if (T == 128 || t < nt128 * 2) {
       ti = t;
@@ -338,9 +356,9 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int nt128 = nblk - jstart;
-  const S4Tile cur = s4_decode<T>(blockIdx.x, total, s4_ntile<T>(nt128, colmode), Kbuf, status, ld, mstride, kp, jstart,
-                                  colmode, nt128, B, pw);
+  const int nt128 = (colmode == 2) ? nblk : nblk - jstart;  // (colmode 2: all nblk active rows of the augmented step)
+  const S4Tile cur = s4_decode<T>(blockIdx.x, total, s4_ntile<T>(nt128, colmode == 2 ? 0 : colmode), Kbuf, status, ld,
+                                  mstride, kp, jstart, colmode, nt128, B, pw);
   if (cur.q >= total) return;
   unsigned voff[T / 32];
   s4_src<T>(voff, ld, w, lane);
@@ -365,7 +383,7 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
 
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
                       int K, int jstart, int colmode, int B, const S4Gen* gen) {
-  const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
+  const int total = B8 * (colmode == 2 ? s4_ntile<64>(nblk, 0) : s4_ntile<64>(nblk - jstart, colmode));
   static int pw = 0;
   if (!pw) {
     const char* e = getenv("BGP_PANEL_WIDTH");  // tile columns per L2-resident column panel (s4_panel_decode)
@@ -394,9 +412,10 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
 template <int VAR>
 __global__ void __launch_bounds__(256, 3)
     trsm4_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
-                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B) {
+                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B,
+                 int augmented = 0) {
   constexpr unsigned AOPB = 64 * S4_ROWB, STAGEB = (64 + 128) * S4_ROWB;
-  const int nrb = nblk - k - 1;
+  const int nrb = augmented ? nblk : nblk - k - 1;  // augmented matrix: nblk active row blocks at every step (bgp_rowblk)
   int b, t;
   bgp_map_block(blockIdx.x, 2 * nrb, B, b, t);
   if (b >= B || status[b] != 0) return;
@@ -404,7 +423,7 @@ __global__ void __launch_bounds__(256, 3)
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ib = k + 1 + (t >> 1), half = t & 1;
+  const int ib = augmented ? bgp_rowblk(t >> 1, k, nblk - k - 1, nblk) : k + 1 + (t >> 1), half = t & 1;
   double* A = Kbuf + (size_t)b * mstride + (size_t)(ib * 128 + half * 64) * ld + k * 128;
   const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
   unsigned voffA[2], voffW[4];
@@ -462,10 +481,11 @@ __global__ void __launch_bounds__(256, 3)
 }
 
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
-                      int ystride, int nblk, int k) {
+                      int ystride, int nblk, int k, int augmented) {
   const int B8 = 8 * ((B + 7) / 8);
-  hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * (nblk - k - 1)), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride,
-                     ystride, nblk, k, B);
+  const int nrb = augmented ? nblk : nblk - k - 1;
+  hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * nrb), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk,
+                     k, B, augmented);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -669,7 +689,7 @@ extern "C" int bgp_debug_launch_trsm4(int var, hipStream_t st, int B, double* dK
   const dim3 grid(B8 * 2 * (nblk - k - 1));
 #define T4_CASE(V)                                                                                                  \
   if (var == V) {                                                                                                   \
-    hipLaunchKernelGGL(trsm4_kernel<V>, grid, dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, B); \
+    hipLaunchKernelGGL(trsm4_kernel<V>, grid, dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, B, 0); \
     return (int)grid.x;                                                                                             \
   }
   T4_CASE(0) T4_CASE(1) T4_CASE(2) T4_CASE(3) T4_CASE(8) T4_CASE(16) T4_CASE(10) T4_CASE(11)
