@@ -17,10 +17,10 @@
 //     scheduled in groups of P block columns by bgp_launch_cholesky_gen below (BGP_SYRK2=1: round 1's syrk2_kernel +
 //     trsm8_kernel, kept as the bit-identical A/B reference);
 //   * posterior builds on the augmented matrix (bgp_post.hip; once per sample(), per hyper-posterior draw of an
-//     acquisition and per gradient evaluation): trsm_kernel / syrk_kernel of this file -- one NT tile GEMM on
-//     v_mfma_f64_16x16x4_f64, 4 waves as 2x2, each wave a 64x64 sub-tile = 4x4 MFMA tiles (128 accumulator VGPRs),
-//     operands staged through LDS in 128x32 chunks with leading dimension 34 (conflict-free ds_read_b64 for the
-//     16-row x 2-k lane pattern), single-panel right-looking steps with the active-row remap of bgp_rowblk.
+//     acquisition and per gradient evaluation): the same ring kernels in single-panel mode with the active-row remap
+//     of bgp_rowblk (bgp_device.h).  BGP_SYRK2=1 keeps round 1's trsm_kernel / syrk_kernel of this file: one NT tile
+//     GEMM on v_mfma_f64_16x16x4_f64, 4 waves as 2x2, each wave a 64x64 sub-tile = 4x4 MFMA tiles (128 accumulator
+//     VGPRs), operands staged through LDS in 128x32 chunks with leading dimension 34.
 #include "bgp_common.h"
 #include "bgp_device.h"
 
