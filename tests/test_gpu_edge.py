@@ -140,7 +140,8 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
         "import sys, numpy as np; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib;"
         "rng=np.random.RandomState(5); n,d=700,6; X=rng.uniform(size=(n,d)); y=np.sin(3*X.sum(1));"
         "H=np.concatenate([[0.],np.full(d,np.log(.4)),[np.log(.02)]])+0.1*np.random.RandomState(6).randn(5,d+2);"
-        "c=_lib.Context(X,y,1e-10,max_batch=8); print(repr(c.lml(H).tolist()))"
+        "c=_lib.Context(X,y,1e-10,max_batch=8); l=c.lml(H).tolist(); r=c.posterior(H[:3], want_alpha=True, want_K_inv=True);"
+        "print(repr(l + r['alpha'].sum(1).tolist() + [float(np.trace(k)) for k in r['K_inv']]))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
@@ -157,7 +158,9 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
     X = rng.uniform(size=(700, 6))
     y = np.sin(3 * X.sum(1))
     H = np.concatenate([[0.0], np.full(6, np.log(0.4)), [np.log(0.02)]]) + 0.1 * np.random.RandomState(6).randn(5, 8)
-    np.testing.assert_allclose(outs[0], O.lml_batch(X, y, np.full(700, 1e-10), H), rtol=RTOL)
+    # (each output: 5 LML values, then alpha sums and trace(K^-1) of three posterior builds -- the BGP_SYRK2=1 run builds
+    # them with round 1's trsm_kernel / syrk_kernel, every other run with the ring kernels and the active-row remap)
+    np.testing.assert_allclose(outs[0][:5], O.lml_batch(X, y, np.full(700, 1e-10), H), rtol=RTOL)
 
 
 def test_bitwise_reproducible_and_batch_split_invariant():
