@@ -316,7 +316,11 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
   }
   // one chunk, no per-launch timing: the pinned submit / wait path (uploads and downloads that do not lock pageable
   // memory around every call: 0.079 -> 0.06 ms for 50 proposals at n = 128)
-  if (B > 0 && B <= c->max_batch && !c->timing && c->pending_B == 0) {
+  if (c->pending_B != 0) {  // the pending batch owns the workspace until bgp_lml_batch_wait collects it
+    bgp_set_error("bgp_lml_batch: a submitted batch is still pending (call bgp_lml_batch_wait)");
+    return BGP_ERR_STATE;
+  }
+  if (B > 0 && B <= c->max_batch && !c->timing) {
     const int rc = bgp_lml_batch_submit(c, B, h);
     if (rc) return rc;
     return bgp_lml_batch_wait(c, lml, status);

@@ -160,3 +160,26 @@ def test_full_size_block_diagonal_additivity(lib):
     order = rng.permutation(na + nb)  # interleave the clusters: the block structure is hidden from the tiling
     joint = lml_of(np.vstack([XA, XB])[order], np.concatenate([yA, yB])[order])
     np.testing.assert_allclose(joint, lml_of(XA, yA) + lml_of(XB, yB), rtol=1e-12)
+
+
+def test_submit_wait_equals_synchronous_call_and_guards_the_workspace(lib):
+    """bgp_lml_batch_submit / _wait (the sampler's asynchronous form: proposals and results through pinned memory) give
+    the bits of bgp_lml_batch; while a batch is pending the workspace is its own -- a second submit or a synchronous
+    call is refused, and a wait without a submit too."""
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(300, 3))
+    y = np.sin(3 * X.sum(1))
+    ctx = lib.Context(X, y, 1e-8, max_batch=8)
+    H = np.concatenate([[0.0], np.full(3, np.log(0.4)), [np.log(0.02)]]) + 0.1 * rng.randn(8, 5)
+    ref = ctx.lml(H)
+    assert ctx.lml_submit(H)
+    with pytest.raises(Exception, match="pending"):
+        ctx.lml(H)
+    with pytest.raises(Exception, match="pending"):
+        lib._check(lib.load().bgp_lml_batch_submit(ctx._h, 8, lib._p(H)), "submit")
+    np.testing.assert_array_equal(ctx.lml_wait(), ref)
+    ctx._pending = 8  # (python-side bookkeeping only: the library must notice that nothing was submitted)
+    with pytest.raises(Exception, match="nothing submitted"):
+        ctx.lml_wait()
+    np.testing.assert_array_equal(ctx.lml(H), ref)
+    ctx.close()
