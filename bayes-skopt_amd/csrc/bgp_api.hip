@@ -238,6 +238,7 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
 }
 
 extern "C" int bgp_ctx_update_data(bgp_ctx* c, int n, const double* X, const double* y, const double* alpha_diag) {
+  BGP_REQUIRE_IDLE(c, "bgp_ctx_update_data");
   if (!c) {
     bgp_set_error("bgp_ctx_update_data: NULL ctx");
     return BGP_ERR_INVALID;
@@ -330,6 +331,7 @@ extern "C" int bgp_lml_batch(bgp_ctx* c, int B, const double* h, double* lml, in
 
 extern "C" int bgp_lml_batch_warped(bgp_ctx* c, int B, const double* h, const double* warp, double* lml,
                                     int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_lml_batch_warped");
   if (!c || !h || !warp || !lml || B < 0) {
     bgp_set_error("bgp_lml_batch_warped: bad argument");
     return BGP_ERR_INVALID;
@@ -539,6 +541,7 @@ extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
 }
 
 extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
+  BGP_REQUIRE_IDLE(c, "bgp_kernel_matrix");
   if (!c || !h || !K) {
     bgp_set_error("bgp_kernel_matrix: NULL argument");
     return BGP_ERR_INVALID;

@@ -107,6 +107,15 @@ struct bgp_ctx {
   std::vector<int> evcat;
 };
 
+// The workspace belongs to a batch submitted with bgp_lml_batch_submit until bgp_lml_batch_wait has collected it.
+#define BGP_REQUIRE_IDLE(c, who)                                                                     \
+  do {                                                                                              \
+    if ((c) && (c)->pending_B != 0) {                                                               \
+      bgp_set_error(who ": a submitted batch is still pending (call bgp_lml_batch_wait)");          \
+      return BGP_ERR_STATE;                                                                         \
+    }                                                                                               \
+  } while (0)
+
 // Per-launch HIP-event timing on the context's stream (only when ctx->timing != 0).
 // Categories: 0 K-build, 1 potrf, 2 trsm, 3 syrk.
 static inline void bgp_tbegin(bgp_ctx* c, int cat, hipStream_t st = nullptr) {

@@ -227,6 +227,7 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
 
 extern "C" int bgp_posterior_batch(bgp_ctx* c, int B, const double* h, double* L, double* alpha, double* K_inv,
                                    double* lml, int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_posterior_batch");
   if (!c || !h || B <= 0) {
     bgp_set_error("bgp_posterior_batch: bad argument");
     return BGP_ERR_INVALID;
@@ -369,6 +370,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
 
 extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double* mean,
                                  double* var, double* cov) {
+  BGP_REQUIRE_IDLE(c, "bgp_predict_batch");
   if (!c || !h_kernel || !Xq || !mean || !var || m <= 0 || B <= 0) {
     bgp_set_error("bgp_predict_batch: bad argument");
     return BGP_ERR_INVALID;
@@ -499,6 +501,7 @@ static int acq_check(const char* who, int n_acq, const int* kinds, const double*
 extern "C" int bgp_acq_batch(bgp_ctx* c, int B, const double* h_kernel, int m, const double* Xq, double y_mean,
                              double y_std, int n_acq, const int* kinds, const double* params, int n_samples,
                              double* out) {
+  BGP_REQUIRE_IDLE(c, "bgp_acq_batch");
   if (!c || !h_kernel || !Xq || m <= 0 || B <= 0) {
     bgp_set_error("bgp_acq_batch: bad argument");
     return BGP_ERR_INVALID;
@@ -514,6 +517,7 @@ extern "C" int bgp_acq_batch(bgp_ctx* c, int B, const double* h_kernel, int m, c
 // The same closed forms on caller-supplied (mu, std) rows: B x m each, already in y units (y_mean = 0, y_std = 1).
 extern "C" int bgp_acq_values(bgp_ctx* c, int B, int m, const double* mu, const double* std_, int n_acq, const int* kinds,
                               const double* params, int n_samples, double* out) {
+  BGP_REQUIRE_IDLE(c, "bgp_acq_values");
   if (!c || !mu || !std_ || m <= 0 || B <= 0) {
     bgp_set_error("bgp_acq_values: bad argument");
     return BGP_ERR_INVALID;
@@ -711,6 +715,7 @@ __global__ void grad_reduce_kernel(const double* __restrict__ gpart, double* __r
 }
 
 extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lml, double* grad, int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_lml_grad_batch");
   if (!c || !h || !lml || !grad || B <= 0) {
     bgp_set_error("bgp_lml_grad_batch: bad argument");
     return BGP_ERR_INVALID;
@@ -766,6 +771,7 @@ __global__ void pvrs_combine_kernel(const double* __restrict__ G, int ldg, const
 
 extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double* Xcand, int T,
                         const double* Xthompson, double* covs) {
+  BGP_REQUIRE_IDLE(c, "bgp_pvrs");
   if (!c || !h_kernel || !Xcand || !Xthompson || !covs || m <= 0 || T <= 0) {
     bgp_set_error("bgp_pvrs: bad argument");
     return BGP_ERR_INVALID;
@@ -827,6 +833,7 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
 }
 
 extern "C" int bgp_pvrs_prepare(bgp_ctx* c, const double* h_kernel, int has_alpha_vec, int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_pvrs_prepare");
   // K_aug's leading block: kernel_(X_train) + alpha only when alpha is a vector
   // (bask/acquisition.py:332-333)
   if (!c || !h_kernel) {
@@ -919,6 +926,7 @@ __global__ void __launch_bounds__(256) tri_matmul_draws_kernel(const double* __r
 
 extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, const double* Xq, int n_draws,
                             const double* z, double jitter, double* out) {
+  BGP_REQUIRE_IDLE(c, "bgp_sample_y");
   if (!c || !h_kernel || !Xq || !z || !out || m <= 0 || n_draws <= 0 || b < 0) {
     bgp_set_error("bgp_sample_y: bad argument");
     return BGP_ERR_INVALID;
@@ -1059,6 +1067,7 @@ static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out) {
 // jitter (out[i] undefined) -- the caller retries those items with a larger jitter.
 extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const double* h_kernel, int m, const double* Xq,
                                   const double* z, double jitter, double* out, int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_sample_y_batch");
   if (!c || !pidx || !h_kernel || !Xq || !z || !out || !status || m <= 0 || B <= 0) {
     bgp_set_error("bgp_sample_y_batch: bad argument");
     return BGP_ERR_INVALID;

@@ -67,6 +67,7 @@ int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* 
 // Context-level warp: subsequent posterior / predict / pvrs / gradient / sample_y / un-warped LML calls
 // see the training inputs (and their query points) through this warp.  warp == NULL clears it.
 extern "C" int bgp_ctx_set_warp(bgp_ctx* c, const double* warp) {
+  BGP_REQUIRE_IDLE(c, "bgp_ctx_set_warp");
   if (!c) {
     bgp_set_error("bgp_ctx_set_warp: NULL ctx");
     return BGP_ERR_INVALID;

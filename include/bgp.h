@@ -107,7 +107,9 @@ int bgp_beta_cdf(bgp_ctx* ctx, int m, const double* X, const double* warp, doubl
  * Asynchronous bgp_lml_batch (B <= max_batch): submit enqueues the whole batch on the device and returns, wait blocks
  * until it is done and hands back lml / status (status may be NULL).  Between the two calls the host is free -- the
  * sampler evaluates the log-priors of the same proposals there (bask/bayesgpr.py:366-372 runs them back to back).
- * One batch may be pending per context; same results as bgp_lml_batch.
+ * One batch may be pending per context, and it owns the workspace: until wait has collected it every other entry point
+ * that computes on the context returns BGP_ERR_STATE.  Proposals and results travel through pinned host memory; same
+ * results as bgp_lml_batch (which takes this path itself for a single chunk).
  */
 int bgp_lml_batch_submit(bgp_ctx* ctx, int B, const double* h);
 int bgp_lml_batch_wait(bgp_ctx* ctx, double* lml, int* status);

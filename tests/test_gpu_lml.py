@@ -176,6 +176,10 @@ def test_submit_wait_equals_synchronous_call_and_guards_the_workspace(lib):
     with pytest.raises(Exception, match="pending"):
         ctx.lml(H)
     with pytest.raises(Exception, match="pending"):
+        ctx.posterior(H[:1])
+    with pytest.raises(Exception, match="pending"):
+        ctx.update_data(X, y, 1e-8)
+    with pytest.raises(Exception, match="pending"):
         lib._check(lib.load().bgp_lml_batch_submit(ctx._h, 8, lib._p(H)), "submit")
     np.testing.assert_array_equal(ctx.lml_wait(), ref)
     ctx._pending = 8  # (python-side bookkeeping only: the library must notice that nothing was submitted)
