@@ -45,6 +45,16 @@ static __device__ __forceinline__ void s4_issue(const double* X, const unsigned 
     s4_glds(X + k0, voff[i], lds_op_base + (unsigned)(((T / 4) * w + 8 * i) * S4_ROWB));
 }
 
+// The same, rows >= minrow only (wave-uniform test): the panel solve's triangular operand -- chunk c never reads the
+// rows below 16 c of W_kk, so they are not staged (their LDS slots keep stale data that no fragment read touches).
+template <int T>
+static __device__ __forceinline__ void s4_issue_from(const double* X, const unsigned (&voff)[T / 32], int k0,
+                                                     unsigned lds_op_base, int w, int minrow) {
+#pragma unroll
+  for (int i = 0; i < T / 32; i++)
+    if ((T / 4) * w + 8 * i + 8 > minrow) s4_glds(X + k0, voff[i], lds_op_base + (unsigned)(((T / 4) * w + 8 * i) * S4_ROWB));
+}
+
 template <int T>
 static __device__ __forceinline__ void s4_src(unsigned (&voff)[T / 32], int ld, int w, int lane) {
 #pragma unroll
@@ -448,7 +458,7 @@ __global__ void __launch_bounds__(256, 3)
       if (!(VAR & 1) && c + s + 1 < 8) {
         const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
         s4_issue<64>(A, voffA, (c + s + 1) * S4_KC, nb, w);
-        if (!(VAR & 16)) s4_issue<128>(W, voffW, (c + s + 1) * S4_KC, nb + AOPB, w);
+        if (!(VAR & 16)) s4_issue_from<128>(W, voffW, (c + s + 1) * S4_KC, nb + AOPB, w, 16 * (c + s + 1));
       }
       s4_mma<1, 8, -64, VAR, 0>(pa, pb, s * STAGEB, acc, c + s);
       __builtin_amdgcn_sched_barrier(0);
