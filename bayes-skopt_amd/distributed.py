@@ -72,11 +72,11 @@ def _uid_file():
     return os.path.join(os.environ.get("BGP_COMM_DIR", "/tmp"), "bgp_comm_uid_" + tag.replace("/", "_"))
 
 
-def _exchange_unique_id(rank, ws, timeout=120.0):
+def _exchange_unique_id(rank, ws, timeout=300.0):
     """Rank 0's ncclUniqueId on every rank.  Single node (MASTER_ADDR is this host's loopback, what the launcher
     contract uses): rank 0 drops the bytes into /tmp/bgp_comm_uid_<addr>_<port>_<run id> (atomic rename) and the
-    other ranks poll for a file no older than their own start (rank 0 removes it at exit; a stale one left by a
-    crashed job with the same port and world size is ignored); no port beyond the launcher's own is needed.  Otherwise: a TCP socket on MASTER_ADDR:(MASTER_PORT+1)."""
+    other ranks poll for a file no older than two minutes before their own start (rank 0 removes it at exit; a stale
+    one left by a crashed job with the same port and world size is ignored); no port beyond the launcher's own is needed.  Otherwise: a TCP socket on MASTER_ADDR:(MASTER_PORT+1)."""
     from . import _lib
 
     local = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1") \
@@ -114,7 +114,7 @@ def _exchange_unique_id(rank, ws, timeout=120.0):
         path = _uid_file()
         while True:
             try:
-                if os.path.getmtime(path) >= _T_START - 30.0:  # (ranks of one job start within seconds of each other)
+                if os.path.getmtime(path) >= _T_START - 120.0:  # (ranks of one job start within seconds of each other)
                     with open(path, "rb") as f:
                         buf = f.read()
                     if len(buf) == _lib.COMM_ID_BYTES:
