@@ -91,6 +91,10 @@ def load():
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C bayes-skopt_amd/csrc`). "
             "There is no CPU fallback."
         )
+    # multi-process GPU work on this platform needs dmabuf IPC (RCCL's ncclCommInitRank fails with
+    # "hipIpcGetMemHandle: invalid argument" otherwise); the runtime reads the switch when it initialises, i.e. at the
+    # first HIP call of the process, so it is set before the library is even loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
