@@ -9,6 +9,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 namespace {
 struct RcclApi {
@@ -90,6 +91,27 @@ static int comm_reserve(bgp_comm* c, size_t nsend, size_t nrecv) {
 
 extern "C" int bgp_comm_available(void) { return load_rccl() == BGP_OK ? 1 : 0; }
 
+// RCCL announces itself ("RCCL version : ...", five lines) on STDOUT when its first communicator is set up.  The job's
+// standard output belongs to the caller (bench.py prints exactly one JSON line there): while RCCL initialises, file
+// descriptor 1 points at standard error, C-level buffers flushed on both sides of the switch.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0 && dup2(2, 1) < 0) {
+      close(saved);
+      saved = -1;
+    }
+  }
+  ~StdoutToStderr() {
+    if (saved < 0) return;
+    fflush(stdout);
+    (void)dup2(saved, 1);
+    close(saved);
+  }
+};
+
 extern "C" int bgp_comm_unique_id(void* id128) {
   if (!id128) {
     bgp_set_error("bgp_comm_unique_id: NULL argument");
@@ -98,7 +120,14 @@ extern "C" int bgp_comm_unique_id(void* id128) {
   int rc = load_rccl();
   if (rc) return rc;
   ncclUniqueId id;
-  BGP_NCCL(g_rccl.GetUniqueId(&id));
+  {
+    StdoutToStderr quiet;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) {
+      bgp_set_error("ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+      return BGP_ERR_HIP;
+    }
+  }
   static_assert(sizeof(id) == BGP_COMM_ID_BYTES, "ncclUniqueId size");
   memcpy(id128, &id, sizeof(id));
   return BGP_OK;
@@ -124,7 +153,11 @@ extern "C" int bgp_comm_init(int device, int rank, int world, const void* id128,
   c->world = world;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
-  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  ncclResult_t r;
+  {
+    StdoutToStderr quiet;
+    r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  }
   if (r != ncclSuccess) {
     bgp_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.GetErrorString(r));
     delete c;

@@ -94,5 +94,9 @@ def test_bench_line_through_native_rccl_group():
            "--warmup", "1", "--no-extras"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
-    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    # the bench line is the ONLY thing on standard output: RCCL's start-up banner ("RCCL version : ...") goes to stderr
+    out_lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(out_lines) == 1 and out_lines[0].startswith("{"), res.stdout[-1500:]
+    assert "RCCL version" in res.stderr
+    d = json.loads(out_lines[0])
     assert d["dist_backend"] == "rccl" and d["n_gpus"] == 1 and d["gathered_chain_rows"] == 2 * 256
