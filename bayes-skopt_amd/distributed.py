@@ -48,6 +48,28 @@ def backend():
     return _state["backend"]
 
 
+class _stdout_to_stderr:
+    """Native libraries announce themselves on file descriptor 1 ("[Gloo] Rank 0 is connected to ...", RCCL's version
+    banner); a job's standard output belongs to its caller (bench.py: one JSON line).  While a group is being formed,
+    descriptor 1 points at standard error."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _torch_dist():
     import torch.distributed as dist
 
@@ -184,7 +206,9 @@ def init_process_group(backend=None, device=None):
         if not dist.is_initialized():
             if name == "nccl":
                 torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-            dist.init_process_group(backend=name, rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=300))
+            with _stdout_to_stderr():
+                dist.init_process_group(backend=name, rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=300))
+                dist.barrier()  # (gloo connects its pairs lazily: make it talk now, while descriptor 1 is redirected)
     _state.update(backend=name, rank=rank, world=ws)
     return rank, local_rank, ws
 

@@ -26,6 +26,7 @@ def test_two_rank_gloo_chain_gather(tmp_path):
            str(tmp_path)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
+    assert "[Gloo]" not in res.stdout  # (the transport's connection chatter is kept off the job's standard output)
     r = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
     for k in range(2):
         assert r[k]["ws"] == 2 and r[k]["rank"] == k
