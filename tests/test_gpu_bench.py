@@ -26,8 +26,8 @@ def _free_port():
 
 def _line(res):
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]  # ONE JSON line and nothing else on stdout
     return json.loads(lines[0])
 
 
