@@ -46,6 +46,7 @@ SIGNATURES = {
     "bgp_ctx_destroy": (None, [_vp]),
     "bgp_lml_batch": (C.c_int, [_vp, C.c_int, _dp, _dp, _ip]),
     "bgp_lml_batch_submit": (C.c_int, [_vp, C.c_int, _dp]),
+    "bgp_lml_batch_warped_submit": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "bgp_lml_batch_wait": (C.c_int, [_vp, _dp, _ip]),
     "bgp_lml_batch_warped": (C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _ip]),
     "bgp_ctx_set_warp": (C.c_int, [_vp, _dp]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "bgp_comm_allreduce_max": (C.c_int, [_vp, _dp, C.c_size_t]),
     "bgp_comm_broadcast": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
     "bgp_comm_barrier": (C.c_int, [_vp]),
+    "bgp_comm_nranks": (C.c_int, [_vp, _ip]),
+    "bgp_lml_batch_wait_allgather": (C.c_int, [_vp, _vp, C.c_int, _dp]),
     "bgp_device_synchronize": (C.c_int, [C.c_int]),
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
@@ -146,6 +149,8 @@ class Context:
                                   C.byref(h)), "bgp_ctx_create")
         self._h = h
         self._lib = lib
+        self._pending, self._pending_H = 0, None  # batch handed to lml_submit and not yet collected
+        self._timing = False
         # canonical vectors of the posteriors whose K^-1 / alpha are resident on the device
         # (None after a call that overwrites them: gradient / pvrs_prepare / update_data)
         self.resident_H = None
@@ -190,17 +195,27 @@ class Context:
         """Enqueue ``lml(H)`` on the device and return at once (False when the batch cannot go asynchronously: larger
         than max_batch, or per-launch timing on); ``lml_wait()`` collects the result."""
         H = self._H(H)
-        if H.shape[0] > self.max_batch or H.shape[0] == 0:
-            return False
-        rc = self._lib.bgp_lml_batch_submit(self._h, H.shape[0], _p(H))
-        if rc == 1:  # BGP_ERR_INVALID: timing mode -- the caller falls back to the synchronous call
-            return False
-        _check(rc, "bgp_lml_batch_submit")
+        if H.shape[0] > self.max_batch or H.shape[0] == 0 or self._timing:
+            return False  # (per-launch timing synchronises inside the call: the caller uses the synchronous form)
+        _check(self._lib.bgp_lml_batch_submit(self._h, H.shape[0], _p(H)), "bgp_lml_batch_submit")
         self._pending, self._pending_H = H.shape[0], H  # (H stays alive until the upload has certainly happened)
         return True
 
+    def lml_warped_submit(self, H, W):
+        """Asynchronous ``lml_warped``: False when the batch cannot go asynchronously (see ``lml_submit``)."""
+        H = self._H(H)
+        W = _c(np.atleast_2d(W))
+        B = H.shape[0]
+        if W.shape != (B, 2 * self.d):
+            raise ValueError(f"warp parameters must be (B, 2d) = ({B}, {2 * self.d}), got {W.shape}")
+        if B > self.max_batch or B == 0 or self._timing:
+            return False
+        _check(self._lib.bgp_lml_batch_warped_submit(self._h, B, _p(H), _p(W)), "bgp_lml_batch_warped_submit")
+        self._pending, self._pending_H = B, (H, W)
+        return True
+
     def lml_wait(self, return_status=False):
-        B = self._pending
+        B = self._pending  # (0: the C layer answers BGP_ERR_STATE, "nothing submitted")
         self._pending, self._pending_H = 0, None
         out = np.empty(B)
         st = np.zeros(B, dtype=np.int32)
@@ -353,6 +368,17 @@ class Context:
 
     def set_timing(self, enable):
         _check(self._lib.bgp_set_timing(self._h, int(bool(enable))), "bgp_set_timing")
+        self._timing = bool(enable)
+
+    def lml_wait_allgather(self, comm, per_rank):
+        """Collective form of ``lml_wait`` for the exact single-ensemble sharding: every rank has submitted its own rows
+        (possibly none) of the half-step's block; returns the (world, per_rank) log-likelihoods of all ranks, gathered
+        device to device over RCCL out of the contexts' resident result vectors (bgp_lml_batch_wait_allgather)."""
+        self._pending, self._pending_H = 0, None
+        out = np.empty((comm.world, int(per_rank)))
+        _check(self._lib.bgp_lml_batch_wait_allgather(self._h, comm._h, int(per_rank), _p(out)),
+               "bgp_lml_batch_wait_allgather")
+        return out
 
     def last_timing(self):
         ms = np.zeros(5)
@@ -419,6 +445,12 @@ class Comm:
 
     def barrier(self):
         _check(self._lib.bgp_comm_barrier(self._h), "bgp_comm_barrier")
+
+    def nranks(self):
+        """Ranks RCCL itself counts in the communicator (ncclCommCount)."""
+        v = C.c_int(0)
+        _check(self._lib.bgp_comm_nranks(self._h, C.byref(v)), "bgp_comm_nranks")
+        return int(v.value)
 
 
 def device_synchronize(device=0):

@@ -321,11 +321,16 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         if self.warp_inputs:
             d = self._X_train_.shape[1]
             Tgp, W = Theta[:, : Theta.shape[1] - 2 * d], Theta[:, Theta.shape[1] - 2 * d :]
-            return _eval_priors(priors, Tgp) + _eval_warp_priors(warp_priors, W, d), (self._canonical(Tgp), W), False
-        H = self._canonical(Theta)
-        submitted = self._ctx.lml_submit(H)
+            H = (self._canonical(Tgp), np.ascontiguousarray(W))
+            submitted = self._ctx.lml_warped_submit(*H)
+        else:
+            Tgp, W, d = Theta, None, 0
+            H = self._canonical(Theta)
+            submitted = self._ctx.lml_submit(H)
         try:
-            lp = _eval_priors(priors, Theta)
+            lp = _eval_priors(priors, Tgp)
+            if W is not None:
+                lp = lp + _eval_warp_priors(warp_priors, W, d)
         except BaseException:
             if submitted:
                 self._ctx.lml_wait()
@@ -424,8 +429,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         self._sampler = EnsembleSampler(
             nwalkers=n_walkers,
             ndim=n_dim,
-            log_prob_fn=distributed.shard_log_prob(self._log_prob_batch) if self.shard_ensemble
-            else _AsyncLogProb(self),
+            log_prob_fn=_ShardedLogProb(self) if self.shard_ensemble else _AsyncLogProb(self),
             kwargs=dict(priors=priors, warp_priors=warp_priors),
             threads=n_threads,
             **kwargs,
@@ -845,6 +849,62 @@ def _eval_warp_priors(warp_priors, W, d):
         for k in range(d):
             lp += np.array([float(warp_priors(a, b)) for a, b in zip(A[:, k], Bm[:, k])])
     return lp
+
+
+class _ShardedLogProb:
+    """``log_prob_fn`` of the exact single-ensemble sharding (SURVEY.md 8e option 1; the reference runs ONE ensemble on
+    one RNG, ``bask/bayesgpr.py:490-530``): every rank is handed the same (B, p) block, evaluates the LML of its own
+    rows [r B/G, (r+1) B/G) on its device and the log-priors of ALL rows on the host meanwhile; ``finish`` gathers the B
+    log-likelihoods device to device (``distributed.allgather_lml``: one RCCL all-gather of B doubles per half-step).
+    Same arithmetic per row as ``_AsyncLogProb``: the chain equals the single-GPU chain bit for bit."""
+
+    def __init__(self, gp):
+        self._gp = gp
+
+    def __call__(self, Theta, priors, warp_priors=None):
+        return self.finish(self.begin(Theta, priors, warp_priors))
+
+    def begin(self, Theta, priors, warp_priors=None):
+        gp = self._gp
+        Theta = np.atleast_2d(np.asarray(Theta, dtype=np.float64))
+        if distributed.backend() is None:
+            return ("single", gp._log_prob_begin(Theta, priors, warp_priors))
+        rank, _lr, ws = distributed.world()
+        B = Theta.shape[0]
+        lo, hi = distributed.shard_rows(B, rank, ws)
+        if gp.warp_inputs:  # per-walker warps: this rank's finished values are gathered from the host
+            return ("host", B, gp._log_prob_begin(Theta[lo:hi], priors, warp_priors) if hi > lo else None)
+        H = gp._canonical(Theta[lo:hi])
+        # decided from what every rank sees alike (same block, same context settings): all ranks gather the same way
+        can_async = not gp._ctx._timing and -(-B // ws) <= gp._ctx.max_batch
+        native = distributed.backend() == "rccl" and can_async
+        submitted = gp._ctx.lml_submit(H) if (can_async and hi > lo) else False
+        try:
+            lp = _eval_priors(priors, Theta)  # all rows on every rank, while the device factorises this rank's
+        except BaseException:
+            if submitted:
+                gp._ctx.lml_wait()
+            raise
+        return ("dev", B, lp, H, submitted, native, hi > lo)
+
+    def finish(self, token):
+        gp = self._gp
+        if token[0] == "single":
+            return gp._log_prob_finish(token[1])
+        if token[0] == "host":
+            _k, B, tok = token
+            local = gp._log_prob_finish(tok) if tok is not None else np.zeros(0)
+            return distributed.allgather_lml(None, B, local=local)
+        _k, B, lp, H, submitted, native, has_rows = token
+        if native:
+            lml = distributed.allgather_lml(gp._ctx, B)
+        else:  # gloo group (CPU tests, ranks sharing one GPU) or a batch that could not go asynchronously
+            local = (gp._ctx.lml_wait() if submitted else gp._ctx.lml(H)) if has_rows else np.zeros(0)
+            lml = distributed.allgather_lml(None, B, local=local)
+        with np.errstate(invalid="ignore"):
+            lp = lp + lml
+        lp[~np.isfinite(lp)] = -np.inf
+        return lp
 
 
 class _AsyncLogProb:

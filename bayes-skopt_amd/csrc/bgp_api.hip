@@ -133,8 +133,8 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_LEFT_LOOKING", "BGP_PANELS", "BGP_PANEL_WIDTH",
-                                "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_SYRK2", "BGP_TWO_PANEL"};
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
+                                "BGP_PANEL_WIDTH", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -191,20 +191,14 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     if (ns < 1) ns = 1;
     if (ns > BGP_MAX_STREAMS) ns = BGP_MAX_STREAMS;
     c->nstreams = ns;
-    const char* envl = getenv("BGP_LEFT_LOOKING");
-    c->left_looking = (envl && atoi(envl) != 0) ? 1 : 0;
-    const char* envs = getenv("BGP_SYRK2");
-    c->use_syrk2 = (envs && atoi(envs) != 0) ? 1 : 0;
     const char* envss = getenv("BGP_SMALL_SPLIT");  // 1: n <= 128 through the two-launch path (A/B of the fused kernel)
     c->use_small_split = (envss && atoi(envss) != 0) ? 1 : 0;
     const char* envk = getenv("BGP_KBUILD1");
     c->use_kbuild1 = (envk && atoi(envk) != 0) ? 1 : 0;
     const char* envf = getenv("BGP_FUSED_GRAM");
     c->fused_gram = (envf && atoi(envf) != 0) ? 1 : 0;
-    const char* envt = getenv("BGP_TWO_PANEL");
-    c->two_panel = (envt && atoi(envt) == 0) ? 0 : 1;
-    c->panels = c->two_panel ? 2 : 1;
-    c->panels_auto = envt ? 0 : 1;
+    c->panels = 2;
+    c->panels_auto = 1;
     const char* envp = getenv("BGP_PANELS");
     if (envp && atoi(envp) >= 1 && atoi(envp) <= 8) {
       c->panels = atoi(envp);
@@ -275,6 +269,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->hlml) (void)hipHostFree(c->hlml);
   if (c->hstatus) (void)hipHostFree(c->hstatus);
   if (c->hh) (void)hipHostFree(c->hh);
+  if (c->hwarp) (void)hipHostFree(c->hwarp);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
@@ -374,8 +369,8 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     }
     BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = BGP_OK;
-    const bool fused_small = c->nblk == 1 && !warp && !c->left_looking && !c->use_small_split;
-    const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->left_looking && !c->use_syrk2 && !c->use_kbuild1;
+    const bool fused_small = c->nblk == 1 && !warp && !c->use_small_split;
+    const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {
       // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
@@ -399,9 +394,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       }
       if (rc) return rc;
     } else if (ng == 1) {
-      if (c->left_looking) {
-        rc = bgp_launch_cholesky_ll_slice(c, 0, nb, c->stream, 1);
-      } else if (fused_gram) {
+      if (fused_gram) {
         S4Gen gen;
         rc = bgp_launch_kbuild_col0(c, 0, nb, c->stream, 1, c->dXeff, 0, &gen);
         if (rc) return rc;
@@ -418,9 +411,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         const int gb = std::min(gsz, nb - o);
         hipStream_t st = c->gstream[g];
         BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
-        if (c->left_looking) {
-          rc = bgp_launch_cholesky_ll_slice(c, o, gb, st, 1);
-        } else if (fused_gram) {
+        if (fused_gram) {
           S4Gen gen;
           rc = bgp_launch_kbuild_col0(c, o, gb, st, 1, c->dXeff, 0, &gen);
           if (rc) return rc;
@@ -478,18 +469,21 @@ static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp
 // Asynchronous form of bgp_lml_batch for the sampler's inner loop: submit enqueues the whole half-step (upload of the
 // proposals, K-build, factorisation, download of the B log-likelihoods into pinned host memory) and returns; the
 // host evaluates the log-priors of the same proposals meanwhile and collects the device results with wait.
-extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h) {
+static int lml_submit_impl(bgp_ctx* c, int B, const double* h, const double* warp, const char* who) {
   if (!c || !h || B <= 0) {
-    bgp_set_error("bgp_lml_batch_submit: bad argument");
+    bgp_set_error("%s: bad argument", who);
     return BGP_ERR_INVALID;
   }
   if (c->pending_B != 0) {
-    bgp_set_error("bgp_lml_batch_submit: a submitted batch is still pending (call bgp_lml_batch_wait)");
+    bgp_set_error("%s: a submitted batch is still pending (call bgp_lml_batch_wait)", who);
     return BGP_ERR_STATE;
   }
-  if (B > c->max_batch || c->timing) {
-    bgp_set_error("bgp_lml_batch_submit: B = %d exceeds max_batch = %d (or per-launch timing is on): use bgp_lml_batch", B,
-                  c->max_batch);
+  if (c->timing) {  // per-launch timing synchronises inside the call: not an argument error, a mode (BGP_ERR_STATE)
+    bgp_set_error("%s: per-launch timing is on (bgp_set_timing): use bgp_lml_batch", who);
+    return BGP_ERR_STATE;
+  }
+  if (B > c->max_batch) {
+    bgp_set_error("%s: B = %d exceeds max_batch = %d: use bgp_lml_batch", who, B, c->max_batch);
     return BGP_ERR_INVALID;
   }
   BGP_HIP(hipSetDevice(c->device));
@@ -506,11 +500,13 @@ extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h) {
     BGP_HIP(hipHostMalloc(&c->hh, (size_t)c->max_batch * (c->d + 2) * sizeof(double)));
     c->cap_pinned = c->max_batch;
   }
+  if (warp && !c->hwarp) BGP_HIP(hipHostMalloc(&c->hwarp, (size_t)c->max_batch * 2 * c->d * sizeof(double)));
   // the proposals go up from pinned memory too: an asynchronous copy out of a pageable numpy array costs the runtime
   // a page lock / unlock per call (tens of microseconds in front of every half-step)
   memcpy(c->hh, h, (size_t)B * (c->d + 2) * sizeof(double));
+  if (warp) memcpy(c->hwarp, warp, (size_t)B * 2 * c->d * sizeof(double));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  const int rc = lml_batch_run(c, B, c->hh, nullptr, c->hlml, c->hstatus, e0, e1, 1);
+  const int rc = lml_batch_run(c, B, c->hh, warp ? c->hwarp : nullptr, c->hlml, c->hstatus, e0, e1, 1);
   if (rc != BGP_OK) {
     (void)hipStreamSynchronize(c->stream);
     for (int g = 0; g < BGP_MAX_STREAMS; g++)
@@ -520,6 +516,20 @@ extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h) {
   }
   c->pending_B = B;
   return BGP_OK;
+}
+
+extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h) {
+  return lml_submit_impl(c, B, h, nullptr, "bgp_lml_batch_submit");
+}
+
+// The same for walkers that carry their own input warp (bask/bayesgpr.py:353-365): the (B, 2d) Beta parameters go up
+// through pinned memory with the hyper-parameters; bgp_lml_batch_wait collects.
+extern "C" int bgp_lml_batch_warped_submit(bgp_ctx* c, int B, const double* h, const double* warp) {
+  if (!warp) {
+    bgp_set_error("bgp_lml_batch_warped_submit: NULL warp");
+    return BGP_ERR_INVALID;
+  }
+  return lml_submit_impl(c, B, h, warp, "bgp_lml_batch_warped_submit");
 }
 
 extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
@@ -566,6 +576,7 @@ extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
     bgp_set_error("bgp_set_streams: nstreams must be in 1..%d", BGP_MAX_STREAMS);
     return BGP_ERR_INVALID;
   }
+  BGP_REQUIRE_IDLE(c, "bgp_set_streams");
   BGP_HIP(hipSetDevice(c->device));
   for (int g = 0; g < nstreams; g++) {
     if (!c->gstream[g]) {
@@ -580,6 +591,7 @@ extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
 
 extern "C" int bgp_set_timing(bgp_ctx* c, int enable) {
   if (!c) return BGP_ERR_INVALID;
+  BGP_REQUIRE_IDLE(c, "bgp_set_timing");
   c->timing = enable ? 1 : 0;
   return BGP_OK;
 }

@@ -12,15 +12,13 @@
 //                 z_k = W_kk y_k, running log-det and z^T z                    (latency: 128 sequential pivots)
 //   panel solve   X_i = A_ik W_kk^T  (fp64 MFMA),  y_i -= X_i z_k
 //   trailing upd. A_ij -= X_i X_j^T  (fp64 MFMA; the n^3/3 bulk -- the kernel the roofline fraction is quoted on)
-// Two generations of the last two live here:
-//   * LML path (bgp_lml_batch; the MCMC hot loop): trsm4_kernel / syrk4_kernel on the LDS-DMA ring (bgp_syrk4.hip),
-//     scheduled in groups of P block columns by bgp_launch_cholesky_gen below (BGP_SYRK2=1: round 1's syrk2_kernel +
-//     trsm8_kernel, kept as the bit-identical A/B reference);
+// Panel solve and trailing update are trsm4_kernel / syrk4_kernel on the LDS-DMA ring (bgp_syrk4.hip):
+//   * LML path (bgp_lml_batch; the MCMC hot loop): scheduled in groups of P block columns by bgp_launch_cholesky_gen;
 //   * posterior builds on the augmented matrix (bgp_post.hip; once per sample(), per hyper-posterior draw of an
-//     acquisition and per gradient evaluation): the same ring kernels in single-panel mode with the active-row remap
-//     of bgp_rowblk (bgp_device.h).  BGP_SYRK2=1 keeps round 1's trsm_kernel / syrk_kernel of this file: one NT tile
-//     GEMM on v_mfma_f64_16x16x4_f64, 4 waves as 2x2, each wave a 64x64 sub-tile = 4x4 MFMA tiles (128 accumulator
-//     VGPRs), operands staged through LDS in 128x32 chunks with leading dimension 34.
+//     acquisition and per gradient evaluation): the same kernels in single-panel mode with the active-row remap of
+//     bgp_rowblk (bgp_device.h).
+// (Round 1's VGPR-staged trsm_kernel / syrk_kernel / syrk2_kernel / trsm8_kernel and the left-looking variant are A/B
+// references of the benches under tools/legacy/ now; they are not part of libbgp.so.)
 #include "bgp_common.h"
 #include "bgp_device.h"
 
@@ -537,253 +535,9 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   PF_T(28);
 }
 
-// ------------------------------------------------------------------------------------------
-// trsm: X_i = A_ik W_kk^T for every row block i > k, then y_i -= X_i z_k.
-// ------------------------------------------------------------------------------------------
-// Active row blocks below the diagonal at step k: the nlow = nblk-k-1 remaining blocks of K, then
-// (posterior builds only) the first k+1 block rows of the identity part of the augmented matrix
-// [[K, .], [I, 0]], which starts at block row `aug`.  Running the same three kernels on the
-// augmented matrix for nblk steps leaves L (top-left), L^-T (bottom-left), the Schur complement
-// -K^-1 (bottom-right) and -alpha = -(K^-1 y) in the lower half of the working right-hand side.
-// (bgp_rowblk: bgp_device.h)
-
-__global__ void __launch_bounds__(256) trsm_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf,
-                                                    double* __restrict__ yw, const int* __restrict__ status,
-                                                    int ld, size_t mstride, int ystride, int nblk, int k, int nact,
-                                                    int aug, int B) {
-  int b, t;
-  bgp_map_block(blockIdx.x, nact, B, b, t);
-  if (b >= B || status[b] != 0) return;
-  __shared__ GemmSmem sm;
-  // 4 waves stacked along the rows (32 rows x 128 columns each): every wave sees the same
-  // triangular structure of W_kk, so the k-skip leaves them equally loaded
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int r0 = w * 32;
-  const int ib = bgp_rowblk(t, k, nblk - k - 1, aug);
-  double* Atile = Kbuf + (size_t)b * mstride + (size_t)(ib * 128) * ld + k * 128;
-  const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-
-  d4 acc[2][8];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < 8; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  for (int k0 = 0; k0 < 128; k0 += GK_KC) {
-    __syncthreads();
-    gk_load_chunk(sm.A, Atile + k0, (size_t)ld, tid);
-    gk_load_chunk(sm.B, W + k0, (size_t)128, tid);
-    __syncthreads();
-    gk_mma_block<2, 8, 0, 1, -64>(sm.A, sm.B, acc, r0, 0, lane, k0);
-  }
-  // In-place overwrite is safe: every global read of this A tile was staged into LDS before the
-  // last chunk's barrier, and no other workgroup touches the tile in this launch.
-  const double* zk = yw + (size_t)b * ystride + k * 128;
-  double zc[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-  double* yi = yw + (size_t)b * ystride + ib * 128;
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = GK_ROWB(r0, i, lane, r);
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const double x = acc[i][j][r];
-        Atile[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
-        part += x * zc[j];
-      }
-      // reduce over the 16 lanes that share this row (lane & 15 varies); the row belongs to this
-      // wave alone, so the right-hand side is updated directly
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
-      if ((lane & 15) == 0) yi[row] -= part;
-    }
-  }
-}
-
-static __device__ __forceinline__ void syrk_diag_tile(GemmSmem& sm, const double* __restrict__ XI,
-                                                      double* __restrict__ C, int ld, int tid, int lane, int w,
-                                                      int K = 128) {
-  // wave 0 / 1: the two 64x64 triangles on the diagonal (10 MFMA tiles each);
-  // wave 2 / 3: the 64x64 square below the diagonal cut into two 32x64 halves (8 MFMA tiles each).
-  // Barriers and staging are common code; only the register block differs per wave.
-  d4 acc[4][4];
-  d4(&acc2)[2][4] = reinterpret_cast<d4(&)[2][4]>(acc);
-  const int r0 = (w == 0) ? 0 : (w == 1) ? 64 : (w == 2) ? 64 : 96;
-  const int c0 = (w == 1) ? 64 : 0;
-  if (w < 2)
-    gk_load_c<4, 4, 0>(C, (size_t)ld, acc, r0, c0, lane);
-  else
-    gk_load_c<2, 4, -64>(C, (size_t)ld, acc2, r0, c0, lane);
-  for (int k0 = 0; k0 < K; k0 += GK_KC) {
-    __syncthreads();
-    gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-    __syncthreads();
-    if (w < 2)
-      gk_mma_block<4, 4, 1, 0, 0>(sm.A, sm.A, acc, r0, c0, lane, k0);
-    else
-      gk_mma_block<2, 4, 1, 0, -64>(sm.A, sm.A, acc2, r0, c0, lane, k0);
-  }
-  if (w < 2)
-    gk_store_c<4, 4, 0>(C, (size_t)ld, acc, r0, c0, lane);
-  else
-    gk_store_c<2, 4, -64>(C, (size_t)ld, acc2, r0, c0, lane);
-}
-
-// ------------------------------------------------------------------------------------------
-// syrk: trailing update A_ij -= X_i X_j^T for k < j <= i.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) syrk_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
-                                                    int ld, size_t mstride, int nblk, int k, int nact, int aug,
-                                                    int B) {
-  const int ntile = nact * (nact + 1) / 2;
-  int b, t;
-  bgp_map_block(blockIdx.x, ntile, B, b, t);
-  if (b >= B || status[b] != 0) return;
-  int ti, tj;
-  bgp_tri_decode(t, ti, tj);
-  const int I = bgp_rowblk(ti, k, nblk - k - 1, aug), J = bgp_rowblk(tj, k, nblk - k - 1, aug);
-  __shared__ GemmSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-  double* M = Kbuf + (size_t)b * mstride;
-  const double* XI = M + (size_t)(I * 128) * ld + k * 128;
-  const double* XJ = M + (size_t)(J * 128) * ld + k * 128;
-  double* C = M + (size_t)(I * 128) * ld + J * 128;
-
-  if (I != J) {
-    d4 acc[4][4];
-    gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
-    for (int k0 = 0; k0 < 128; k0 += GK_KC) {
-      __syncthreads();
-      gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-      gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
-      __syncthreads();
-      gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
-    }
-    gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
-  } else {
-    // Diagonal tile: only its lower triangle (36 of the 64 16x16 MFMA tiles) is ever read again,
-    // split 10 / 10 / 8 / 8 over the waves: two 4x4 triangles and the 4x4 square below the
-    // diagonal cut in two.  X_I is staged once and serves as both operands.
-    syrk_diag_tile(sm, XI, C, ld, tid, lane, w);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// syrk2: trailing update of the LML path with a panel of width K = 128 or 256 (two factorised block
-// columns at once: halves the C-tile traffic and the per-tile prologue/epilogue per flop).
-//   A_IJ -= X_I X_J^T,  X_I = rows of block I, columns [kp*128, kp*128 + K)
-//   colmode 1: only block column jstart (the look-ahead column the next potrf/trsm need)
-//   colmode 0: every tile with I >= J >= jstart
-// ------------------------------------------------------------------------------------------
-template <int SPLIT>
-__global__ void __launch_bounds__(256, 2) syrk2_kernel(double* __restrict__ Kbuf, const int* __restrict__ status,
-                                                       int ld, size_t mstride, int nblk, int kp, int K, int jstart,
-                                                       int colmode, int B) {
-  const int nt = nblk - jstart;
-  const int ntile = colmode ? nt : nt * (nt + 1) / 2;
-  int b, t;
-  bgp_map_block(blockIdx.x, SPLIT * ntile, B, b, t);
-  if (b >= B || status[b] != 0) return;
-  // SPLIT == 2 (small launches that would leave the GPU under-filled): two workgroups per tile, 64 rows each
-  const int half = (SPLIT == 2) ? (t & 1) : 0;
-  if (SPLIT == 2) t >>= 1;
-  int ti, tj;
-  if (colmode) {
-    ti = t;
-    tj = 0;
-  } else {
-    bgp_tri_decode(t, ti, tj);
-  }
-  const int I = jstart + ti, J = jstart + tj;
-  __shared__ GemmSmem sm;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
-  double* M = Kbuf + (size_t)b * mstride;
-  const double* XI = M + (size_t)(I * 128) * ld + kp * 128;
-  const double* XJ = M + (size_t)(J * 128) * ld + kp * 128;
-  double* C = M + (size_t)(I * 128) * ld + J * 128;
-
-  if (I != J) {
-    if (SPLIT == 2) {
-      // small launches are latency-bound: the next chunk's global loads are in flight (registers) while the
-      // current one is multiplied -- the half-size accumulator block leaves room for the 64 staging VGPRs
-      d4 acc[2][4];
-      const int r0 = half * 64 + wr * 32;
-      d2 va[8], vb[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int c = tid + 256 * i;
-        va[i] = *reinterpret_cast<const d2*>(XI + (size_t)(c >> 4) * ld + (c & 15) * 2);
-        vb[i] = *reinterpret_cast<const d2*>(XJ + (size_t)(c >> 4) * ld + (c & 15) * 2);
-      }
-      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
-      for (int k0 = 0; k0 < K; k0 += GK_KC) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int c = tid + 256 * i;
-          *reinterpret_cast<d2*>(sm.A + (c >> 4) * GK_LD + (c & 15) * 2) = va[i];
-          *reinterpret_cast<d2*>(sm.B + (c >> 4) * GK_LD + (c & 15) * 2) = vb[i];
-        }
-        __syncthreads();
-        if (k0 + GK_KC < K) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const int c = tid + 256 * i;
-            va[i] = *reinterpret_cast<const d2*>(XI + k0 + GK_KC + (size_t)(c >> 4) * ld + (c & 15) * 2);
-            vb[i] = *reinterpret_cast<const d2*>(XJ + k0 + GK_KC + (size_t)(c >> 4) * ld + (c & 15) * 2);
-          }
-        }
-        gk_mma_block<2, 4, 1, 0, -64>(sm.A, sm.B, acc, r0, wc * 64, lane, k0);
-      }
-      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, r0, wc * 64, lane);
-    } else {
-      d4 acc[4][4];
-      gk_load_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
-      for (int k0 = 0; k0 < K; k0 += GK_KC) {
-        __syncthreads();
-        gk_load_chunk(sm.A, XI + k0, (size_t)ld, tid);
-        gk_load_chunk(sm.B, XJ + k0, (size_t)ld, tid);
-        __syncthreads();
-        gk_mma_block<4, 4, 1, 0, -64>(sm.A, sm.B, acc, wr * 64, wc * 64, lane, k0);
-      }
-      gk_store_c<4, 4, -64>(C, (size_t)ld, acc, wr * 64, wc * 64, lane);
-    }
-  } else {
-    if (half) return;  // diagonal tiles (half the work of a full tile already) stay on one workgroup
-    syrk_diag_tile(sm, XI, C, ld, tid, lane, w, K);
-  }
-}
-
-// tiles x walkers below this many workgroups: split the off-diagonal tiles over two workgroups each
-#define SYRK_SPLIT_BELOW 1024
-static void launch_syrk2(hipStream_t st, int B8, int ntile, double* dK, const int* dstatus, int ld, size_t mstride,
-                         int nblk, int kp, int K, int jstart, int colmode, int B) {
-  if (B8 * ntile < SYRK_SPLIT_BELOW)
-    hipLaunchKernelGGL(syrk2_kernel<2>, dim3(B8 * ntile * 2), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,
-                       jstart, colmode, B);
-  else
-    hipLaunchKernelGGL(syrk2_kernel<1>, dim3(B8 * ntile), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,
-                       jstart, colmode, B);
-}
-
-#ifdef PF_TRACE
-extern "C" void bgp_debug_launch_syrk2(hipStream_t st, int B8, int ntile, double* dK, const int* dstatus, int ld,
-                                       size_t mstride, int nblk, int kp, int K, int jstart, int colmode, int B) {
-  launch_syrk2(st, B8, ntile, dK, dstatus, ld, mstride, nblk, kp, K, jstart, colmode, B);
-}
-#endif
-
-// LDS-DMA pipelined trailing update (bgp_syrk4.hip): the default of the LML path; BGP_SYRK2=1 selects syrk2_kernel
+// LDS-DMA pipelined trailing update and panel solve (bgp_syrk4.hip)
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
                       int K, int jstart, int colmode, int B, const S4Gen* gen);
-void bgp_launch_trsm8(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
-                      int ystride, int nblk, int k);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k, int augmented);
 
@@ -837,7 +591,7 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
   double* dlml = ctx->dlml + off;
   int* dstatus = ctx->dstatus + off;
   if (!augmented) {
-    // LML path: panel solve on the 4x4x4 MFMA core (bgp_llchol.hip) and multi-panel trailing updates.  A group
+    // LML path: multi-panel trailing updates.  A group
     // of P block columns is factorised with look-ahead column updates only, then everything to its right is
     // updated ONCE with the whole K = 128 P panel (P times fewer passes over the trailing matrix):
     //   potrf(k) trsm(k) | col k+1 (K=128) | potrf(k+1) trsm(k+1) | col k+2 (K=256) | ... | rest (K = 128 P)
@@ -855,27 +609,18 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
         bgp_tend(ctx, st);
         if (k + j + 1 >= nblk) break;
         bgp_tbegin(ctx, 2, st);
-        if (ctx->use_syrk2)
-          bgp_launch_trsm8(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j);
-        else
-          bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
+        bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 3, st);
-          if (ctx->use_syrk2)
-            launch_syrk2(st, B8, nblk - (k + j + 1), dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
-          else
-            bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
+          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
           bgp_tend(ctx, st);
         }
       }
       const int nt = nblk - (k + np);
       if (nt > 0) {
         bgp_tbegin(ctx, 3, st);
-        if (ctx->use_syrk2)
-          launch_syrk2(st, B8, nt * (nt + 1) / 2, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
-        else
-          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B, k == 0 ? gen : nullptr);
+        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B, k == 0 ? gen : nullptr);
         bgp_tend(ctx, st);
       }
       k += np;
@@ -883,32 +628,19 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     BGP_HIP(hipGetLastError());
     return BGP_OK;
   }
+  // posterior build: nblk steps on the augmented matrix, the ring kernels in single-panel mode with the active-row
+  // remap of bgp_rowblk (nblk active row blocks at every step)
   for (int k = 0; k < nblk; k++) {
     bgp_tbegin(ctx, 1, st);
     hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus, ctx->n,
                        ld, mstride, ystride, nblk, k, PfGen());
     bgp_tend(ctx, st);
-    const int nlow = nblk - k - 1;
-    const int nact = augmented ? nblk : nlow;
-    if (nact > 0) {
-      // posterior builds (augmented) run the ring kernels with the active-row remap; BGP_SYRK2=1 keeps round 1's
-      // trsm_kernel / syrk_kernel as the A/B reference (they also serve a non-augmented single-panel call)
-      const bool ring = augmented && !ctx->use_syrk2;
-      bgp_tbegin(ctx, 2, st);
-      if (ring)
-        bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, 1);
-      else
-        hipLaunchKernelGGL(trsm_kernel, dim3(B8 * nact), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride,
-                           nblk, k, nact, nblk, B);
-      bgp_tend(ctx, st);
-      bgp_tbegin(ctx, 3, st);
-      if (ring)
-        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128, 0, 2, B, nullptr);
-      else
-        hipLaunchKernelGGL(syrk_kernel, dim3(B8 * (nact * (nact + 1) / 2)), dim3(256), 0, st, dK, dstatus, ld, mstride,
-                           nblk, k, nact, nblk, B);
-      bgp_tend(ctx, st);
-    }
+    bgp_tbegin(ctx, 2, st);
+    bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, 1);
+    bgp_tend(ctx, st);
+    bgp_tbegin(ctx, 3, st);
+    bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128, 0, 2, B, nullptr);
+    bgp_tend(ctx, st);
   }
   BGP_HIP(hipGetLastError());
   return BGP_OK;

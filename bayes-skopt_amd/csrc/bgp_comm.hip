@@ -4,7 +4,12 @@
 // communicator's own HIP stream over device-resident staging buffers that are grown on demand and reused.
 // librccl is loaded lazily with dlopen: libbgp.so has no link-time dependency on it and single-GPU use never
 // touches it.  The rendezvous (rank 0's ncclUniqueId to every rank) is the caller's: bayes-skopt_amd/distributed.py
-// ships the 128 bytes over a TCP socket on MASTER_ADDR:MASTER_PORT.
+// hands the 128 bytes over through a per-job file in a per-user directory on a single node (every rank then reports
+// "have it" / "failed" before anybody enters ncclCommInitRank), or over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1)
+// across nodes.
+// Device-resident exchange: bgp_lml_batch_wait_allgather gathers the log-likelihoods of a submitted batch straight
+// out of every rank's context (no host staging on the send side): the per-half-step exchange of the exact
+// single-ensemble sharding.
 #include "bgp_common.h"
 
 #include <dlfcn.h>
@@ -17,6 +22,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -43,6 +49,7 @@ int load_rccl() {
   BGP_SYM(GetUniqueId, "ncclGetUniqueId")
   BGP_SYM(CommInitRank, "ncclCommInitRank")
   BGP_SYM(CommDestroy, "ncclCommDestroy")
+  BGP_SYM(CommCount, "ncclCommCount")
   BGP_SYM(AllGather, "ncclAllGather")
   BGP_SYM(AllReduce, "ncclAllReduce")
   BGP_SYM(Broadcast, "ncclBroadcast")
@@ -60,6 +67,9 @@ struct bgp_comm {
   double* dsend = nullptr;  // device-resident staging, grown on demand
   double* drecv = nullptr;
   size_t cap_send = 0, cap_recv = 0;
+  double* hrecv = nullptr;  // pinned landing buffer of the device-resident gathers
+  size_t cap_hrecv = 0;
+  hipEvent_t ev = nullptr;  // "the context's stream has produced its log-likelihoods"
 };
 
 #define BGP_NCCL(call)                                                                          \
@@ -180,8 +190,58 @@ extern "C" void bgp_comm_destroy(bgp_comm* c) {
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->dsend) (void)hipFree(c->dsend);
   if (c->drecv) (void)hipFree(c->drecv);
+  if (c->hrecv) (void)hipHostFree(c->hrecv);
+  if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+// Ranks RCCL itself counts in the communicator (ncclCommCount): what a caller reports as "the group that really formed".
+extern "C" int bgp_comm_nranks(bgp_comm* c, int* nranks) {
+  if (!c || !nranks) {
+    bgp_set_error("bgp_comm_nranks: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_NCCL(g_rccl.CommCount(c->comm, nranks));
+  return BGP_OK;
+}
+
+// Exact single-ensemble sharding (SURVEY.md 8e option 1): every rank has submitted ITS rows of the half-step's proposal
+// block with bgp_lml_batch_submit (at most per_rank of them); this call replaces bgp_lml_batch_wait.  The communicator's
+// stream waits for the context's stream, RCCL all-gathers per_rank doubles straight out of every context's device-resident
+// log-likelihood vector, and ONE copy brings the world * per_rank values to the host (rank-major; the entries behind a
+// rank's own row count are padding).  No host staging on the send side, no second synchronisation.
+extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_rank, double* lml_all) {
+  if (!ctx || !c || !lml_all || per_rank <= 0) {
+    bgp_set_error("bgp_lml_batch_wait_allgather: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (per_rank > ctx->max_batch || ctx->pending_B > per_rank || ctx->device != c->device) {
+    bgp_set_error("bgp_lml_batch_wait_allgather: per_rank = %d must cover the pending batch (%d) and fit max_batch = %d, on "
+                  "the communicator's device", per_rank, ctx->pending_B, ctx->max_batch);
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  const size_t total = (size_t)per_rank * c->world;
+  int rc = comm_reserve(c, 0, total);
+  if (rc) return rc;
+  if (total > c->cap_hrecv) {
+    if (c->hrecv) (void)hipHostFree(c->hrecv);
+    c->hrecv = nullptr;
+    c->cap_hrecv = 0;
+    BGP_HIP(hipHostMalloc((void**)&c->hrecv, total * sizeof(double), hipHostMallocDefault));
+    c->cap_hrecv = total;
+  }
+  if (!c->ev) BGP_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+  ctx->pending_B = 0;  // (a rank without rows of its own has nothing pending: it contributes padding)
+  BGP_HIP(hipEventRecord(c->ev, ctx->stream));
+  BGP_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+  BGP_NCCL(g_rccl.AllGather(ctx->dlml, c->drecv, (size_t)per_rank, ncclFloat64, c->comm, c->stream));
+  BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(hipStreamSynchronize(ctx->stream));  // (its own download of the local values: long done)
+  memcpy(lml_all, c->hrecv, total * sizeof(double));
+  return BGP_OK;
 }
 
 extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count, double* recv) {

@@ -39,11 +39,8 @@ struct bgp_ctx {
   hipStream_t stream = nullptr;
   // walker groups: the batch of an LML call is split over nstreams HIP streams so that the
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
-  int use_syrk2 = 0;     // trailing update with the VGPR-staged syrk2_kernel instead of syrk4_kernel (env BGP_SYRK2=1)
-  int two_panel = 1;     // (legacy switch) env BGP_TWO_PANEL=0 == BGP_PANELS=1
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
-  int panels_auto = 1;   // no BGP_PANELS / BGP_TWO_PANEL in the environment: chosen per problem size (bgp_chol.hip)
-  int left_looking = 0;  // LML path: right-looking kernels of bgp_chol.hip (default) or bgp_llchol.hip (experimental)
+  int panels_auto = 1;   // no BGP_PANELS in the environment: chosen per problem size (bgp_chol.hip)
   int nstreams = 1;
   int streams_auto = 1;  // choose the group count per call from the batch size (see bgp_ctx_create)
   hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};
@@ -94,6 +91,7 @@ struct bgp_ctx {
   double* hstage = nullptr;  // pinned staging of the training set (bgp_ctx_update_data)
   size_t cap_stage = 0;
   double* hh = nullptr;      // pinned copy of the submitted hyper-parameter block
+  double* hwarp = nullptr;   // pinned copy of the submitted per-walker warp parameters (max_batch * 2d)
   double* hlml = nullptr;
   int* hstatus = nullptr;
   size_t cap_pinned = 0;
@@ -193,6 +191,3 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
 // n <= 128: K-build + factorisation + LML of the slice [off, off+B) in ONE launch (bgp_chol.hip, potrf_kernel<1,..>)
 int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st);
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);
-// LML path: left-looking update with fused kernel-matrix generation (bgp_llchol.hip); replaces
-// bgp_launch_kbuild_slice + bgp_launch_cholesky_slice(augmented = 0)
-int bgp_launch_cholesky_ll_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha);

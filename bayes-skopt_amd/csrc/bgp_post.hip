@@ -1051,10 +1051,8 @@ static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out) {
     w->cap_n = mpad;
     c->child = w;
   }
-  w->two_panel = c->two_panel;
   w->panels = c->panels;
   w->panels_auto = c->panels_auto;
-  w->use_syrk2 = c->use_syrk2;
   *out = w;
   return BGP_OK;
 }

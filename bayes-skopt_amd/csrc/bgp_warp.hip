@@ -97,6 +97,7 @@ extern "C" int bgp_beta_cdf(bgp_ctx* c, int m, const double* X, const double* wa
     bgp_set_error("bgp_beta_cdf: bad argument");
     return BGP_ERR_INVALID;
   }
+  BGP_REQUIRE_IDLE(c, "bgp_beta_cdf");
   BGP_HIP(hipSetDevice(c->device));
   const size_t md = (size_t)m * c->d;
   int rc = bgp_ensure_scratch(c, 2 * md + 2 * (size_t)c->d + 8);

@@ -1,40 +1,44 @@
-"""Multi-GPU sharding of the MCMC chains: one process per GPU (launched by ``torch.distributed.run`` or any other
-launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+"""Multi-GPU sharding of the hyper-posterior MCMC: one process per GPU (launched by ``torch.distributed.run``, by
+``bench.py --gpus N`` itself, or by any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
 
-Default (SURVEY.md 8(e) option 2 / BASELINE.json north_star: "chains shard naturally ... RCCL over xGMI
-only for the final posterior-sample gather"): each rank runs an independent sub-ensemble on its own
-device with NO collective in the sampling loop; the only exchange is the final gather of the posterior
-samples (``gather_chains``).
+Exact single-ensemble sharding (SURVEY.md 8(e) option 1; what ``bask/bayesgpr.py:490-530`` runs is ONE
+``n_walkers`` ensemble on one RNG): every rank holds the same data and drives the same sampler RNG, so all ranks
+propose the same (B, p) block each half-step; rank r evaluates rows [r*B/G, (r+1)*B/G) on its device and the B
+log-likelihoods are all-gathered (``ShardedLogProb`` in bayesgpr.py through ``allgather_lml``: device to device over RCCL,
+one latency-bound collective of B doubles per half-step).  Accept/reject then runs identically on every rank and the
+chain equals the single-GPU chain bit for bit.
 
-Option (SURVEY.md 8(e) option 1, exact single-ensemble semantics): every rank holds the same data and
-the same sampler RNG, so all ranks propose the same (B, p) block each half-step; ``shard_log_prob``
-makes rank r evaluate rows [r*B/G, (r+1)*B/G) on its device and all-gathers the B log-probabilities
-(one latency-bound collective of B doubles per half-step).  Accept/reject then runs identically on
-every rank and the chain equals the single-GPU chain bit for bit.
+Independent sub-ensembles (SURVEY.md 8(e) option 2): each rank its own walkers and seeds, NO collective in the
+sampling loop; the only exchange is the final gather of the posterior samples (``gather_chains``).
 
 Backends (``BGP_DIST_BACKEND`` or the ``backend`` argument):
-  ``rccl``  (default when this process sees a GPU) -- RCCL through libbgp's own C-ABI (``bgp_comm_*``,
-            csrc/bgp_comm.hip): no PyTorch anywhere in the product path.  Rank 0 creates the ncclUniqueId and
-            hands its 128 bytes to the other ranks through a file under /tmp on a single node (MASTER_ADDR =
-            loopback) or over a TCP socket on MASTER_ADDR:(MASTER_PORT + 1) otherwise (``BGP_COMM_TCP=1`` forces it,
-            ``BGP_COMM_PORT`` overrides the port; MASTER_PORT itself belongs to the launcher's rendezvous store).
-  ``gloo`` / ``nccl`` -- ``torch.distributed`` process groups: the CPU tests (world size 2 over gloo) and an A/B
-            path for the native one; torch is only imported when one of these is selected.
-When no backend is named and the native group cannot be formed (librccl missing, id exchange timed out,
-ncclCommInitRank refused the group) every rank reports it on stderr and the job continues over gloo: the only exchange
-on the default path is the final gather of host-resident chains.  A backend asked for by name fails loudly instead.
-``BGP_DIST_FORCE=1`` joins a group even at world size 1 (the GPU test that runs real RCCL collectives on one GPU).
+  ``rccl``  (default when every rank has a GPU of its own) -- RCCL through libbgp's own C-ABI (``bgp_comm_*``,
+            csrc/bgp_comm.hip): no PyTorch anywhere in the product path.  Rank 0 creates the ncclUniqueId and hands its
+            128 bytes to the other ranks through a file that is unique to the job (named after the common launcher
+            process and its start time, ``BGP_COMM_JOB`` overrides) in a per-user 0700 directory; every rank then
+            publishes "have it" / "failed" and nobody enters ncclCommInitRank before all ranks have it -- one rank
+            timing out cannot leave the others blocked in the collective.  Across nodes (MASTER_ADDR not loopback, or
+            ``BGP_COMM_TCP=1``): a TCP socket on MASTER_ADDR:(MASTER_PORT + 1) (``BGP_COMM_PORT`` overrides the port;
+            MASTER_PORT itself belongs to the launcher's rendezvous store).
+  ``gloo``  -- a ``torch.distributed`` CPU group: the world-size-2 CPU tests, and ranks that share one GPU (RCCL refuses
+            two ranks on a device); torch is only imported when this is selected.  There is no second GPU backend.
+When no backend is named and the native group cannot be formed (librccl missing, id exchange failed on ANY rank) every
+rank learns so from the same status files, says so on stderr and the job continues over gloo.  A backend asked for by
+name fails loudly instead.  ``BGP_DIST_FORCE=1`` joins a group even at world size 1 (the GPU test that runs real RCCL
+collectives on one GPU).
 """
 import os
 import socket
+import sys
+import tempfile
 import time
 
 import numpy as np
 
 __all__ = ["world", "init_process_group", "destroy_process_group", "gather_chains", "barrier", "max_over_ranks",
-           "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend"]
+           "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend", "group_info", "allgather_lml"]
 
-_state = {"backend": None, "comm": None, "rank": 0, "world": 1}
+_state = {"backend": None, "comm": None, "rank": 0, "world": 1, "device": None}
 
 
 def world():
@@ -44,7 +48,7 @@ def world():
 
 
 def backend():
-    """Name of the active backend ("rccl", "gloo", "nccl") or None outside a group."""
+    """Name of the active backend ("rccl", "gloo") or None outside a group."""
     return _state["backend"]
 
 
@@ -54,16 +58,12 @@ class _stdout_to_stderr:
     descriptor 1 points at standard error."""
 
     def __enter__(self):
-        import sys
-
         sys.stdout.flush()
         self._saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
-        import sys
-
         sys.stdout.flush()
         os.dup2(self._saved, 1)
         os.close(self._saved)
@@ -85,39 +85,142 @@ def _comm_endpoint():
     return host, port
 
 
-_T_START = time.time()
+def _job_id():
+    """A name every rank of THIS launch derives alike and no other launch shares: the common parent (torchrun's agent,
+    bench.py's self-spawning parent, a shell) and that process's start time in clock ticks (/proc/<pid>/stat field
+    22) -- a recycled pid has another start time, a crashed earlier job another parent.  ``BGP_COMM_JOB`` names it
+    explicitly for launchers whose ranks have no common parent."""
+    job = os.environ.get("BGP_COMM_JOB")
+    if job:
+        return job
+    ppid = os.getppid()
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        start = "0"
+    return "p%d_%s" % (ppid, start)
 
 
-def _uid_file():
-    tag = "%s_%s_%s_ws%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "29500"),
-                             os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("WORLD_SIZE", "1"))
-    return os.path.join(os.environ.get("BGP_COMM_DIR", "/tmp"), "bgp_comm_uid_" + tag.replace("/", "_"))
+def _comm_dir():
+    """Per-user directory (mode 0700, owned by this uid) for the rendezvous files: not a predictable name in a
+    world-writable place."""
+    base = os.environ.get("BGP_COMM_DIR")
+    if not base:
+        root = os.environ.get("XDG_RUNTIME_DIR")
+        if not (root and os.path.isdir(root) and os.access(root, os.W_OK)):
+            root = tempfile.gettempdir()
+        base = os.path.join(root, "bgp_comm_%d" % os.getuid())
+    os.makedirs(base, mode=0o700, exist_ok=True)
+    st = os.stat(base)
+    if st.st_uid != os.getuid():
+        raise RuntimeError(f"rendezvous directory {base} belongs to uid {st.st_uid}, not to this user")
+    if st.st_mode & 0o077 and not os.environ.get("BGP_COMM_DIR"):
+        os.chmod(base, 0o700)
+    return base
 
 
-def _exchange_unique_id(rank, ws, timeout=300.0):
-    """Rank 0's ncclUniqueId on every rank.  Single node (MASTER_ADDR is this host's loopback, what the launcher
-    contract uses): rank 0 drops the bytes into /tmp/bgp_comm_uid_<addr>_<port>_<run id> (atomic rename) and the
-    other ranks poll for a file no older than two minutes before their own start (rank 0 removes it at exit; a stale
-    one left by a crashed job with the same port and world size is ignored); no port beyond the launcher's own is needed.  Otherwise: a TCP socket on MASTER_ADDR:(MASTER_PORT+1)."""
+def _job_prefix(ws):
+    tag = "%s_%s_%s_ws%d" % (os.environ.get("MASTER_PORT", "29500"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                             _job_id(), ws)
+    return os.path.join(_comm_dir(), "job_" + tag.replace("/", "_"))
+
+
+def _write_private(path, data):
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(data)
+    os.replace(tmp, path)
+
+
+def _read_owned(path):
+    """Contents of a rendezvous file, or None while it does not exist; a file of another user is refused."""
+    try:
+        fd = os.open(path, os.O_RDONLY)
+    except OSError:
+        return None
+    with os.fdopen(fd, "rb") as f:
+        if os.fstat(f.fileno()).st_uid != os.getuid():
+            raise RuntimeError(f"rendezvous file {path} is not owned by this user")
+        return f.read()
+
+
+def _cleanup_job_files(prefix):
+    import glob
+
+    for p in glob.glob(prefix + ".*"):
+        try:
+            os.remove(p)
+        except OSError:
+            pass
+
+
+def _exchange_unique_id_files(rank, ws, timeout):
+    """Single node.  Phase 1: rank 0 writes <job>.uid (atomic rename), the others poll for it.  Phase 2: every rank
+    writes <job>.st.<rank> = b"ok" or b"fail: ..." and waits for all ws of them.  Returns the id when ALL ranks have
+    it; raises RuntimeError (on every rank alike) otherwise -- before anyone has entered ncclCommInitRank."""
     from . import _lib
 
-    local = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1") \
-        and os.environ.get("BGP_COMM_TCP") != "1"
-    if rank == 0:
-        uid = _lib.comm_unique_id()
-        if ws == 1:
-            return uid
-        if local:
-            path = _uid_file()
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "wb") as f:
-                f.write(uid)
-            os.replace(tmp, path)
+    prefix = _job_prefix(ws)
+    deadline = time.monotonic() + timeout
+    uid, err = None, None
+    try:
+        if rank == 0:
+            _cleanup_job_files(prefix)  # (nothing of this job can exist yet; a pid + start-time collision is unheard of)
+            uid = _lib.comm_unique_id()
+            _write_private(prefix + ".uid", uid)
             import atexit
 
-            atexit.register(lambda p=path: os.path.exists(p) and os.remove(p))  # no stale id for the next job
-            return uid
-        host, port = _comm_endpoint()
+            atexit.register(_cleanup_job_files, prefix)
+        else:
+            while uid is None:
+                buf = _read_owned(prefix + ".uid")
+                if buf is not None and len(buf) == _lib.COMM_ID_BYTES:
+                    uid = buf
+                elif _read_owned(prefix + ".abort") is not None:
+                    raise RuntimeError("another rank gave the native group up")
+                elif time.monotonic() > deadline:
+                    raise RuntimeError(f"no ncclUniqueId file {prefix}.uid from rank 0 within {timeout:.0f} s")
+                else:
+                    time.sleep(0.01)
+    except Exception as exc:  # reported to the others below, then raised
+        err = exc
+    _write_private("%s.st.%d" % (prefix, rank), b"ok" if err is None else ("fail: %r" % (err,)).encode())
+    # phase 2: the verdict of every rank
+    bad = None if err is None else "rank %d: %r" % (rank, err)
+    pending = set(range(ws))
+    while pending and bad is None:
+        for r in sorted(pending):
+            buf = _read_owned("%s.st.%d" % (prefix, r))
+            if buf is None:
+                continue
+            pending.discard(r)
+            if buf != b"ok":
+                bad = "rank %d: %s" % (r, buf.decode(errors="replace"))
+        if pending and bad is None:
+            if _read_owned(prefix + ".abort") is not None:
+                bad = "another rank gave the native group up"
+            elif time.monotonic() > deadline + 5.0:
+                bad = "no status from rank(s) %s within %.0f s" % (sorted(pending), timeout)
+            else:
+                time.sleep(0.01)
+    if bad is not None:
+        try:  # a rank that arrives late must not walk into the collective alone
+            _write_private(prefix + ".abort", bad.encode())
+        except OSError:
+            pass
+        raise RuntimeError("native RCCL group not formed (%s)" % bad)
+    return uid
+
+
+def _exchange_unique_id_tcp(rank, ws, timeout):
+    """Across nodes: rank 0 serves the id on MASTER_ADDR:(MASTER_PORT+1)."""
+    from . import _lib
+
+    host, port = _comm_endpoint()
+    if rank == 0:
+        uid = _lib.comm_unique_id()
         srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((host, port))
@@ -132,21 +235,6 @@ def _exchange_unique_id(rank, ws, timeout=300.0):
             srv.close()
         return uid
     deadline = time.monotonic() + timeout
-    if local:
-        path = _uid_file()
-        while True:
-            try:
-                if os.path.getmtime(path) >= _T_START - 120.0:  # (ranks of one job start within seconds of each other)
-                    with open(path, "rb") as f:
-                        buf = f.read()
-                    if len(buf) == _lib.COMM_ID_BYTES:
-                        return buf
-            except OSError:
-                pass
-            if time.monotonic() > deadline:
-                raise RuntimeError(f"rank {rank}: no ncclUniqueId file {path} from rank 0 within {timeout:.0f} s")
-            time.sleep(0.02)
-    host, port = _comm_endpoint()
     while True:
         try:
             with socket.create_connection((host, port), timeout=5.0) as s:
@@ -163,6 +251,18 @@ def _exchange_unique_id(rank, ws, timeout=300.0):
             time.sleep(0.05)
 
 
+def _exchange_unique_id(rank, ws, timeout=120.0):
+    from . import _lib
+
+    if ws == 1:
+        return _lib.comm_unique_id()
+    local = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1") \
+        and os.environ.get("BGP_COMM_TCP") != "1"
+    if local:
+        return _exchange_unique_id_files(rank, ws, timeout)
+    return _exchange_unique_id_tcp(rank, ws, timeout)
+
+
 def init_process_group(backend=None, device=None):
     """Join the process group when launched with WORLD_SIZE > 1 (or BGP_DIST_FORCE=1).  Returns
     (rank, local_rank, world_size)."""
@@ -173,43 +273,40 @@ def init_process_group(backend=None, device=None):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    ndev = _lib.device_count()
     name = backend or os.environ.get("BGP_DIST_BACKEND")
+    explicit = bool(name)
+    if name not in (None, "rccl", "gloo"):
+        raise ValueError(f"unknown backend {name!r}: the GPU exchange is 'rccl' (libbgp's own communicator); 'gloo' is "
+                         "the CPU group of the tests and of ranks that share a device")
+    ndev = _lib.device_count() if name != "gloo" else 0
     if not name:
-        # librccl loads (or not) identically on every rank of a node: a consistent choice without any exchange
-        name = ("rccl" if _lib.comm_available() else "nccl") if ndev > 0 else "gloo"
-    explicit = bool(backend or os.environ.get("BGP_DIST_BACKEND"))
+        # decided from what every rank of a node sees alike, without any exchange: a GPU per rank and a loadable
+        # librccl -> the native group; ranks sharing a device (RCCL refuses that) or no device at all -> gloo
+        local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+        name = "rccl" if (ndev >= max(local_ws, 1) and _lib.comm_available()) else "gloo"
+    dev = None
     if name == "rccl":
         if ndev < 1:
             raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")
         dev = (local_rank % ndev) if device is None else int(device)
         try:
-            uid = _exchange_unique_id(rank, ws)
+            uid = _exchange_unique_id(rank, ws)  # raises on EVERY rank when any rank failed (single node)
             _state["comm"] = _lib.Comm(dev, rank, ws, uid)
         except Exception as exc:
-            # ncclCommInitRank is collective: it fails on every rank or on none.  When the backend was not asked for
-            # by name, the job goes on with the launcher's own store and gloo (the only exchange is the final gather of
-            # the chains: host memory either way); an explicit BGP_DIST_BACKEND=rccl fails loudly.
             if explicit:
                 raise
-            import sys
-
             print(f"[bayes_skopt_amd.distributed] rank {rank}: native RCCL group failed ({exc}); using gloo",
                   file=sys.stderr, flush=True)
             name = "gloo"
-    if name != "rccl":
+    if name == "gloo":
         import datetime
-
-        import torch
 
         dist = _torch_dist()
         if not dist.is_initialized():
-            if name == "nccl":
-                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
             with _stdout_to_stderr():
-                dist.init_process_group(backend=name, rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=300))
+                dist.init_process_group(backend="gloo", rank=rank, world_size=ws, timeout=datetime.timedelta(seconds=300))
                 dist.barrier()  # (gloo connects its pairs lazily: make it talk now, while descriptor 1 is redirected)
-    _state.update(backend=name, rank=rank, world=ws)
+    _state.update(backend=name, rank=rank, world=ws, device=dev)
     return rank, local_rank, ws
 
 
@@ -220,15 +317,20 @@ def destroy_process_group():
         dist = _torch_dist()
         if dist.is_initialized():
             dist.destroy_process_group()
-    _state.update(backend=None, comm=None, rank=0, world=1)
+    _state.update(backend=None, comm=None, rank=0, world=1, device=None)
 
 
-def _torch_device():
-    import torch
-
-    if _state["backend"] == "nccl":
-        return torch.device("cuda", torch.cuda.current_device())
-    return torch.device("cpu")
+def group_info(device=None):
+    """What formed: backend, world size, the rank count RCCL itself reports (ncclCommCount; None over gloo) and the
+    device index of every rank (all-gathered)."""
+    info = {"backend": _state["backend"], "world": _state["world"], "rccl_nranks": None, "rank_devices": None}
+    if _state["backend"] is None:
+        return info
+    if _state["backend"] == "rccl":
+        info["rccl_nranks"] = _state["comm"].nranks()
+    dev = _state["device"] if device is None else device
+    info["rank_devices"] = [int(v) for v in _allgather(np.array([-1.0 if dev is None else float(dev)])).ravel()]
+    return info
 
 
 def _allgather(a):
@@ -239,10 +341,10 @@ def _allgather(a):
     import torch
 
     dist = _torch_dist()
-    t = torch.from_numpy(a.copy()).to(_torch_device())
+    t = torch.from_numpy(a.copy())
     out = [torch.empty_like(t) for _ in range(_state["world"])]
     dist.all_gather(out, t)
-    return torch.stack(out, dim=0).cpu().numpy()
+    return torch.stack(out, dim=0).numpy()
 
 
 def rank_seed(seed, rank):
@@ -274,7 +376,7 @@ def max_over_ranks(value):
     import torch
 
     dist = _torch_dist()
-    t = torch.tensor([float(value)], dtype=torch.float64, device=_torch_device())
+    t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -284,9 +386,32 @@ def shard_rows(B, rank, ws):
     return (B * rank) // ws, (B * (rank + 1)) // ws
 
 
+def _assemble(parts, B, ws):
+    full = np.empty(B)
+    for r in range(ws):
+        lo, hi = shard_rows(B, r, ws)
+        full[lo:hi] = parts[r][: hi - lo]
+    return full
+
+
+def allgather_lml(ctx, B, local=None):
+    """The B log-likelihoods of a sharded proposal block on every rank.  Native group: ``ctx`` holds this rank's
+    submitted rows (``Context.lml_submit``) and the values travel device to device (bgp_lml_batch_wait_allgather);
+    gloo (CPU tests, ranks sharing a GPU): ``local`` = this rank's values, already collected on the host."""
+    ws = _state["world"]
+    per = -(-B // ws)
+    if _state["backend"] == "rccl" and local is None:
+        return _assemble(ctx.lml_wait_allgather(_state["comm"], per), B, ws)
+    buf = np.zeros(per)
+    if local is not None and len(local):
+        buf[: len(local)] = local
+    return _assemble(_allgather(buf), B, ws)
+
+
 def shard_log_prob(fn):
     """Wrap a vectorised log-probability ``fn(Theta (B,p), **kw) -> (B,)`` so that each rank evaluates only
-    its own rows and the full vector is re-assembled with one all-gather (exact single-ensemble sharding).
+    its own rows and the full vector is re-assembled with one all-gather of host values (exact single-ensemble sharding
+    of ANY log-probability; BayesGPR's own device path uses the device-resident gather of ``allgather_lml``).
     Every rank must call it with the same Theta (same sampler RNG on every rank).  Outside a process
     group it is ``fn`` itself."""
 
@@ -297,15 +422,8 @@ def shard_log_prob(fn):
         ws, rank = _state["world"], _state["rank"]
         B = Theta.shape[0]
         lo, hi = shard_rows(B, rank, ws)
-        local = np.zeros(-(-B // ws))
-        if hi > lo:
-            local[: hi - lo] = fn(Theta[lo:hi], *args, **kwargs)
-        parts = _allgather(local)
-        full = np.empty(B)
-        for r in range(ws):
-            rlo, rhi = shard_rows(B, r, ws)
-            full[rlo:rhi] = parts[r][: rhi - rlo]
-        return full
+        local = fn(Theta[lo:hi], *args, **kwargs) if hi > lo else np.zeros(0)
+        return allgather_lml(None, B, local=np.asarray(local, dtype=np.float64))
 
     return wrapped
 
@@ -320,6 +438,6 @@ def broadcast_array(arr, src=0):
         return _state["comm"].broadcast(arr, root=src).reshape(arr.shape)
     import torch
 
-    t = torch.from_numpy(arr.copy()).to(_torch_device())
+    t = torch.from_numpy(arr.copy())
     _torch_dist().broadcast(t, src=src)
-    return t.cpu().numpy()
+    return t.numpy()

@@ -12,15 +12,21 @@ Inputs (X, y, walker positions) are resident / tiny; only (128, 18) doubles of p
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, each rank an independent 256-walker sub-ensemble on its own device
-(weak scaling, no collective in the sampling loop); the posterior samples are all-gathered over
-RCCL at the end (outside the timed region, reported as `gather_ms`) through libbgp's own communicator
-(bgp_comm_*, no PyTorch in the path; `dist_backend` in the JSON line names what ran).
-Prints ONE JSON line on rank 0.
+N > 1, one process per GPU either way: without a launcher's RANK / WORLD_SIZE in the environment `bench.py --gpus N`
+starts its N ranks itself (fresh child processes, before this process has imported the package or made any HIP
+call) and relays rank 0's line.  The headline is BASELINE config C AS STATED: ONE 256-walker ensemble (what
+bask/bayesgpr.py:490-530 runs) whose 128 proposals per half-step are split over the GPUs -- 16 per GPU at N = 8 --
+with the log-likelihoods all-gathered device to device over RCCL each half-step (bgp_lml_batch_wait_allgather through
+libbgp's own communicator, no PyTorch in the path): `"scaling": "strong"`, chain bit-identical to the one-GPU chain.
+The rate of N independent 256-walker sub-ensembles (no collective in the loop, final gather only; `--shard chains`
+makes it the headline) is timed behind it and reported as `weak_chains_evals_per_s`.  `rccl_nranks` (ncclCommCount),
+`rank_devices` and `dist_backend` say what group really formed.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
 import time
 
@@ -48,6 +54,32 @@ def trailing_flops_per_launch(n, nb=NB):
     return [nb * (n - j * nb) * (n - j * nb + 1) for j in range(1, n // nb)]
 
 
+def _PROFILER_ENV(k):
+    return k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTX_")) or k in ("LD_PRELOAD", "HSA_TOOLS_LIB")
+
+
+def being_profiled():
+    """True when this process runs under rocprofv3 / rocprof (their tool library is preloaded or configured)."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "")
+    return "rocprof" in pre or any(k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_")) for k in os.environ)
+
+
+def _kill_group(proc, grace=3.0):
+    """End a child started with start_new_session=True together with everything it started (exact process group)."""
+    try:
+        os.killpg(proc.pid, signal.SIGTERM)
+    except (ProcessLookupError, PermissionError):
+        return
+    try:
+        proc.wait(timeout=grace)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        proc.wait()
+
+
 def live_pmc_traffic(kernel_sub="syrk4_kernel", timeout_s=240):
     """HBM bytes per launch of the trailing-update kernel, collected NOW: two child runs of this script's hot path
     (`--steps 1 --warmup 1 --no-extras`, one stream) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
@@ -56,22 +88,32 @@ def live_pmc_traffic(kernel_sub="syrk4_kernel", timeout_s=240):
     import glob
     import shutil
     import sqlite3
-    import subprocess
     import tempfile
 
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if not exe:
+    if not exe or being_profiled():
+        # (under a profiler this process already carries its preloaded tool library: a nested `rocprofv3` -- a
+        # `#!/usr/bin/env python3` script -- would be an exec from a GPU-initialised process)
         return None
     per_launch = {}
-    env = dict(os.environ, BGP_STREAMS="1", TMPDIR="/tmp")
+    env = {k: v for k, v in os.environ.items() if not _PROFILER_ENV(k)}
+    env.update(BGP_STREAMS="1", TMPDIR="/tmp")
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="bgp_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--no-extras"]
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            # own session: on a timeout the whole group goes (rocprofv3 AND the bench it started), so nothing of this
+            # pass can linger on the GPU under the measurements that follow
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rcode = proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                _kill_group(proc)
+                return None
             dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
-            if res.returncode != 0 or not dbs:
+            if rcode != 0 or not dbs:
                 return None
             cur = sqlite3.connect(dbs[0]).cursor()
             rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
@@ -178,12 +220,16 @@ def cpu_baseline_sklearn(X, y, thetas, budget_s=6.0):
             "kind": "sklearn 1.7 GaussianProcessRegressor.log_marginal_likelihood", "runs": runs}, vals[1:]
 
 
-def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget_walkers=36, budget_steps=2):
+def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget_walkers=36, budget_steps=1):
     """TIMED host run of the reference's sampling loop at this size: the package's host ensemble sampler (emcee's
     stretch move, one proposal block per half-step) driving scikit-learn's log_marginal_likelihood one walker at a
-    time -- what BayesGPR.sample does on the CPU (bask/bayesgpr.py:510-530, :351-379).  Bounded: `budget_walkers`
-    walkers (the smallest ensemble emcee accepts, 2p) x `budget_steps` steps; the full-size figure is that time per
-    evaluation x the evaluations of the full run, stated as an extrapolation."""
+    time -- what BayesGPR.sample does on the CPU (bask/bayesgpr.py:510-530, :351-379: a sequential per-walker map,
+    whatever the host's core count).  Bounded: `budget_walkers` walkers (the smallest ensemble emcee accepts, 2p) x
+    `budget_steps` steps, run at ONE BLAS thread and at all of them; the better setting is the baseline (as in
+    cpu_baseline) and the full-size figure is its time per evaluation x the evaluations of the full run, stated as an
+    extrapolation."""
+    from threadpoolctl import threadpool_limits
+
     from bayes_skopt_amd.sampler import EnsembleSampler
 
     gpr = _sklearn_gpr(X, y)
@@ -199,25 +245,32 @@ def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget
 
     p = len(theta0)
     W = max(budget_walkers, 2 * p)
-    rng = np.random.RandomState(0)
-    pos = theta0 + 1e-2 * rng.randn(W, p)
-    smp = EnsembleSampler(W, p, log_prob, kwargs=dict(priors=priors))
-    smp.random_state = np.random.RandomState(1).get_state()
-    t0 = time.perf_counter()
-    smp.run_mcmc(pos, budget_steps)
-    dt = time.perf_counter() - t0
     evals_full = n_walkers_full * (steps_full + 1)
+    runs = {}
+    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+        rng = np.random.RandomState(0)
+        pos = theta0 + 1e-2 * rng.randn(W, p)
+        smp = EnsembleSampler(W, p, log_prob, kwargs=dict(priors=priors))
+        smp.random_state = np.random.RandomState(1).get_state()
+        n_eval[0] = 0
+        with threadpool_limits(limits=nthreads):
+            t0 = time.perf_counter()
+            smp.run_mcmc(pos, budget_steps)
+            dt = time.perf_counter() - t0
+        runs[label] = {"threads": int(nthreads), "timed_ms": dt * 1e3, "timed_evals": int(n_eval[0]),
+                       "ms_per_eval": dt * 1e3 / max(n_eval[0], 1)}
+    best = min(runs, key=lambda k: runs[k]["ms_per_eval"])
     return {
-        "timed_ms": dt * 1e3,
-        "timed_evals": int(n_eval[0]),
-        "timed_config": f"{W} walkers x {budget_steps} steps (+ initial ensemble), sklearn log_marginal_likelihood per "
-        f"walker, {_blas_threads()} BLAS threads",
-        "ms_per_eval": dt * 1e3 / max(n_eval[0], 1),
-        "extrapolated_full_ms": dt * 1e3 / max(n_eval[0], 1) * evals_full,
+        "runs": runs,
+        "best": best,
+        "timed_config": f"{W} walkers x {budget_steps} step(s) (+ initial ensemble), sklearn log_marginal_likelihood per "
+        f"walker, sequential over the walkers as the reference runs them, on a {os.cpu_count()}-core host",
+        "ms_per_eval": runs[best]["ms_per_eval"],
+        "extrapolated_full_ms": runs[best]["ms_per_eval"] * evals_full,
         "extrapolated_full_evals": int(evals_full),
-        "extrapolation": f"timed ms per evaluation x {evals_full} evaluations = {n_walkers_full} walkers x "
-        f"({steps_full} steps + initial ensemble); the MAP start of fit() (a few dozen more evaluations with gradients) "
-        "is not included",
+        "extrapolation": f"timed ms per evaluation (better of 1 / all BLAS threads) x {evals_full} evaluations = "
+        f"{n_walkers_full} walkers x ({steps_full} steps + initial ensemble); the MAP start of fit() (a few dozen more "
+        "evaluations with gradients) is not included",
     }
 
 
@@ -257,45 +310,159 @@ def config_d_roofline(bask_lib, device, peak_tflops):
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="only the config C hot path (no fit(), no config D, no CPU baselines): what the rocprofv3 "
-                    "passes of tools/profile_round.sh run, so that their per-kernel numbers are config C's alone")
-    ap.add_argument("--no-live-pmc", action="store_true",
-                    help="do not collect roofline.traffic with two rocprofv3 --pmc child passes (~25 s); use the "
-                    "committed profiles/r02_pmc_traffic.json instead")
-    ap.add_argument("--shard", choices=("chains", "ensemble"), default="chains",
-                    help="chains (default): independent 256-walker sub-ensemble per GPU, weak scaling, no collective in "
-                    "the loop; ensemble: ONE 256-walker ensemble, each half-step's 128 proposals split over the GPUs + "
-                    "an all-gather of 128 doubles (exact reference semantics, strong scaling; SURVEY 8e option 1)")
-    args = ap.parse_args()
+def small_batch_shards(bask_lib, X, y, pos_H, device, sizes=(128, 64, 32, 16), reps=12):
+    """Wall time of ONE half-step's device call at n = 2048 for the per-GPU share of the 128 proposals when ONE
+    256-walker ensemble is split over 1 / 2 / 4 / 8 GPUs (128 / 64 / 32 / 16 matrices): what strong scaling of BASELINE
+    config C is bounded by, measured on this one GPU."""
+    ctx = bask_lib.Context(X, y, 1e-10, max_batch=max(sizes), device=device)
+    out = {}
+    for m in sizes:
+        H = pos_H[:m]
+        for _ in range(3):
+            ctx.lml(H)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctx.lml(H)
+            ts.append(time.perf_counter() - t0)
+        out[str(m)] = float(np.median(ts) * 1e3)
+    ctx.close()
+    return out
 
-    import bayes_skopt_amd as bask
-    from bayes_skopt_amd import _lib, distributed
+
+def config_b(bask, device, steps=150):
+    """BASELINE config B (n = 1024, d = 8, Matern-5/2, 64 walkers; the configuration runs 500 steps, this leg times
+    `steps` of them after the start ensemble): MCMC LML-evaluations/s, ms per half-step (32 proposals) and the
+    per-kernel split of one half-step (HIP events, one stream)."""
+    n, d, W = 1024, 8, 64
+    X, y = synth(n, d, seed=0)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device,
+                       max_batch=W // 2)
+    from bayes_skopt_amd.bayesgpr import _AsyncLogProb
     from bayes_skopt_amd.kernels import WhiteKernel
 
-    ndev = _lib.device_count()
-    if ndev < 1:
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    rank, local_rank, ws = distributed.init_process_group()
-    if ws != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ws}: launch one rank per GPU with\n  python -m "
-                         f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                         f"--master-port 29500 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
-    device = local_rank % ndev
+    gp.kernel_ = gp.kernel + WhiteKernel(noise_level=0.01)
+    gp.noise_ = 0.01
+    gp.X_train_, gp.y_train_ = X, y
+    gp.y_train_mean_, gp.y_train_std_ = np.zeros(1), 1
+    gp._ensure_context(batch_hint=W // 2)
+    priors = bask.guess_priors(gp.kernel_)
+    theta0 = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+    pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)
+    smp = bask.sampler.EnsembleSampler(W, d + 2, _AsyncLogProb(gp), kwargs=dict(priors=priors))
+    smp.random_state = np.random.RandomState(1).get_state()
+    st = smp.run_mcmc(pos, 5)
+    t0 = time.perf_counter()
+    st = smp.run_mcmc(st.coords, steps, log_prob0=st.log_prob, skip_initial_state_check=True)
+    dt = time.perf_counter() - t0
+    H = gp._canonical(st.coords[: W // 2])
+    gp._ctx.set_streams(1)
+    gp._ctx.set_timing(True)
+    split = {k: 0.0 for k in ("kbuild", "potrf", "trsm", "syrk")}
+    dev = 0.0
+    for _ in range(5):
+        gp._ctx.lml(H)
+        tm = gp._ctx.last_timing()
+        for k in split:
+            split[k] += tm[k]["ms"] / 5
+        dev += tm["device_total_ms"] / 5
+    gp._ctx.set_timing(False)
+    gp._ctx.close()
+    return {"workload": f"n={n}, d={d}, {W} walkers, {steps} timed MCMC steps (32 proposals per half-step)",
+            "evals_per_s": W * steps / dt, "ms_per_half_step": dt / (2 * steps) * 1e3,
+            "kernel_ms_per_half_step": split, "device_ms_per_half_step_instrumented": dev,
+            "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
 
-    n, d, W = N_POINTS, N_DIMS, N_WALKERS
+
+def config_e(bask, device, n_iters=50, n0=974, m=10000, d=8):
+    """BASELINE config E: the Optimizer.tell loop, 50 iterations, PVRS over a 10 000-candidate grid with 128
+    hyper-posterior samples, n growing 975 -> 1024 (bask/optimizer.py:228-380, bask/acquisition.py:316-339); and the
+    same 50 tells with EI averaged over 128 hyper-posterior samples x 10 000-point predicts.  Wall time per tell
+    (the first tell of each loop also runs the MAP fit and is reported apart)."""
+    out = {"n_iters": n_iters, "candidates": m, "d": d}
+    for tag, acq, kw in (("pvrs", "pvrs", dict(gp_samples=128, gp_burnin=10, n_samples=0)),
+                         ("ei128", "ei", dict(gp_samples=200, gp_burnin=10, n_samples=128))):
+        rng = np.random.RandomState(0)
+
+        def f(x):
+            return float(np.sin(3 * np.sum(x)) + 0.1 * rng.randn())
+
+        opt = bask.Optimizer(dimensions=[(0.0, 1.0)] * d, n_points=m, n_initial_points=10, init_strategy="r2",
+                             acq_func=acq, random_state=0, gp_kwargs=dict(device=device))
+        X0 = rng.uniform(size=(n0, d)).tolist()
+        opt.tell(X0, [f(x) for x in X0], fit=False)
+        times = []
+        for _ in range(n_iters):
+            x = opt.ask() if opt._next_x is not None else rng.uniform(size=d).tolist()
+            t0 = time.perf_counter()
+            opt.tell(x, f(x), **kw)
+            times.append((time.perf_counter() - t0) * 1e3)
+        rest = np.array(times[1:])
+        out[tag] = {"first_tell_ms_incl_fit": times[0], "median_ms_per_tell": float(np.median(rest)),
+                    "p90_ms_per_tell": float(np.percentile(rest, 90)), "total_s": float(np.sum(times) / 1e3),
+                    "n_final": len(opt.Xi), "tell_kwargs": kw}
+        del opt
+    return out
+
+
+def self_spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this parent has not
+    imported the package, loaded libbgp or made any HIP call -- nothing is ever re-executed from a process that
+    touched the GPU), relay rank 0's single JSON line, exit with the worst child return code."""
+    import socket
+    import tempfile
+
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                BGP_COMM_JOB="bench_%d_%d" % (os.getpid(), time.time_ns()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out0 = tempfile.TemporaryFile(mode="w+")
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else sys.stderr, start_new_session=True))
+    deadline = time.monotonic() + float(os.environ.get("BGP_BENCH_TIMEOUT", "3000"))
+    worst = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            failed = [p for p in procs if p.poll() not in (None, 0)]
+            if failed or time.monotonic() > deadline:
+                time.sleep(5.0 if failed else 0.0)  # (let the others report their own error first)
+                for p in procs:
+                    if p.poll() is None:
+                        _kill_group(p)
+                worst = worst or (failed[0].returncode if failed else 124)
+                break
+            time.sleep(0.05)
+    except BaseException:
+        for p in procs:
+            if p.poll() is None:
+                _kill_group(p)
+        raise
+    for p in procs:
+        rc = p.wait()
+        worst = worst or rc
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
+    if lines:
+        print(lines[-1], flush=True)
+    elif worst == 0:
+        worst = 1
+    sys.exit(worst if 0 <= worst < 256 else 1)
+
+
+def setup_config_c(bask, device, seed_gp, W=N_WALKERS):
+    """BayesGPR in the state right after the MAP fit of BayesGPR.fit (bask/bayesgpr.py:602-607) at config C, the
+    default priors and the reference's start ball (:506-509)."""
+    from bayes_skopt_amd.kernels import WhiteKernel
+
+    n, d = N_POINTS, N_DIMS
     X, y = synth(n, d, seed=0)
-    ensemble = args.shard == "ensemble" and ws > 1
-    seed_rank = 0 if ensemble else rank  # one shared ensemble needs the same RNG streams on every rank
-    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))),
-                       random_state=distributed.rank_seed(0, seed_rank), device=device, max_batch=W // 2)
-    # state right after the MAP fit of BayesGPR.fit (bask/bayesgpr.py:602-607) without running it:
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=seed_gp, device=device,
+                       max_batch=W // 2)
     gp.kernel_ = gp.kernel + WhiteKernel(noise_level=0.01)
     gp.noise_ = 0.01
     gp.X_train_ = X
@@ -304,37 +471,114 @@ def main():
     gp._ensure_context(batch_hint=W // 2)
     priors = bask.guess_priors(gp.kernel_)
     theta0 = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
-    pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)  # the reference's start ball (:506-509)
+    pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)
+    return gp, X, y, priors, theta0, pos
 
-    log_prob = distributed.shard_log_prob(gp._log_prob_batch) if ensemble else gp._log_prob_batch
-    sampler = bask.sampler.EnsembleSampler(W, d + 2, log_prob, kwargs=dict(priors=priors))
-    sampler.random_state = np.random.RandomState(distributed.rank_seed(1, seed_rank)).get_state()
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the config C hot path (no fit(), no configs B / D / E, no CPU baselines): what the "
+                    "rocprofv3 passes of tools/profile_round.sh run, so that their per-kernel numbers are config C's alone")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect roofline.traffic with two rocprofv3 --pmc child passes (~25 s); use the "
+                    "committed profiles/r03_pmc_traffic.json instead")
+    ap.add_argument("--shard", choices=("ensemble", "chains"), default="ensemble",
+                    help="N > 1 only.  ensemble (default; BASELINE config C as stated, the reference's semantics): ONE "
+                    "256-walker ensemble, each half-step's 128 proposals split over the GPUs + a device-to-device "
+                    "all-gather of 128 doubles, strong scaling (SURVEY 8e option 1); chains: an independent 256-walker "
+                    "sub-ensemble per GPU, weak scaling, no collective in the loop")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="form the process group, report it (backend, ranks RCCL counts, device of every rank) and exit "
+                    "without device work: the launch path alone (the CPU tests run it over gloo)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
+        return self_spawn(args, sys.argv[1:])  # (before the package, libbgp or HIP are touched in this process)
+
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd import _lib, distributed
+    from bayes_skopt_amd.bayesgpr import _AsyncLogProb, _ShardedLogProb
+
+    ndev = _lib.device_count()
+    if ndev < 1 and not args.rendezvous_only:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    rank, local_rank, ws = distributed.world()
+    if ws != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher's WORLD_SIZE is {ws}: they must agree (or start "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher: it spawns its own ranks)")
+    device = local_rank % ndev if ndev > 0 else None
+    distributed.init_process_group(device=device)
+    info = distributed.group_info(device)
+    if args.rendezvous_only:
+        seen = distributed.gather_chains(np.full((1, 1), float(rank)))[:, 0].tolist()
+        tmax = distributed.max_over_ranks(float(rank))
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": ws, "dist_backend": info["backend"],
+                              "rccl_nranks": info["rccl_nranks"], "rank_devices": info["rank_devices"],
+                              "ranks_seen": seen, "max_rank": tmax}), flush=True)
+        if ws > 1:
+            distributed.barrier()
+            distributed.destroy_process_group()
+        return
+
+    n, d, W = N_POINTS, N_DIMS, N_WALKERS
+    ensemble = args.shard == "ensemble" and ws > 1
+    seed_rank = 0 if (ensemble or ws == 1) else rank  # one shared ensemble needs the same RNG streams on every rank
+    gp, X, y, priors, theta0, pos = setup_config_c(bask, device, distributed.rank_seed(0, seed_rank))
+
+    def make_sampler(shared):
+        lp = _ShardedLogProb(gp) if shared else _AsyncLogProb(gp)
+        s = bask.sampler.EnsembleSampler(W, d + 2, lp, kwargs=dict(priors=priors))
+        s.random_state = np.random.RandomState(distributed.rank_seed(1, 0 if shared else seed_rank)).get_state()
+        return s
 
     def sync():
         _lib.device_synchronize(device)
 
+    def timed(sampler, pos, lp, steps):
+        distributed.barrier()
+        sync()
+        t0 = time.perf_counter()
+        state = sampler.run_mcmc(pos, steps, log_prob0=lp, skip_initial_state_check=True)
+        sync()
+        distributed.barrier()
+        return distributed.max_over_ranks(time.perf_counter() - t0), state
+
+    sampler = make_sampler(ensemble)
     state = sampler.run_mcmc(pos, max(args.warmup, 1))  # also evaluates the initial ensemble
+    dt, state = timed(sampler, state.coords, state.log_prob, args.steps)
     pos, lp = state.coords, state.log_prob
 
-    distributed.barrier()
-    sync()
-    t0 = time.perf_counter()
-    state = sampler.run_mcmc(pos, args.steps, log_prob0=lp, skip_initial_state_check=True)
-    sync()
-    distributed.barrier()
-    dt = distributed.max_over_ranks(time.perf_counter() - t0)
-    pos, lp = state.coords, state.log_prob
-
-    # final posterior-sample gather (RCCL over xGMI when N > 1)
+    # final posterior-sample gather (RCCL over xGMI when N > 1; the shared ensemble's chain is on every rank already)
     tg = time.perf_counter()
     chain_local = sampler.get_chain(flat=True, discard=max(args.warmup, 1))
     chain_all = chain_local if ensemble else distributed.gather_chains(chain_local)
     gather_ms = (time.perf_counter() - tg) * 1e3
 
-    # instrumented pass: HIP events around every launch, same work.  The timed pass above runs the two
-    # walker-group streams of the product default (the groups' launches overlap, so per-launch durations
-    # there are not those of a kernel running alone); for the per-kernel numbers and the roofline every
-    # launch goes to ONE stream, like the rocprofv3 runs under profiles/ (BGP_STREAMS=1).
+    # N > 1: the other sharding, timed the same way behind the headline (extra key, never `value`)
+    other = None
+    if ws > 1:
+        if ensemble:  # independent sub-ensembles: own seeds, own start ball, no collective in the loop
+            s_o = bask.sampler.EnsembleSampler(W, d + 2, _AsyncLogProb(gp), kwargs=dict(priors=priors))
+            s_o.random_state = np.random.RandomState(distributed.rank_seed(1, rank)).get_state()
+            pos_o = theta0 + 1e-2 * np.random.RandomState(distributed.rank_seed(0, rank)).randn(W, d + 2)
+        else:  # (headline = chains): ONE shared ensemble on rank 0's streams
+            s_o = make_sampler(True)
+            pos_o = distributed.broadcast_array(pos)
+        st_o = s_o.run_mcmc(pos_o, 1)
+        dt_o, _ = timed(s_o, st_o.coords, st_o.log_prob, args.steps)
+        other = W * args.steps * (ws if ensemble else 1) / dt_o
+
+    # instrumented pass: HIP events around every launch, same work.  The timed pass above runs the product default
+    # (two walker-group streams at >= 64 matrices: the groups' launches overlap, so per-launch durations there are not
+    # those of a kernel running alone); for the per-kernel numbers and the roofline every launch goes to ONE stream,
+    # like the rocprofv3 runs under profiles/ (BGP_STREAMS=1).
     gp._ctx.set_streams(1)
     gp._ctx.set_timing(True)
     acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk")}
@@ -386,11 +630,13 @@ def main():
                               "(%d launches; FETCH_SIZE %.0f KiB raw x 2 + WRITE_SIZE %.0f KiB)"
                               % (live["launches_averaged"], live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
     if traffic is None:
-        try:  # the committed PMC passes of tools/profile_round.sh
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))["traffic_bytes_per_launch"]
-            traffic_source = "profiles/r02_pmc_traffic.json (committed passes of tools/profile_round.sh)"
-        except Exception:
-            pass
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the committed PMC passes of tools/profile_round.sh
+            try:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["traffic_bytes_per_launch"]
+                traffic_source = f"profiles/{name} (committed passes of tools/profile_round.sh)"
+                break
+            except Exception:
+                pass
     peak = min(FP64_MFMA_PEAK_TFLOPS, mfma_measured) if mfma_measured else FP64_MFMA_PEAK_TFLOPS
     roofline = {
         "bound": "mfma",
@@ -408,13 +654,13 @@ def main():
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
         "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
-        "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x 128 matrices per launch (SURVEY 8d); "
-        "peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
+        "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x the matrices of a launch (SURVEY "
+        "8d); peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
         "MI355X_MICROARCH.md has no fp64 row; traffic = HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
         "+ WRITE_SIZE, separate passes; see traffic_source)",
     }
 
-    evals = W * args.steps * (1 if ensemble else ws)
+    evals = W * args.steps * (1 if (ensemble or ws == 1) else ws)
     value = evals / dt
     line = {
         "metric": "mcmc_lml_evals_per_s_n2048",
@@ -431,12 +677,14 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "BASELINE config C: BayesGPR hyper-posterior MCMC, n=2048, d=16, c*Matern52(ARD)+White, "
-            + ("ONE 256-walker ensemble, the 128 proposals of each half-step split over the GPUs, " if ensemble else
+            + ("ONE 256-walker ensemble, the 128 proposals of each half-step split over the GPUs and their "
+               "log-likelihoods all-gathered device to device over RCCL, " if ensemble else
                "256 walkers per GPU (128 batched kernel-build+Cholesky+LML per half-step), ")
             + "start ball of bask/bayesgpr.py:506-509, default priors",
             "n": n,
             "d": d,
-            "walkers_per_gpu": W / ws if ensemble else W,
+            "walkers_total": W if (ensemble or ws == 1) else W * ws,
+            "proposals_per_gpu_per_half_step": B,
             "parallelism": f"ensemble_sharded{ws}" if ensemble else f"chains{ws}",
         },
         "roofline": roofline,
@@ -444,13 +692,33 @@ def main():
         "device_ms_per_half_step": dev_total / max(n_calls, 1),
         "instrumented_ms_per_step": dt_instr / args.steps * 1e3,
         "gather_ms": gather_ms,
-        "dist_backend": distributed.backend(),
+        "dist_backend": info["backend"],
+        "rccl_nranks": info["rccl_nranks"],
+        "rank_devices": info["rank_devices"],
         "gathered_chain_rows": int(chain_all.shape[0]),
         "acceptance_fraction": float(np.mean(sampler.acceptance_fraction)),
     }
+    if other is not None:
+        line["weak_chains_evals_per_s" if ensemble else "strong_ensemble_evals_per_s"] = other
+        line["other_sharding_note"] = ("N independent 256-walker sub-ensembles, no collective in the loop (weak scaling; reads "
+                                       "~N x by construction)" if ensemble else
+                                       "ONE 256-walker ensemble split over the GPUs (strong scaling, BASELINE config C as stated)")
     if args.no_extras:
         args.no_cpu_baseline = True
     if rank == 0 and ws == 1 and not args.no_extras:
+        # strong-scaling ceiling of config C, measured on this one GPU: one half-step's device call for the per-GPU
+        # share of the 128 proposals at N = 1 / 2 / 4 / 8
+        try:
+            sh = small_batch_shards(_lib, X, y, gp._canonical(pos[: W // 2]), device)
+            line["shard_ms"] = sh
+            line["shard_projection"] = {
+                "what": "PROJECTION, not a multi-GPU measurement: 256 evaluations per step / (2 x shard_ms[128 / N]) -- "
+                "the rate ONE 256-walker ensemble split over N GPUs would reach if the per-half-step all-gather and the "
+                "host bookkeeping were free",
+                "evals_per_s": {str(N): 256.0 / (2.0 * sh[str(128 // N)] * 1e-3) for N in (1, 2, 4, 8)},
+            }
+        except Exception as exc:
+            line["shard_ms"] = {"error": repr(exc)}
         # the other half of BASELINE.json's metric: wall clock of a whole BayesGPR.fit() (MAP start by L-BFGS-B on
         # the device LML + gradient, then 256 walkers x 25 steps after 5 burn-in steps) at the same size
         gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device)
@@ -461,19 +729,23 @@ def main():
         line["fit_plus_sample_config"] = f"BayesGPR.fit: MAP start (L-BFGS-B on the device LML + gradient) + {W} walkers x 30 steps"
         del gp2
         line["roofline_n4096"] = config_d_roofline(_lib, device, peak)
+        for key, fn in (("config_B", config_b), ("config_E", config_e)):
+            try:
+                line[key] = fn(bask, device)
+            except Exception as exc:  # reported, never fatal for the bench line
+                line[key] = {"error": repr(exc)}
     if rank == 0:
         if not args.no_cpu_baseline and ws == 1:  # (the CPU legs run at N = 1 only: the N > 1 runs time the GPUs)
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
-            line["speedup_vs_cpu_baseline"] = value / (1 if ensemble else ws) / line["cpu_baseline"]["value"]
-            if ws == 1:
-                try:  # the CPU side of BASELINE.json's fit+sample metric, timed (bounded) instead of estimated
-                    cf = cpu_fit_plus_sample(X, y, priors, theta0, W, 30)
-                    line["cpu_fit_plus_sample_ms"] = cf["extrapolated_full_ms"]
-                    line["cpu_fit_plus_sample"] = cf
-                    if "fit_plus_sample_ms" in line:
-                        line["fit_plus_sample_speedup_vs_cpu"] = cf["extrapolated_full_ms"] / line["fit_plus_sample_ms"]
-                except Exception as exc:
-                    line["cpu_fit_plus_sample"] = {"error": repr(exc)}
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            try:  # the CPU side of BASELINE.json's fit+sample metric, timed (bounded) instead of estimated
+                cf = cpu_fit_plus_sample(X, y, priors, theta0, W, 30)
+                line["cpu_fit_plus_sample_ms"] = cf["extrapolated_full_ms"]
+                line["cpu_fit_plus_sample"] = cf
+                if "fit_plus_sample_ms" in line:
+                    line["fit_plus_sample_speedup_vs_cpu"] = cf["extrapolated_full_ms"] / line["fit_plus_sample_ms"]
+            except Exception as exc:
+                line["cpu_fit_plus_sample"] = {"error": repr(exc)}
             try:  # the reference's own per-walker call, and a live parity check of the device path against it
                 sk, sk_vals = cpu_baseline_sklearn(X, y, pos[:32])
                 dev_vals = gp._ctx.lml(gp._canonical(pos[: len(sk_vals)]))
@@ -481,7 +753,7 @@ def main():
                 line["cpu_baseline_sklearn"] = sk
             except Exception as exc:  # reported, never fatal for the bench line
                 line["cpu_baseline_sklearn"] = {"error": repr(exc)}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if ws > 1:
         distributed.barrier()
         distributed.destroy_process_group()

@@ -105,13 +105,16 @@ int bgp_beta_cdf(bgp_ctx* ctx, int m, const double* X, const double* warp, doubl
 
 /*
  * Asynchronous bgp_lml_batch (B <= max_batch): submit enqueues the whole batch on the device and returns, wait blocks
- * until it is done and hands back lml / status (status may be NULL).  Between the two calls the host is free -- the
+ * until it is done and hands back lml / status (status may be NULL); with per-launch timing on (bgp_set_timing) submit
+ * returns BGP_ERR_STATE (the timed path synchronises inside bgp_lml_batch).  Between the two calls the host is free -- the
  * sampler evaluates the log-priors of the same proposals there (bask/bayesgpr.py:366-372 runs them back to back).
  * One batch may be pending per context, and it owns the workspace: until wait has collected it every other entry point
  * that computes on the context returns BGP_ERR_STATE.  Proposals and results travel through pinned host memory; same
  * results as bgp_lml_batch (which takes this path itself for a single chunk).
  */
 int bgp_lml_batch_submit(bgp_ctx* ctx, int B, const double* h);
+/* the same for per-walker warps (the asynchronous form of bgp_lml_batch_warped; bask/bayesgpr.py:353-374) */
+int bgp_lml_batch_warped_submit(bgp_ctx* ctx, int B, const double* h, const double* warp);
 int bgp_lml_batch_wait(bgp_ctx* ctx, double* lml, int* status);
 
 /*
@@ -240,7 +243,8 @@ int bgp_mfma_f64_layout(int device, int* rows, int* cols);
  * the sampling loop, ONE all-gather of the posterior samples at the end (bgp_comm_allgather; in the exact
  * single-ensemble option also the B log-probabilities of each half-step).  Host buffers in, host buffers out; the
  * staging buffers stay resident on the device.  bgp_comm_unique_id is called on rank 0 and its BGP_COMM_ID_BYTES bytes
- * are handed to every rank by the caller (bayes-skopt_amd/distributed.py: a TCP socket on MASTER_ADDR:MASTER_PORT).
+ * are handed to every rank by the caller (bayes-skopt_amd/distributed.py: a per-job file in a per-user directory on a
+ * single node, a TCP socket on MASTER_ADDR:(MASTER_PORT + 1) across nodes).
  * Replaces: nothing in the reference (it is single-process); mirrors what torch.distributed's all_gather /
  * all_reduce(MAX) / broadcast would do, without PyTorch in the product path.
  */
@@ -255,6 +259,13 @@ int bgp_comm_allgather(bgp_comm* comm, const double* send, size_t count, double*
 int bgp_comm_allreduce_max(bgp_comm* comm, double* inout, size_t count);
 int bgp_comm_broadcast(bgp_comm* comm, double* buf, size_t count, int root);
 int bgp_comm_barrier(bgp_comm* comm);
+/* ranks RCCL counts in the communicator (ncclCommCount) */
+int bgp_comm_nranks(bgp_comm* comm, int* nranks);
+/* Exact single-ensemble sharding of bask/bayesgpr.py:490-530 (ONE n_walkers ensemble, one RNG): every rank has
+ * submitted its own rows of a half-step's proposal block with bgp_lml_batch_submit; this replaces bgp_lml_batch_wait
+ * and returns the log-likelihoods of ALL ranks (world * per_rank doubles, rank-major, gathered device to device out of
+ * every context's resident result vector -- no host staging on the send side). */
+int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, double* lml_all);
 
 #ifdef __cplusplus
 }

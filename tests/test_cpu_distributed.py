@@ -1,5 +1,6 @@
 """N>1 path on CPU: world_size-2 gloo job (torch.distributed.run), independent sub-ensembles per rank,
-final all-gather of the chains, max-over-ranks timing."""
+final all-gather of the chains, max-over-ranks timing; exact single-ensemble sharding; the ncclUniqueId rendezvous
+(job-unique files, every rank's verdict before anyone enters the collective); bench.py starting its own ranks."""
 import json
 import os
 import socket
@@ -131,7 +132,7 @@ def test_group_falls_back_to_gloo_when_the_native_group_cannot_form(tmp_path):
     code = (
         "import os, sys, json; sys.path.insert(0, %r); import numpy as np; import bayes_skopt_amd;"
         "from bayes_skopt_amd import _lib, distributed;"
-        "_lib.device_count = lambda: 1; _lib.comm_available = lambda: True;\n"
+        "_lib.device_count = lambda: 2; _lib.comm_available = lambda: True;\n"
         "def boom(*a, **k): raise RuntimeError('ncclCommInitRank failed: invalid usage')\n"
         "distributed._exchange_unique_id = boom\n"
         "r, lr, ws = distributed.init_process_group()\n"
@@ -154,3 +155,83 @@ def test_group_falls_back_to_gloo_when_the_native_group_cannot_form(tmp_path):
     res = subprocess.run(cmd[:-1] + [str(script)], env=dict(base, BGP_DIST_BACKEND="rccl"), capture_output=True, text=True,
                          timeout=600)
     assert res.returncode != 0 and "invalid usage" in res.stderr
+
+
+def test_rendezvous_failure_on_one_rank_is_every_ranks_verdict(tmp_path):
+    """A rank that cannot get the id (here: rank 1 expects another id size, so rank 0's file never satisfies it and it
+    times out) reports "fail"; rank 0 -- which has its id -- must NOT walk into ncclCommInitRank alone: both raise,
+    promptly, from the same status files.  The files are private (0600 in a 0700 directory of this user)."""
+    code = (
+        "import os, sys, json, time; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib, distributed;"
+        "_lib.comm_unique_id = lambda: bytes(range(128));"
+        "r = int(os.environ['RANK']);\n"
+        "if r == 1: _lib.COMM_ID_BYTES = 64\n"
+        "t0 = time.time()\n"
+        "try:\n"
+        "    distributed._exchange_unique_id(r, 2, timeout=3.0); out = 'entered'\n"
+        "except RuntimeError as exc:\n"
+        "    out = 'refused: ' + str(exc)\n"
+        "modes = sorted(oct(os.stat(os.path.join(d, f)).st_mode & 0o777) for d, _s, fs in os.walk(%r) for f in fs if f.startswith('job_'))\n"
+        "json.dump({'out': out, 'dt': time.time() - t0, 'modes': modes}, open(os.path.join(%r, 'v%%d.json' %% r), 'w'))\n"
+    ) % (ROOT, str(tmp_path), str(tmp_path))
+    script = tmp_path / "w.py"
+    script.write_text(code)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r),
+                                       WORLD_SIZE="2", BGP_COMM_DIR=str(tmp_path / "rdv"))) for r in (0, 1)]
+    for p in procs:
+        assert p.wait(timeout=120) == 0
+    v = [json.load(open(tmp_path / f"v{r}.json")) for r in range(2)]
+    assert v[0]["out"].startswith("refused") and "rank 1" in v[0]["out"], v
+    assert v[1]["out"].startswith("refused"), v
+    assert v[0]["dt"] < 30 and v[1]["dt"] < 30
+    assert set(v[0]["modes"] + v[1]["modes"]) <= {"0o600"}
+    assert oct(os.stat(tmp_path / "rdv").st_mode & 0o777) == "0o700"
+
+
+def test_job_names_differ_between_launches(tmp_path):
+    """The id file is named after the launching process and ITS start time: a crashed job's leftover (same port, same
+    world size) cannot be picked up by the next launch."""
+    code = ("import os, sys; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import distributed;"
+            "print(distributed._job_prefix(2))") % ROOT
+    env = dict(os.environ, MASTER_PORT="29500", BGP_COMM_DIR=str(tmp_path))
+    env.pop("BGP_COMM_JOB", None)
+    # two launches = two different parents (each `sh -c` is the common parent of its ranks)
+    a = subprocess.run(["sh", "-c", f"{sys.executable} -c {code!r}; {sys.executable} -c {code!r}"], env=env,
+                       capture_output=True, text=True, timeout=120).stdout.split()
+    b = subprocess.run(["sh", "-c", f"{sys.executable} -c {code!r}; true"], env=env, capture_output=True, text=True,
+                       timeout=120).stdout.split()
+    assert len(a) == 2 and a[0] == a[1]      # ranks of one launch agree
+    assert len(b) == 1 and b[0] != a[0]      # another launch: another name
+    same = subprocess.run([sys.executable, "-c", code], env=dict(env, BGP_COMM_JOB="named"), capture_output=True,
+                          text=True, timeout=120).stdout.split()
+    assert "named" in same[0]
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` with no launcher environment: the parent spawns N fresh rank processes (before it has
+    imported the package or touched HIP), they form a group (gloo here: no GPU), rank 0's ONE line is relayed and the
+    return code is the children's.  --rendezvous-only stops before the device work (which needs the MI355X)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--rendezvous-only"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["dist_backend"] == "gloo" and d["ranks_seen"] == [float(r) for r in range(n)]
+    assert d["max_rank"] == n - 1 and d["rccl_nranks"] is None and len(d["rank_devices"]) == n
+
+
+def test_bench_self_spawn_reports_a_failing_rank():
+    """A rank that dies takes the job down with its return code instead of leaving the others waiting."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    # without --rendezvous-only the ranks need a GPU: on this CPU box every rank exits with "needs an MI355X"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    if res.returncode == 0:  # (a GPU box: the job really ran)
+        assert json.loads(res.stdout.splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert "needs an MI355X" in res.stderr and not res.stdout.strip()

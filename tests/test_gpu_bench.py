@@ -51,14 +51,33 @@ def test_bench_single_gpu_line():
     n4 = d["roofline_n4096"]  # the north star's own target: >= 40 % of fp64 peak on the trailing update at n = 4096
     assert n4["lml_finite"] and n4["peak"] == r["peak"] and 0.4 < n4["frac"] < 1.0
     assert d["fit_plus_sample_ms"] > 0 and d["fit_plus_sample_evals"] == 256 * 31
+    # the other BASELINE configurations and the strong-scaling shards, in the driver-run line
+    sh = d["shard_ms"]
+    assert set(sh) == {"128", "64", "32", "16"} and sh["16"] < sh["32"] < sh["64"] < sh["128"]
+    assert set(d["shard_projection"]["evals_per_s"]) == {"1", "2", "4", "8"}
+    cb = d["config_B"]
+    assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9
+    ce = d["config_E"]
+    assert ce["n_iters"] == 50 and ce["pvrs"]["n_final"] == 1024 and ce["ei128"]["n_final"] == 1024
+    assert 0 < ce["pvrs"]["median_ms_per_tell"] < 500 and 0 < ce["ei128"]["median_ms_per_tell"] < 500
 
 
-def test_bench_refuses_multi_gpu_without_launcher():
-    """--gpus N without torch.distributed.run (WORLD_SIZE unset) must not silently run on one GPU."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
-                         env=env, capture_output=True, text=True, timeout=300)
-    assert res.returncode != 0 and "torch.distributed.run" in (res.stderr + res.stdout)
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver calls it): the parent starts two
+    fresh rank processes itself, both on GPU 0 here (one device on the box -> the ranks agree on gloo: RCCL refuses two
+    ranks on one device), and relays ONE line: BASELINE config C as stated -- one 256-walker ensemble split over the
+    ranks, strong scaling -- with the weak sub-ensemble rate as an extra key."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT",
+                                                            "BGP_DIST_BACKEND")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    d = _line(res)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["parallelism"] == "ensemble_sharded2" and d["config"]["proposals_per_gpu_per_half_step"] == 64
+    assert d["config"]["walkers_total"] == 256
+    assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
+    assert d["dist_backend"] == "gloo" and d["rank_devices"] == [0, 0] and d["rccl_nranks"] is None
+    assert d["weak_chains_evals_per_s"] > 0 and d["gathered_chain_rows"] == 2 * 256
 
 
 @pytest.mark.parametrize("shard", ["chains", "ensemble"])
@@ -71,8 +90,10 @@ def test_bench_two_ranks_on_one_gpu(shard):
     assert KEYS <= set(d) and d["n_gpus"] == 2
     if shard == "chains":   # independent 256-walker sub-ensemble per rank: whole-job evaluations = 2 x
         assert d["scaling"] == "weak" and d["gathered_chain_rows"] == 2 * 2 * 256  # ranks x kept steps x walkers
+        assert d["strong_ensemble_evals_per_s"] > 0
         assert abs(d["value"] - 2 * 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
     else:                   # ONE 256-walker ensemble split over the ranks
-        assert d["scaling"] == "strong" and d["config"]["walkers_per_gpu"] == 128
+        assert d["scaling"] == "strong" and d["config"]["proposals_per_gpu_per_half_step"] == 64
+        assert d["weak_chains_evals_per_s"] > 0
         assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
 

@@ -61,11 +61,12 @@ allc = distributed.gather_chains(chain)
 tmax = distributed.max_over_ranks(3.25 + rank)
 b = distributed.broadcast_array(np.array([1.5, -2.0, 7.0]))
 lp = distributed.shard_log_prob(lambda T: T.sum(axis=1))(np.arange(10.0).reshape(5, 2))
+info = distributed.group_info()
 distributed.barrier()
 big = distributed.gather_chains(np.random.RandomState(1).randn(5120, 18))   # the bench's final gather, again (buffers reused)
 distributed.destroy_process_group()
 print(json.dumps({"ws": ws, "allc": allc.tolist(), "tmax": tmax, "b": b.tolist(), "lp": lp.tolist(),
-                  "big": [big.shape[0], float(big.sum())], "torch": "torch" in sys.modules}))
+                  "big": [big.shape[0], float(big.sum())], "torch": "torch" in sys.modules, "info": info}))
 """
 
 
@@ -79,6 +80,7 @@ def test_native_rccl_collectives_world_size_one():
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["ws"] == 1 and d["torch"] is False
+    assert d["info"]["backend"] == "rccl" and d["info"]["rccl_nranks"] == 1 and d["info"]["rank_devices"] == [0]
     np.testing.assert_array_equal(np.array(d["allc"]), np.arange(12.0).reshape(6, 2))
     assert d["tmax"] == 3.25 and d["b"] == [1.5, -2.0, 7.0] and d["lp"] == [1.0, 5.0, 9.0, 13.0, 17.0]
     ref = np.random.RandomState(1).randn(5120, 18)
@@ -100,3 +102,47 @@ def test_bench_line_through_native_rccl_group():
     assert "RCCL version" in res.stderr
     d = json.loads(out_lines[0])
     assert d["dist_backend"] == "rccl" and d["n_gpus"] == 1 and d["gathered_chain_rows"] == 2 * 256
+
+
+_GATHER_WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import bayes_skopt_amd as bask
+from bayes_skopt_amd import distributed
+rank, local_rank, ws = distributed.init_process_group()
+rng = np.random.RandomState(0)
+X = rng.uniform(size=(300, 3)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(300)
+kw = dict(n_desired_samples=80, n_burnin=3, n_walkers_per_thread=20, progress=False)
+gs = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state=3, device=0, normalize_y=True,
+                   shard_ensemble=True).fit(X, y, **kw)
+calls = []
+orig = gs._ctx.lml_wait_allgather
+g1 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state=3, device=0, normalize_y=True).fit(X, y, **kw)
+# and once more with the collective counted
+gs2 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state=3, device=0, normalize_y=True,
+                    shard_ensemble=True)
+from bayes_skopt_amd import _lib
+real = _lib.Context.lml_wait_allgather
+def counted(self, comm, per_rank):
+    calls.append(per_rank)
+    return real(self, comm, per_rank)
+_lib.Context.lml_wait_allgather = counted
+gs2.fit(X, y, **kw)
+distributed.destroy_process_group()
+print(json.dumps({"same": bool(np.array_equal(gs.chain_, g1.chain_) and np.array_equal(gs2.chain_, g1.chain_)),
+                  "calls": len(calls), "per_rank": sorted(set(calls)), "torch": "torch" in sys.modules}))
+"""
+
+
+def test_device_resident_lml_gather_through_rccl():
+    """The per-half-step exchange of the exact single-ensemble sharding: bgp_lml_batch_wait_allgather gathers the
+    log-likelihoods out of the context's device-resident result vector over RCCL (one-rank group here: the box has one
+    GPU).  A sharded fit through it reproduces the unsharded chain bit for bit."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), BGP_DIST_FORCE="1",
+               BGP_DIST_BACKEND="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, "-c", _GATHER_WORKER % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["same"] and d["torch"] is False
+    assert d["calls"] == 1 + 2 * 7 and d["per_rank"] == [10, 20]  # initial ensemble (20 rows) + 2 half-steps x 7 steps

@@ -144,13 +144,13 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
         "print(repr(l + r['alpha'].sum(1).tolist() + [float(np.trace(k)) for k in r['K_inv']]))"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"BGP_LEFT_LOOKING": "1"}, {"BGP_TWO_PANEL": "0"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
-                {"BGP_PANELS": "4"}, {"BGP_SYRK2": "1"}, {"BGP_FUSED_GRAM": "1"}, {"BGP_FUSED_GRAM": "1", "BGP_PANELS": "4"}):
+    for env in ({}, {"BGP_PANELS": "3"}, {"BGP_PANELS": "1"}, {"BGP_STREAMS": "1"}, {"BGP_STREAMS": "3"},
+                {"BGP_PANELS": "4"}, {"BGP_KBUILD1": "1"}, {"BGP_FUSED_GRAM": "1"}, {"BGP_FUSED_GRAM": "1", "BGP_PANELS": "4"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         outs.append(np.array(eval(r.stdout.strip().splitlines()[-1])))
-    for o in outs[1:]:
-        np.testing.assert_allclose(o, outs[0], rtol=1e-9)
+    for o in outs[1:]:  # (panel grouping, stream count and the Gram build's pipelining only regroup the same operations)
+        np.testing.assert_array_equal(o, outs[0])
     # Gram tiles generated inside the first trailing update that touches them: the same K bits, hence the same LML bits
     np.testing.assert_array_equal(outs[7], outs[0])
     np.testing.assert_array_equal(outs[8], outs[5])
@@ -158,8 +158,8 @@ def test_left_looking_and_single_panel_variants_agree(lib, O):
     X = rng.uniform(size=(700, 6))
     y = np.sin(3 * X.sum(1))
     H = np.concatenate([[0.0], np.full(6, np.log(0.4)), [np.log(0.02)]]) + 0.1 * np.random.RandomState(6).randn(5, 8)
-    # (each output: 5 LML values, then alpha sums and trace(K^-1) of three posterior builds -- the BGP_SYRK2=1 run builds
-    # them with round 1's trsm_kernel / syrk_kernel, every other run with the ring kernels and the active-row remap)
+    # (each output: 5 LML values, then alpha sums and trace(K^-1) of three posterior builds on the ring kernels with the
+    # active-row remap; round 1's kernels left the library in round 3 -- tools/legacy/ keeps them for the A/B benches)
     np.testing.assert_allclose(outs[0][:5], O.lml_batch(X, y, np.full(700, 1e-10), H), rtol=RTOL)
 
 

@@ -95,32 +95,37 @@ def _config_e_optimizer(bask, acq, n0=974, n_points=10_000, seed=0):
 
 
 def test_config_e_tell_loop_pvrs_at_size(bask, O):
-    """BASELINE config E: Optimizer.tell, PVRS over a 10 000-candidate grid, 128 posterior samples, n ~ 1000."""
+    """BASELINE config E as stated: Optimizer.tell, 50 iterations, PVRS over a 10 000-candidate grid, 128 posterior
+    samples, n growing 975 -> 1024 (bask/optimizer.py:228-380).  Every tell is checked for shape / finiteness /
+    argmax consistency; the last three against the oracle: the device PVRS vector vs the reference's per-candidate
+    (n+1) x (n+1) Cholesky loop on a candidate subset that includes the chosen point, and the reported
+    hyper-posterior LML at the median."""
     opt, f = _config_e_optimizer(bask, "pvrs")
-    for it in range(3):
+    n_iters = 50
+    for it in range(n_iters):
         x = opt.ask() if it else [0.5] * 8
         res = opt.tell(x, f(x), gp_samples=128, gp_burnin=10, n_samples=0)
-    n = 974 + 3
-    gp = opt.gp
-    assert len(opt.Xi) == n and gp.X_train_.shape == (n, 8)
-    assert gp.chain_.shape == (200, 10)  # 100 walkers x ceil(128 / 100) kept steps (bask/bayesgpr.py:390,496-500)
-    cand, vals = opt._last_candidates, opt._last_acq_values
-    assert cand.shape == (10_000, 8) and vals.shape == (10_000,) and np.all(np.isfinite(vals)) and np.all(vals > 0)
-    np.testing.assert_allclose(opt.ask(), opt.space.inverse_transform(cand[np.argmax(vals)][None, :])[0])
-    assert res.fun == min(opt.yi)
-    # the device PVRS vector for the median GP and fixed Thompson points vs the reference's per-candidate
-    # (n+1) x (n+1) Cholesky loop (oracle restatement) on a candidate subset that includes the chosen point
-    tp = cand[[3, 77, 1234, 5000, 9999]]
-    dev = gp._pvrs(cand, tp, True)
-    sub = np.unique(np.concatenate([[int(np.argmax(vals)), int(np.argmax(dev)), int(np.argmin(dev))],
-                                    np.random.RandomState(1).choice(10_000, size=13, replace=False)]))
-    h = gp._canonical(gp._kernel_theta_for_predict())[0]
-    ref = O.pvrs_covs(gp.X_train_, np.asarray(gp.alpha), h, cand[sub], tp)
-    np.testing.assert_allclose(dev[sub], ref, rtol=RTOL)
-    # and the hyper-posterior LML at the median the optimizer reports (bask/bayesgpr.py:545-547)
-    ad = np.asarray(gp.alpha, dtype=np.float64)
-    np.testing.assert_allclose(gp.log_marginal_likelihood_value_,
-                               O.lml(gp.X_train_, gp.y_train_, ad, gp._canonical(gp.theta)[0]), rtol=RTOL)
+        n = 974 + it + 1
+        gp = opt.gp
+        assert len(opt.Xi) == n and gp.X_train_.shape == (n, 8)
+        assert gp.chain_.shape == (200, 10)  # 100 walkers x ceil(128 / 100) kept steps (bask/bayesgpr.py:390,496-500)
+        cand, vals = opt._last_candidates, opt._last_acq_values
+        assert cand.shape == (10_000, 8) and vals.shape == (10_000,) and np.all(np.isfinite(vals)) and np.all(vals > 0)
+        np.testing.assert_allclose(opt.ask(), opt.space.inverse_transform(cand[np.argmax(vals)][None, :])[0])
+        assert res.fun == min(opt.yi) and np.isfinite(gp.log_marginal_likelihood_value_)
+        if it < n_iters - 3:
+            continue
+        tp = cand[[3, 77, 1234, 5000, 9999]]
+        dev = gp._pvrs(cand, tp, True)
+        sub = np.unique(np.concatenate([[int(np.argmax(vals)), int(np.argmax(dev)), int(np.argmin(dev))],
+                                        np.random.RandomState(it).choice(10_000, size=9, replace=False)]))
+        h = gp._canonical(gp._kernel_theta_for_predict())[0]
+        ref = O.pvrs_covs(gp.X_train_, np.asarray(gp.alpha), h, cand[sub], tp)
+        np.testing.assert_allclose(dev[sub], ref, rtol=RTOL)
+        ad = np.asarray(gp.alpha, dtype=np.float64)
+        np.testing.assert_allclose(gp.log_marginal_likelihood_value_,
+                                   O.lml(gp.X_train_, gp.y_train_, ad, gp._canonical(gp.theta)[0]), rtol=RTOL)
+    assert len(opt.Xi) == 1024 and gp.X_train_.shape == (1024, 8)  # n = 8 x 128: the full-tile case, no padding rows
 
 
 def test_config_e_tell_ei_128_hyper_samples_at_size(bask, O):

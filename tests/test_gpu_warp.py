@@ -121,3 +121,50 @@ def test_optimizer_with_warping():
     assert opt.gp.chain_.shape == (100, 4 + 4)
     nxt = opt.ask()
     assert all(0.0 <= v <= 1.0 for v in nxt)
+
+
+def test_warped_device_chain_equals_oracle_chain(O):
+    """warp_inputs=True through the sampler's asynchronous path (bgp_lml_batch_warped_submit / _wait: the per-walker
+    Beta parameters are extra chain columns, bask/bayesgpr.py:353-365): the device-driven chain must coincide with the
+    per-walker oracle replay (warp -> LML, default priors + N(0, 0.3) warp priors) on the same RandomState stream --
+    one accept/reject flip would make them diverge."""
+    import scipy.stats as st
+
+    import bayes_skopt_amd as bask
+
+    rng = np.random.RandomState(4)
+    n, d, W, steps = 50, 2, 20, 25
+    X = rng.uniform(size=(n, d))
+    y = np.sin(9.0 * X[:, 0] ** 2) + X[:, 1] + 0.05 * rng.randn(n)
+    y = (y - y.mean()) / y.std()
+    ad = np.full(n, 1e-10)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=7, warp_inputs=True)
+    gp.fit(X, y, n_desired_samples=W, n_burnin=0, n_walkers_per_thread=W, progress=False)
+    start = np.array(gp.pos_, copy=True)
+    assert start.shape == (W, d + 2 + 2 * d)
+    submitted = []
+    real = gp._ctx.lml_warped_submit
+
+    def spy(H, Wp):
+        ok = real(H, Wp)
+        submitted.append((len(H), ok))
+        return ok
+
+    gp._ctx.lml_warped_submit = spy
+    gp.random_state = np.random.RandomState(321)
+    gp.sample(n_desired_samples=W * steps, n_burnin=0, n_walkers_per_thread=W, position=start)
+    dev_chain = gp._sampler.get_chain()
+    assert len(submitted) == 1 + 2 * steps
+    assert all(ok for b, ok in submitted if b == W // 2)  # every half-step block went through submit / wait
+    seed = np.random.RandomState(321).randint(0, np.iinfo(np.int32).max)
+    wp = st.norm(loc=0.0, scale=0.3).logpdf
+
+    def log_prob(theta):
+        th, w = theta[: d + 2], theta[d + 2:]
+        lp = float(O.default_log_prior(th[None, :], d)[0]) + float(np.sum(wp(w)))
+        lp += O.lml_warped(X, y, ad, th, w)
+        return lp if np.isfinite(lp) else -np.inf
+
+    ref_chain, ref_lp, _, _, _ = O.stretch_move_sampler(log_prob, start, steps, np.random.RandomState(seed))
+    np.testing.assert_allclose(dev_chain, ref_chain, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(gp._sampler.get_log_prob(), ref_lp, rtol=1e-7)

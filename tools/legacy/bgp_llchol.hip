@@ -18,6 +18,7 @@
 // The flops are the same n^3/3; what changes is where the bytes go and which MFMA form executes them.
 #include "bgp_common.h"
 #include "bgp_device.h"
+#include "bgp_gemm_legacy.h"
 #include "bgp_gemm8.h"
 
 #define LU_DK 16
