@@ -2,7 +2,7 @@
 """profiles/rNN_pmc_traffic.json from the rocprofv3 PMC passes of tools/profile_round.sh: HBM bytes per launch of the
 trailing-update kernel class (FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md section HBM -- plus
 WRITE_SIZE; both counters are reported in KiB... units of 1024 B by this rocprofv3) and its MFMA utilisation.
-Usage: make_pmc_traffic.py out.json fetch.db write.db mfma.db kernel-substring"""
+Usage: make_pmc_traffic.py out.json fetch.db write.db mfma.db kernel-substring ["what ran"]"""
 import json
 import sqlite3
 import sys
@@ -22,13 +22,14 @@ def per_kernel(db, sub):
 
 def main():
     out, fdb, wdb, mdb, sub = sys.argv[1:6]
+    what = sys.argv[6] if len(sys.argv) > 6 else "tools/profile_round.sh: bench.py --steps 2 --warmup 1 --no-extras (config C only)"
     f = per_kernel(fdb, sub)["FETCH_SIZE"]
     w = per_kernel(wdb, sub)["WRITE_SIZE"]
     m = per_kernel(mdb, sub)
     fetch_kb, write_kb = f[1] / f[0], w[1] / w[0]
     rec = {
-        "source": "tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES "
-                  "in separate passes, BGP_STREAMS=1, bench.py --steps 2 --warmup 1 --no-extras (config C only)",
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate passes, "
+                  "BGP_STREAMS=1; " + what,
         "kernel": sub,
         "launches_averaged": int(f[0]),
         "fetch_size_kb_per_launch_raw": fetch_kb,
