@@ -15,6 +15,14 @@ void bgp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bgp_last_error(void) { return g_err.c_str(); }
+
+int bgp_wait_spins() {
+  static const int spins = [] {
+    const char* e = getenv("BGP_WAIT");
+    return (e && strcmp(e, "block") == 0) ? 0 : 1;
+  }();
+  return spins;
+}
 extern "C" const char* bgp_version(void) { return "bgp 0.1 (gfx950, fp64 MFMA blocked Cholesky)"; }
 
 extern "C" int bgp_device_count(void) {
@@ -119,7 +127,7 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
   BGP_HIP(hipMemcpyAsync(c->dX, hx, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(c->dy, hy, np_ * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(c->dalpha, ha, np_ * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   c->post_B = 0;
   c->has_warp = 0;  // new data: the caller re-installs the warp (bgp_ctx_set_warp)
   c->dXeff = c->dX;
@@ -134,7 +142,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS"};
+                                "BGP_PANEL_WIDTH", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -432,7 +440,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     }
     if (c->timing) (void)hipEventRecord(e1, c->stream);
     if (defer_sync) return BGP_OK;  // (single chunk, timing off: bgp_lml_batch_wait synchronises)
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    BGP_HIP(bgp_stream_sync(c->stream));
     bgp_tcollect(c);
     if (c->timing) {
       float ms = 0.f;
@@ -544,7 +552,7 @@ extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
   const int B = c->pending_B;
   c->pending_B = 0;
   BGP_HIP(hipSetDevice(c->device));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   memcpy(lml, c->hlml, (size_t)B * sizeof(double));
   if (status) memcpy(status, c->hstatus, (size_t)B * sizeof(int));
   return BGP_OK;
@@ -561,7 +569,7 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
   if (rc) return rc;
   BGP_HIP(hipMemcpy2DAsync(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),
                            (size_t)c->n * sizeof(double), c->n, hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 

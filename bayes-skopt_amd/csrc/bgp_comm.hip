@@ -238,8 +238,8 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
   BGP_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
   BGP_NCCL(g_rccl.AllGather(ctx->dlml, c->drecv, (size_t)per_rank, ncclFloat64, c->comm, c->stream));
   BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
-  BGP_HIP(hipStreamSynchronize(ctx->stream));  // (its own download of the local values: long done)
+  BGP_HIP(bgp_stream_sync(c->stream));
+  BGP_HIP(bgp_stream_sync(ctx->stream));  // (its own download of the local values: long done)
   memcpy(lml_all, c->hrecv, total * sizeof(double));
   return BGP_OK;
 }
@@ -256,7 +256,7 @@ extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count,
   BGP_HIP(hipMemcpyAsync(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, count, ncclFloat64, c->comm, c->stream));
   BGP_HIP(hipMemcpyAsync(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 
@@ -272,7 +272,7 @@ extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) 
   BGP_HIP(hipMemcpyAsync(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllReduce(c->dsend, c->drecv, count, ncclFloat64, ncclMax, c->comm, c->stream));
   BGP_HIP(hipMemcpyAsync(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 
@@ -288,7 +288,7 @@ extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int ro
   BGP_HIP(hipMemcpyAsync(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.Broadcast(c->dsend, c->drecv, count, ncclFloat64, root, c->comm, c->stream));
   BGP_HIP(hipMemcpyAsync(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 

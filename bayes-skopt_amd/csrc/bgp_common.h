@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +31,27 @@ void bgp_set_error(const char* fmt, ...);
       return BGP_ERR_HIP;                                                                    \
     }                                                                                        \
   } while (0)
+
+// Wait for a stream the way the sampler's inner loop needs it: ACTIVELY.  hipStreamSynchronize's default wait parks
+// the thread, and for the 0.5-1 ms device calls of the small-batch regime (config E: 26 calls of 50 proposals at
+// n ~ 1000 per tell) the wake-up was measured BISTABLE on MI355X -- the same tell took 25 ms or 52 ms of MCMC, +1 ms per
+// call, run to run and tell to tell.  Polling hipStreamQuery from the calling thread (which has nothing else to do)
+// removes that; after 200 ms of polling the core is handed back to the blocking wait.  BGP_WAIT=block selects the
+// runtime's wait from the start (A/B measurements, oversubscribed hosts).
+int bgp_wait_spins();
+static inline hipError_t bgp_stream_sync(hipStream_t st) {
+  if (bgp_wait_spins()) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; it++) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e != hipErrorNotReady) return e;
+      (void)hipGetLastError();  // (hipErrorNotReady is recorded as the thread's last error)
+      if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+      __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize(st);
+}
 
 struct bgp_ctx {
   int device = 0;

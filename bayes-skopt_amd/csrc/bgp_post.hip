@@ -216,10 +216,10 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
                            ld * ld, b);
         BGP_HIP(hipMemcpyAsync(L + (size_t)(off + b) * n * n, c->dscratch, (size_t)n * n * sizeof(double),
                                hipMemcpyDeviceToHost, c->stream));
-        BGP_HIP(hipStreamSynchronize(c->stream));
+        BGP_HIP(bgp_stream_sync(c->stream));
       }
     }
-    BGP_HIP(hipStreamSynchronize(c->stream));
+    BGP_HIP(bgp_stream_sync(c->stream));
   }
   c->post_B = B;
   return BGP_OK;
@@ -364,7 +364,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
     rc = acq_run(c, c->stream, B, m, mpad, doutB, dqB, *ap, dT, dbad, dmumin, dacc);
     if (rc) return rc;
   }
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 
@@ -544,7 +544,7 @@ extern "C" int bgp_acq_values(bgp_ctx* c, int B, int m, const double* mu, const 
   ap.n_acq = n_acq, ap.kinds = kinds, ap.params = params, ap.n_samples = n_samples, ap.out = out;
   rc = acq_run(c, c->stream, B, m, mpad, dmu, dvar, ap, dT, dbad, dmumin, dacc);
   if (rc) return rc;
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 
@@ -742,7 +742,7 @@ extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lm
                      (int)p);
   BGP_HIP(hipGetLastError());
   BGP_HIP(hipMemcpyAsync(grad, dgrad, (size_t)B * p * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   for (int b = 0; b < B; b++) {
     if (st[b] != 0)
       for (size_t k = 0; k < p; k++) grad[(size_t)b * p + k] = 0.0;  // sklearn/_gpr.py:589: (-inf, zeros)
@@ -828,7 +828,7 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
                      dst, kernel_diag_value(c, h_kernel), m, T, dcov);
   BGP_HIP(hipGetLastError());
   BGP_HIP(hipMemcpyAsync(covs, dcov, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 
@@ -990,7 +990,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     if ((rc = bgp_launch_cholesky(w, 1, 0))) break;
     int st = 0;
     SY(hipMemcpyAsync(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    SY(hipStreamSynchronize(c->stream));
+    SY(bgp_stream_sync(c->stream));
     if (st != 0) {
       bgp_set_error("bgp_sample_y: predictive covariance not positive definite at pivot %d (jitter %.3g)", st, jitter);
       rc = BGP_ERR_NOTPD;
@@ -1002,7 +1002,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     SY(hipGetLastError());
     SY(hipMemcpy2DAsync(out, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
                         (size_t)m * sizeof(double), n_draws, hipMemcpyDeviceToHost, c->stream));
-    SY(hipStreamSynchronize(c->stream));
+    SY(bgp_stream_sync(c->stream));
 #undef SY
   } while (0);
   (void)hipStreamSynchronize(c->stream);
@@ -1137,7 +1137,7 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     BGP_HIP(hipMemcpy2DAsync(out + (size_t)off * m, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
                              (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
   }
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
 

@@ -85,7 +85,7 @@ extern "C" int bgp_ctx_set_warp(bgp_ctx* c, const double* warp) {
   BGP_HIP(hipMemcpyAsync(c->dwarp, warp, 2 * (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarp, c->dXw1, c->n, 1, 0);
   if (rc) return rc;
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   c->has_warp = 1;
   c->dXeff = c->dXw1;
   return BGP_OK;
@@ -110,6 +110,6 @@ extern "C" int bgp_beta_cdf(bgp_ctx* c, int m, const double* X, const double* wa
   rc = bgp_launch_warp(c, c->stream, dXi, dW, dXo, m, 1, 0);
   if (rc) return rc;
   BGP_HIP(hipMemcpyAsync(out, dXo, md * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(hipStreamSynchronize(c->stream));
+  BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
