@@ -142,7 +142,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_TIMEOUT_MS", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -199,6 +199,8 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     if (ns < 1) ns = 1;
     if (ns > BGP_MAX_STREAMS) ns = BGP_MAX_STREAMS;
     c->nstreams = ns;
+    const char* envps = getenv("BGP_PERSIST");  // 0: never, 1: whenever the batch fits (<= 64 matrices, n > 128); unset: automatic
+    c->persist = envps ? (atoi(envps) != 0 ? 1 : 0) : -1;
     const char* envss = getenv("BGP_SMALL_SPLIT");  // 1: n <= 128 through the two-launch path (A/B of the fused kernel)
     c->use_small_split = (envss && atoi(envss) != 0) ? 1 : 0;
     const char* envk = getenv("BGP_KBUILD1");
@@ -278,6 +280,15 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->hstatus) (void)hipHostFree(c->hstatus);
   if (c->hh) (void)hipHostFree(c->hh);
   if (c->hwarp) (void)hipHostFree(c->hwarp);
+  for (int k = 0; k < 9; k++) {
+    if (c->ps_chain[k]) (void)hipStreamDestroy(c->ps_chain[k]);
+    if (c->ps_tile[k]) (void)hipStreamDestroy(c->ps_tile[k]);
+  }
+  if (c->ps_ev0) (void)hipEventDestroy(c->ps_ev0);
+  if (c->ps_eva) (void)hipEventDestroy(c->ps_eva);
+  if (c->ps_evb) (void)hipEventDestroy(c->ps_evb);
+  free_dev(c->ps_flags);
+  if (c->ps_herr) (void)hipHostFree(c->ps_herr);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
@@ -309,6 +320,27 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
 }
 
 static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status);
+
+// Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (measured on MI355X, DESIGN.md
+// section 6): off until measured.
+static bool bgp_persist_auto(const bgp_ctx* c, int nb) {
+  (void)c;
+  (void)nb;
+  return false;
+}
+
+// A persistent call whose waits timed out (error word != 0 behind the synchronisation) is redone on the multi-launch
+// path, once and loudly; the context stays on that path afterwards.
+static int ps_check(bgp_ctx* c) {
+  if (!c->ps_inflight) return 0;
+  c->ps_inflight = 0;
+  if (!c->ps_herr || *c->ps_herr == 0) return 0;
+  *c->ps_herr = 0;
+  c->ps_disabled = 1;
+  fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); the "
+                  "batch is redone on the multi-launch path, which this context keeps from now on\n");
+  return 1;
+}
 
 extern "C" int bgp_lml_batch_submit(bgp_ctx* c, int B, const double* h);
 extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status);
@@ -379,6 +411,10 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     int rc = BGP_OK;
     const bool fused_small = c->nblk == 1 && !warp && !c->use_small_split;
     const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
+    // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
+    // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
+    const bool use_ps = !fused_small && !warp && !fused_gram && !c->timing && !c->ps_disabled && c->nblk >= 2 && nb <= 64 &&
+                        (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb)));
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {
       // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
@@ -401,6 +437,13 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         rc = bgp_launch_cholesky(c, nb, 0);
       }
       if (rc) return rc;
+    } else if (use_ps) {
+      // small batch: K-build on this stream, then ONE chain / tile kernel pair instead of ~3 launches per block column
+      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+      if (rc) return rc;
+      rc = bgp_launch_cholesky_persist(c, nb);
+      if (rc) return rc;
+      c->ps_inflight = 1;
     } else if (ng == 1) {
       if (fused_gram) {
         S4Gen gen;
@@ -441,6 +484,10 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     if (c->timing) (void)hipEventRecord(e1, c->stream);
     if (defer_sync) return BGP_OK;  // (single chunk, timing off: bgp_lml_batch_wait synchronises)
     BGP_HIP(bgp_stream_sync(c->stream));
+    if (ps_check(c)) {
+      off -= c->max_batch;  // redo this chunk (ps_disabled is set: the multi-launch path takes it)
+      continue;
+    }
     bgp_tcollect(c);
     if (c->timing) {
       float ms = 0.f;
@@ -523,6 +570,7 @@ static int lml_submit_impl(bgp_ctx* c, int B, const double* h, const double* war
     return rc;
   }
   c->pending_B = B;
+  c->pending_warped = warp ? 1 : 0;
   return BGP_OK;
 }
 
@@ -553,9 +601,21 @@ extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
   c->pending_B = 0;
   BGP_HIP(hipSetDevice(c->device));
   BGP_HIP(bgp_stream_sync(c->stream));
+  if (ps_check(c)) {  // redo on the multi-launch path (the submitted block is still in the pinned buffers)
+    const double* wp = c->pending_warped ? c->hwarp : nullptr;
+    return lml_batch_impl(c, B, c->hh, wp, lml, status);
+  }
   memcpy(lml, c->hlml, (size_t)B * sizeof(double));
   if (status) memcpy(status, c->hstatus, (size_t)B * sizeof(int));
   return BGP_OK;
+}
+
+// For collectors outside this file (bgp_lml_batch_wait_allgather): the context's stream has been synchronised; if the
+// pending batch ran on the launch-free path and timed out, redo it (device-resident results included) on the
+// multi-launch path.
+int bgp_lml_redo_if_abandoned(bgp_ctx* c, int B) {
+  if (!ps_check(c)) return BGP_OK;
+  return lml_batch_impl(c, B, c->hh, c->pending_warped ? c->hwarp : nullptr, c->hlml, c->hstatus);
 }
 
 extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {

@@ -24,6 +24,8 @@
 
 #include "bgp_gemm.h"
 
+#include <cstdlib>
+
 // ------------------------------------------------------------------------------------------
 // potrf: diagonal block k of every walker, one workgroup (4 waves) per walker, block in LDS.
 //
@@ -269,13 +271,15 @@ static __device__ __forceinline__ void pf_generate_tile(double* __restrict__ s, 
 }
 }
 
+// One diagonal block of one walker (the whole workgroup).  Returns 0, or the 1-based pivot index inside the block at
+// which the factorisation failed (status / lml of the walker are set here either way).  Called once per launch by
+// potrf_kernel and once per block column by the persistent chain kernel (ps_chain_kernel): the LDS tile is free again
+// when the function returns through its trailing barrier.
 template <int GEN, int STAT, int FORM>
-__global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
-                                                     double* __restrict__ yw, double* __restrict__ accb,
-                                                     double* __restrict__ lml, int* __restrict__ status, int n,
-                                                     int ld, size_t mstride, int ystride, int nblk, int k, PfGen gen) {
-  const int b = blockIdx.x;
-  if (!GEN && status[b] != 0) return;
+static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf, double* __restrict__ Wbuf,
+                                               double* __restrict__ yw, double* __restrict__ accb,
+                                               double* __restrict__ lml, int* __restrict__ status, int n, int ld,
+                                               size_t mstride, int ystride, int nblk, int k, const PfGen& gen) {
   __shared__ double s[128 * PF_LD];
   __shared__ double Minv[8 * 16 * PF_MLD];
   __shared__ double xrow[2][16 * PF_MLD];  // X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
       status[b] = k * 128 + failed;  // 1-based index of the failing pivot
       lml[b] = -INFINITY;            // sklearn/_gpr.py:588-589
     }
-    return;
+    return failed;
   }
   PF_T(26);
   // ---- L_kk out.  Only the lower triangle is written (16-byte stores; the element right of the diagonal in
@@ -533,6 +537,149 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
     }
   }
   PF_T(28);
+  __syncthreads();  // (every wave is past its last LDS read: a caller may run the next block in this workgroup)
+  return 0;
+}
+
+template <int GEN, int STAT, int FORM>
+__global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
+                                                     double* __restrict__ yw, double* __restrict__ accb,
+                                                     double* __restrict__ lml, int* __restrict__ status, int n,
+                                                     int ld, size_t mstride, int ystride, int nblk, int k, PfGen gen) {
+  const int b = blockIdx.x;
+  if (!GEN && status[b] != 0) return;
+  (void)pf_block<GEN, STAT, FORM>(b, Kbuf, Wbuf, yw, accb, lml, status, n, ld, mstride, ystride, nblk, k, gen);
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch-free factorisation of SMALL batches (B <= 64 matrices, or one large matrix): ONE pair of persistent kernels per
+// batch instead of ~3 dependent launches per block column.
+//
+// Why: with few matrices the chain of dependent launches is the critical path -- potrf(k) keeps B of the 256 CUs busy
+// for 30 us while the rest idle, and the trailing update of step k cannot overlap the next panel (stream / event
+// look-ahead was measured slower than the chain it shortens: events cost more than they hide).  Here the diagonal-block
+// chain and the tile work run SIDE BY SIDE and talk through device-scope flags:
+//   * ps_chain_kernel (this file): one 512-thread workgroup per matrix walks the diagonal blocks J = 0 .. nblk-1: waits
+//     until both row halves of block (J, J) have received their left-looking update, factorises it (pf_block: the same
+//     code as potrf_kernel), publishes L_JJ / W_JJ / z_J and raises wready[J];
+//   * ps_tile_kernel (bgp_syrk4.hip): 256-thread workgroups draw tasks from one ticket counter, in an order that is
+//     topological for the dependency graph (column by column), and do the left-looking tile work -- update with all
+//     finished panels to the left, then the panel solve against W_JJ -- waiting on / raising xready, diagcnt, wready.
+// The two kernels run on a pair of CU-masked streams (hipExtStreamCreateWithCUMask; on MI355X mask bit i selects a CU of
+// XCD i % 8: the low 8k bits give the chain k CUs in every XCD, the complement gives the tile kernel the other 32 - k), so
+// the chain's workgroups -- 133 KB of LDS each, one per CU -- are resident by construction whatever the tile kernel does.
+// Every wait is bounded (PsArgs::spin_limit): a timeout raises the error word, both kernels drain, and the host redoes
+// the batch on the multi-launch path.  Arithmetic, operand order and summation order are those of the multi-launch path:
+// the log-likelihoods are bit-identical (tests/test_gpu_persist.py).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ int ps_ok;
+  unsigned* const flags = a.flags;
+  unsigned* const err = flags + PS_ERROR;
+  unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
+  const unsigned* const diagcnt = flags + PS_HDR + (size_t)a.B * a.nblk + (size_t)b * a.nblk;
+  for (int J = 0; J < a.nblk; J++) {
+    if (tid == 0) {
+      int ok = 1;
+      if (J > 0) {  // both row halves of (J, J) carry every update from the panels to their left
+        ok = ps_wait_ge(diagcnt + J, 2u, err, a.spin_limit) ? 1 : 0;
+        ps_acquire();
+      }
+      ps_ok = ok;
+    }
+    __syncthreads();
+    if (!ps_ok) return;  // (timed out / abandoned: the host redoes the batch)
+    const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
+                                         a.nblk, J, PfGen());
+    ps_publish_barrier();
+    if (tid == 0) {
+      ps_release();
+      // a failed matrix (status set above) releases every later column at once: its tile tasks see the status and
+      // only pass their own flags on
+      for (int j = J; j < (failed ? a.nblk : J + 1); j++) ps_st(wready + j, 1u);
+    }
+    if (failed) return;
+  }
+}
+
+int bgp_ps_total_tasks(int B, int nblk);
+
+// Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
+// this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes
+// c->stream wait for both.  The error word travels to pinned memory behind them (ctx->ps_herr): != 0 after the
+// synchronisation means a wait timed out and the caller redoes the batch on the multi-launch path.
+int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
+  const int nblk = c->nblk, ld = c->npad;
+  const int k = (B + 7) / 8;
+  if (B < 1 || k > 8 || nblk < 2) {
+    bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
+    return BGP_ERR_INVALID;
+  }
+  if (!c->ps_chain[k]) {
+    // mask bit i selects one CU of XCD i % 8 (the driver's symmetric map; tools/cumask_probe.hip): the low 8k bits are
+    // k CUs in every XCD
+    uint32_t ma[8], mb[8];
+    for (int i = 0; i < 8; i++) ma[i] = 0u, mb[i] = 0xffffffffu;
+    for (int i = 0; i < 8 * k; i++) {
+      ma[i / 32] |= 1u << (i % 32);
+      mb[i / 32] &= ~(1u << (i % 32));
+    }
+    BGP_HIP(hipExtStreamCreateWithCUMask(&c->ps_chain[k], 8, ma));
+    BGP_HIP(hipExtStreamCreateWithCUMask(&c->ps_tile[k], 8, mb));
+  }
+  if (!c->ps_ev0) {
+    BGP_HIP(hipEventCreateWithFlags(&c->ps_ev0, hipEventDisableTiming));
+    BGP_HIP(hipEventCreateWithFlags(&c->ps_eva, hipEventDisableTiming));
+    BGP_HIP(hipEventCreateWithFlags(&c->ps_evb, hipEventDisableTiming));
+    BGP_HIP(hipHostMalloc((void**)&c->ps_herr, sizeof(unsigned), hipHostMallocDefault));
+    *c->ps_herr = 0;
+  }
+  const size_t words = ps_flag_words(B, nblk);
+  if (words > c->cap_psflags) {
+    if (c->ps_flags) (void)hipFree(c->ps_flags);
+    c->ps_flags = nullptr;
+    c->cap_psflags = 0;
+    BGP_HIP(hipMalloc(&c->ps_flags, (words + words / 2) * sizeof(unsigned)));
+    c->cap_psflags = words + words / 2;
+  }
+  BGP_HIP(hipMemsetAsync(c->ps_flags, 0, words * sizeof(unsigned), c->stream));
+  static unsigned long long limit = 0;
+  if (!limit) {
+    const char* e = getenv("BGP_PS_TIMEOUT_MS");
+    limit = 100000ull * (unsigned long long)((e && atoi(e) > 0) ? atoi(e) : 3000);  // 100 MHz wall clock
+  }
+  PsArgs a;
+  a.K = c->dK;
+  a.W = c->dW;
+  a.yw = c->dyw;
+  a.acc = c->dacc;
+  a.lml = c->dlml;
+  a.status = c->dstatus;
+  a.flags = c->ps_flags;
+  a.n = c->n;
+  a.ld = ld;
+  a.nblk = nblk;
+  a.B = B;
+  a.ystride = ld;
+  a.mstride = (size_t)ld * ld;
+  a.total = bgp_ps_total_tasks(B, nblk);
+  a.spin_limit = limit;
+  hipStream_t sa = c->ps_chain[k], sb = c->ps_tile[k];
+  BGP_HIP(hipEventRecord(c->ps_ev0, c->stream));
+  BGP_HIP(hipStreamWaitEvent(sa, c->ps_ev0, 0));
+  BGP_HIP(hipStreamWaitEvent(sb, c->ps_ev0, 0));
+  hipLaunchKernelGGL(ps_chain_kernel, dim3(B), dim3(PF_THREADS), 0, sa, a);
+  BGP_HIP(hipEventRecord(c->ps_eva, sa));
+  const int grid = std::min(a.total, 3 * 8 * (32 - k));
+  bgp_launch_ps_tile(sb, a, grid);
+  BGP_HIP(hipEventRecord(c->ps_evb, sb));
+  BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_eva, 0));
+  BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_evb, 0));
+  BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
 }
 
 // LDS-DMA pipelined trailing update and panel solve (bgp_syrk4.hip)

@@ -69,7 +69,6 @@ struct bgp_comm {
   size_t cap_send = 0, cap_recv = 0;
   double* hrecv = nullptr;  // pinned landing buffer of the device-resident gathers
   size_t cap_hrecv = 0;
-  hipEvent_t ev = nullptr;  // "the context's stream has produced its log-likelihoods"
 };
 
 #define BGP_NCCL(call)                                                                          \
@@ -191,7 +190,6 @@ extern "C" void bgp_comm_destroy(bgp_comm* c) {
   if (c->dsend) (void)hipFree(c->dsend);
   if (c->drecv) (void)hipFree(c->drecv);
   if (c->hrecv) (void)hipHostFree(c->hrecv);
-  if (c->ev) (void)hipEventDestroy(c->ev);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -232,14 +230,18 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
     BGP_HIP(hipHostMalloc((void**)&c->hrecv, total * sizeof(double), hipHostMallocDefault));
     c->cap_hrecv = total;
   }
-  if (!c->ev) BGP_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+  const int Bp = ctx->pending_B;
   ctx->pending_B = 0;  // (a rank without rows of its own has nothing pending: it contributes padding)
-  BGP_HIP(hipEventRecord(c->ev, ctx->stream));
-  BGP_HIP(hipStreamWaitEvent(c->stream, c->ev, 0));
+  // the local batch must be complete and sound before its values leave the device: a launch-free factorisation that
+  // timed out is redone here (this wait is the host's only synchronisation with the context's stream per half-step)
+  BGP_HIP(bgp_stream_sync(ctx->stream));
+  if (Bp > 0) {
+    rc = bgp_lml_redo_if_abandoned(ctx, Bp);
+    if (rc) return rc;
+  }
   BGP_NCCL(g_rccl.AllGather(ctx->dlml, c->drecv, (size_t)per_rank, ncclFloat64, c->comm, c->stream));
   BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
-  BGP_HIP(bgp_stream_sync(ctx->stream));  // (its own download of the local values: long done)
   memcpy(lml_all, c->hrecv, total * sizeof(double));
   return BGP_OK;
 }

@@ -119,6 +119,17 @@ struct bgp_ctx {
   size_t cap_pinned = 0;
   int pending_B = 0;
   bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
+  // launch-free factorisation of small batches: CU-masked stream pairs (k CUs per XCD for the diagonal-block chain,
+  // the other 32 - k for the tile workers), created on first use; flag block; events
+  int persist = -1;          // env BGP_PERSIST: 0 never, 1 whenever possible, -1 (unset) automatic by batch size
+  hipStream_t ps_chain[9] = {nullptr}, ps_tile[9] = {nullptr};
+  hipEvent_t ps_ev0 = nullptr, ps_eva = nullptr, ps_evb = nullptr;
+  unsigned* ps_flags = nullptr;
+  size_t cap_psflags = 0;
+  unsigned* ps_herr = nullptr;  // pinned: error word of the last persistent call
+  int ps_inflight = 0;          // a persistent call is on the stream (its error word is checked behind the sync)
+  int ps_disabled = 0;          // a persistent call timed out: multi-launch path from now on
+  int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
   // timing
   int timing = 0;
   double t_ms[5] = {0, 0, 0, 0, 0};
@@ -166,6 +177,33 @@ static inline void bgp_tcollect(bgp_ctx* c) {
   c->ev.clear();
   c->evcat.clear();
 }
+
+// ---- launch-free factorisation of small batches (bgp_chol.hip: ps_chain_kernel, bgp_syrk4.hip: ps_tile_kernel) ----
+// Flag block of one persistent factorisation (32-bit words, zeroed by a memset node in front of every call):
+//   [PS_TICKET]  next task of the tile kernel          [PS_ERROR]  != 0: a spin timed out / a rank gave up: everybody leaves
+//   wready[b * nblk + J]          1 when potrf(J) of matrix b has published L_JJ, W_JJ, z_J (or the matrix has failed)
+//   diagcnt[b * nblk + J]         row halves of the diagonal block (J, J) whose left-looking update is complete (0..2)
+//   xready[(b * nblk + I) * nblk + J]   row halves of the panel block X_IJ that are final (0..2), I > J
+#define PS_TICKET 0
+#define PS_ERROR 1
+#define PS_HDR 16
+struct PsArgs {
+  double* K;          // B working matrices (ld x ld, row-major), become L in place
+  double* W;          // B x nblk inverses of the diagonal blocks
+  double* yw;         // B working right-hand sides (become z)
+  double* acc;        // B x 4 running {log det, z^T z}
+  double* lml;
+  int* status;
+  unsigned* flags;    // the block above
+  int n, ld, nblk, B, ystride;
+  size_t mstride;
+  int total;          // tasks of the tile kernel
+  unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
+};
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (2 + nblk); }
+int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
+int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int grid);
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);

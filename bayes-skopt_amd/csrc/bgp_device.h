@@ -15,6 +15,49 @@ static __device__ __forceinline__ double bgp_stationary(double r2, int stat) {
   return (1.0 + t + t * t / 3.0) * exp(-t);
 }
 
+// ---- in-launch hand-off between workgroups (persistent factorisation; cdna_hip_programming.md section 6, Guideline 16) ----
+// Every shared word is accessed with relaxed AGENT-scope atomics (sc1: they bypass the per-CU L1); payload visibility
+// comes from ONE agent-scope release on the producer (after every storing wave has drained its stores and the workgroup
+// has met at a barrier) and ONE agent-scope acquire on the consumer (after the poll has succeeded, before a barrier
+// that releases the other waves to their plain loads).  Never from placement, never from workgroup scope.
+static __device__ __forceinline__ unsigned ps_ld(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void ps_st(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ONE lane: spin (with s_sleep) until *p >= want.  False when somebody raised the error word or this wait outlasted
+// `limit` ticks of the 100 MHz wall clock (it raises the error word itself then): every loop in both kernels leaves.
+static __device__ __forceinline__ bool ps_wait_ge(const unsigned* p, unsigned want, unsigned* err, unsigned long long limit) {
+  if (ps_ld(p) >= want) return true;
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned it = 0;; it++) {
+    __builtin_amdgcn_s_sleep(2);
+    if (ps_ld(p) >= want) return true;
+    if ((it & 15) == 15) {
+      if (ps_ld(err) != 0) return false;
+      if (wall_clock64() - t0 > limit) {
+        ps_st(err, 1u);
+        return false;
+      }
+    }
+  }
+}
+// EVERY thread, after its last payload store: drain, meet.  Then ONE lane: ps_signal_*.
+static __device__ __forceinline__ void ps_publish_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+static __device__ __forceinline__ void ps_release() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2: restated)
+}
+static __device__ __forceinline__ void ps_signal_add(unsigned* p) {
+  ps_release();
+  __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static __device__ __forceinline__ void ps_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
 // XCD-aware block -> (matrix b, tile t) map.  The dispatcher places block id on XCD id % 8
 // (MI355X_MICROARCH.md "Workgroup dispatch"); matrix b is pinned to XCD b % 8 and each XCD walks
 // through its matrices one after another so that the panels a matrix's tiles share stay in that

@@ -499,6 +499,194 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 }
 
 // ------------------------------------------------------------------------------------------
+// Tile worker of the launch-free factorisation (see ps_chain_kernel, bgp_chol.hip, for the scheme).  Left-looking by
+// tiles: task (b, I, J, h) owns the 64 x 128 row half h of block (I, J) of matrix b and
+//   1. loads it once and applies EVERY finished panel to its left,  C -= X_I,p X_J,p^T  for p = 0 .. J-1, on the ring
+//      (two-stage LDS-DMA pipeline, 64 + 128 operand rows per 16-wide chunk), as far as the panels are final -- it
+//      waits on xready only when it has caught up with the factorisation;
+//   2. I == J: stores the updated diagonal half and raises diagcnt (the chain kernel factorises the block when both
+//      halves are in);  I > J: stores the half, waits for W_JJ (wready), and runs the panel solve X = C W_JJ^T in
+//      place with the fused right-hand-side update y_I -= X z_J (the code of trsm4_kernel), then raises xready.
+// Tasks are drawn from ONE ticket counter in column-major order (per column: every matrix's diagonal halves, then
+// block J+1, J+2, ...), which is a topological order of the dependency graph: the earliest unfinished task always
+// belongs to a running workgroup, so the waits cannot deadlock whatever the number of resident workgroups.
+// Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
+// ascending, A-negate): bit-identical factors.
+// ------------------------------------------------------------------------------------------
+static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk) { return B * (nblk - 1) * (nblk + 2); }
+
+__global__ void __launch_bounds__(256, 3) ps_tile_kernel(PsArgs a) {
+  constexpr unsigned AOPB = 64 * S4_ROWB, STAGEB = (64 + 128) * S4_ROWB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  __shared__ int sh_t, sh_q;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int nblk = a.nblk, B = a.B, ld = a.ld;
+  unsigned* const flags = a.flags;
+  unsigned* const err = flags + PS_ERROR;
+  unsigned voffA[2], voffB[4], voffW[4];
+  s4_src<64>(voffA, ld, w, lane);
+  s4_src<128>(voffB, ld, w, lane);
+  s4_src<128>(voffW, 128, w, lane);
+  for (;;) {
+    if (tid == 0) sh_t = (int)__hip_atomic_fetch_add(flags + PS_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int t = sh_t;
+    if (t >= a.total) return;
+    // ---- ticket -> (column J, matrix b, block row I, half h)
+    int J = 0;
+    for (;;) {
+      const int c = (J == 0 ? 2 * (nblk - 1) : 2 * (nblk - J)) * B;
+      if (t < c) break;
+      t -= c;
+      J++;
+    }
+    const int q0 = t / B, b = t - q0 * B, h = q0 & 1, I = (J == 0 ? 1 : J) + (q0 >> 1);
+    const bool diag = (I == J);
+    unsigned* const wready = flags + PS_HDR + (size_t)b * nblk;
+    unsigned* const diagcnt = flags + PS_HDR + (size_t)B * nblk + (size_t)b * nblk;
+    unsigned* const xrI = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + I) * nblk;
+    unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + J) * nblk;
+    const int* const stat = a.status + b;
+    double* const M = a.K + (size_t)b * a.mstride;
+    const size_t row0 = (size_t)I * 128 + h * 64;
+    double* const C = M + row0 * ld + J * 128;
+    if (tid == 0) sh_q = (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    __syncthreads();
+    bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
+    __syncthreads();
+    if (J > 0 && !dead) {
+      // ---- 1. left-looking update with the panels 0 .. J-1
+      const double* const XA = M + row0 * ld;
+      const double* const XB = M + (size_t)J * 128 * ld;
+      unsigned pa[4], pb[4];
+      s4_frag_addr(pa, lds0, wr * 32, lane);
+      s4_frag_addr(pb, lds0 + AOPB, wc * 64, lane);
+      d4 acc[2][4];
+      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(acc[i][j]));
+      int q = 0;
+      while (q < J) {
+        if (tid == 0) {
+          int qq = q;
+          bool ok = true;
+          while (qq < J && ps_ld(xrI + qq) >= 2u && (diag || ps_ld(xrJ + qq) >= 2u)) qq++;
+          if (qq == q) {  // caught up with the factorisation: wait for the next panel
+            ok = ps_wait_ge(xrI + q, 2u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 2u, err, a.spin_limit));
+            qq = q + 1;
+            while (ok && qq < J && ps_ld(xrI + qq) >= 2u && (diag || ps_ld(xrJ + qq) >= 2u)) qq++;
+          }
+          ps_acquire();
+          sh_q = ok ? qq : -1;
+        }
+        __syncthreads();
+        const int qq = sh_q;
+        if (qq < 0) return;  // abandoned
+        const int nch = (qq - q) * 8;
+        const double* const XAq = XA + (size_t)q * 128;
+        const double* const XBq = XB + (size_t)q * 128;
+        s4_issue<64>(XAq, voffA, 0, lds0, w);
+        s4_issue<128>(XBq, voffB, 0, lds0 + AOPB, w);
+        for (int c = 0; c < nch; c += 2) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; s2++) {
+            S4_WAIT_VM0();
+            __builtin_amdgcn_s_barrier();
+            if (c + s2 + 1 < nch) {
+              const unsigned nb = lds0 + (unsigned)((s2 ^ 1) * STAGEB);
+              s4_issue<64>(XAq, voffA, (c + s2 + 1) * S4_KC, nb, w);
+              s4_issue<128>(XBq, voffB, (c + s2 + 1) * S4_KC, nb + AOPB, w);
+            }
+            s4_mma<2, 4, -64, 0, 1>(pa, pb, s2 * STAGEB, acc);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        __syncthreads();  // (the ring and sh_q are free again)
+        q = qq;
+      }
+      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+    }
+    if (diag) {
+      ps_publish_barrier();
+      if (tid == 0) ps_signal_add(diagcnt + J);
+      __syncthreads();
+      continue;
+    }
+    // ---- 2. panel solve against W_JJ
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this half's updated values have left the wave
+    if (tid == 0) {
+      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit);
+      ps_acquire();
+      sh_q = !ok ? -1 : (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : 1);
+    }
+    __syncthreads();
+    if (sh_q < 0) return;
+    dead = dead || sh_q == 0;
+    if (!dead) {
+      const double* const Wm = a.W + ((size_t)b * nblk + J) * (128 * 128);
+      const int r0 = w * 16;
+      unsigned pa[4], pb[4];
+      s4_frag_addr(pa, lds0, r0, lane);
+      s4_frag_addr(pb, lds0 + AOPB, 0, lane);
+      d4 acc[1][8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) acc[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
+      s4_issue<64>(C, voffA, 0, lds0, w);
+      s4_issue<128>(Wm, voffW, 0, lds0 + AOPB, w);
+      for (int c = 0; c < 8; c += 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+          S4_WAIT_VM0();
+          __builtin_amdgcn_s_barrier();
+          if (c + s2 + 1 < 8) {
+            const unsigned nb = lds0 + (unsigned)((s2 ^ 1) * STAGEB);
+            s4_issue<64>(C, voffA, (c + s2 + 1) * S4_KC, nb, w);
+            s4_issue_from<128>(Wm, voffW, (c + s2 + 1) * S4_KC, nb + AOPB, w, 16 * (c + s2 + 1));
+          }
+          s4_mma<1, 8, -64, 0, 0>(pa, pb, s2 * STAGEB, acc, c + s2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
+      // one wave per row, fixed shuffle order (as trsm4_kernel)
+      const double* const zk = a.yw + (size_t)b * a.ystride + J * 128;
+      double zc[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
+      double* const yi = a.yw + (size_t)b * a.ystride + I * 128 + h * 64;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = GK_ROWB(r0, 0, lane, r);
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const double x = acc[0][j][r];
+          C[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
+          part += x * zc[j];
+        }
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        part += __shfl_xor(part, 8);
+        if ((lane & 15) == 0) yi[row] -= part;
+      }
+    }
+    ps_publish_barrier();
+    if (tid == 0) ps_signal_add(xrI + J);
+    __syncthreads();
+  }
+}
+
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int grid) {
+  hipLaunchKernelGGL(ps_tile_kernel, dim3(grid), dim3(256), 0, st, a);
+}
+int bgp_ps_total_tasks(int B, int nblk) { return ps_total_tasks(B, nblk); }
+
+// ------------------------------------------------------------------------------------------
 // General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):
 //     MODE 0:  C  = A B^T          (C not read)             P = K_* K^-1
 //     MODE 1:  C -= A B^T  on the tiles with ti >= tj only   cov = K_** - P K_*^T when only a Cholesky reads it

@@ -1,0 +1,97 @@
+// hipExtStreamCreateWithCUMask on MI355X: which (XCC, SE, CU) does mask bit i select?  And: do two kernels on
+// complementary masks really run side by side (a resident spinner on mask A, work on mask B)?
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/bin/cumask_probe tools/cumask_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ void where_kernel(unsigned* out) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // XCC_ID
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID: wave/simd/pipe/cu/sh/se...
+    out[blockIdx.x * 2] = xcc;
+    out[blockIdx.x * 2 + 1] = hwid;
+  }
+  // stay a little so that every block gets its own slot
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000) {}
+}
+
+__global__ void spinner(volatile unsigned* flag, unsigned* resident) {
+  if (threadIdx.x == 0) {
+    atomicAdd(resident, 1u);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load((unsigned*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < 200000000ull) __builtin_amdgcn_s_sleep(8);
+  }
+}
+__global__ void worker(unsigned* cnt) { if (threadIdx.x == 0) atomicAdd(cnt, 1u); }
+__global__ void release(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+int main() {
+  setvbuf(stdout, nullptr, _IONBF, 0);
+  hipDeviceProp_t p;
+  CK(hipGetDeviceProperties(&p, 0));
+  printf("CUs %d\n", p.multiProcessorCount);
+  unsigned* dout;
+  CK(hipMalloc(&dout, 4096 * 8));
+  for (int bit : {0, 1, 2, 7, 8, 9, 31, 32, 33, 63, 64, 127, 128, 255}) {
+    std::vector<uint32_t> mask(8, 0);
+    mask[bit / 32] = 1u << (bit % 32);
+    hipStream_t st;
+    if (hipExtStreamCreateWithCUMask(&st, 8, mask.data()) != hipSuccess) { printf("bit %d: create failed\n", bit); continue; }
+    CK(hipMemset(dout, 0xff, 64));
+    hipLaunchKernelGGL(where_kernel, dim3(4), dim3(64), 0, st, dout);
+    CK(hipStreamSynchronize(st));
+    unsigned h[8];
+    CK(hipMemcpy(h, dout, 32, hipMemcpyDeviceToHost));
+    printf("bit %3d -> xcc %u hwid 0x%08x (cu %u sh %u se %u) | blk1 xcc %u hwid 0x%08x\n", bit, h[0], h[1], (h[1] >> 8) & 15, (h[1] >> 12) & 1,
+           (h[1] >> 13) & 7, h[2], h[3]);
+    CK(hipStreamDestroy(st));
+  }
+  // complementary masks: 32 spinners (one per CU: 64 KB LDS each would be better; here 1024 threads) on the low 32 bits, workers on the rest
+  std::vector<uint32_t> ma(8, 0), mb(8, 0xffffffffu);
+  ma[0] = 0xffffffffu;
+  mb[0] = 0;
+  hipStream_t sa, sb;
+  CK(hipExtStreamCreateWithCUMask(&sa, 8, ma.data()));
+  CK(hipExtStreamCreateWithCUMask(&sb, 8, mb.data()));
+  unsigned *flag, *res, *cnt;
+  CK(hipMalloc(&flag, 4)); CK(hipMalloc(&res, 4)); CK(hipMalloc(&cnt, 4));
+  CK(hipMemset(flag, 0, 4)); CK(hipMemset(res, 0, 4)); CK(hipMemset(cnt, 0, 4));
+  hipLaunchKernelGGL(spinner, dim3(32), dim3(1024), 0, sa, flag, res);
+  hipLaunchKernelGGL(worker, dim3(100000), dim3(256), 0, sb, cnt);
+  hipLaunchKernelGGL(release, dim3(1), dim3(1), 0, sb, flag);
+  CK(hipStreamSynchronize(sb));
+  CK(hipStreamSynchronize(sa));
+  unsigned hr, hc;
+  CK(hipMemcpy(&hr, res, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hc, cnt, 4, hipMemcpyDeviceToHost));
+  printf("complementary masks: %u spinners were resident while %u worker blocks ran and released them: OK\n", hr, hc);
+  // low 8k bits = k CUs in every XCC?  (bit i -> XCC i % 8, the driver's symmetric map); complement = the other 32 - k
+  for (int k : {1, 2, 4, 8}) {
+    for (int comp = 0; comp < 2; comp++) {
+      std::vector<uint32_t> m(8, comp ? 0xffffffffu : 0u);
+      for (int i = 0; i < 8 * k; i++) {
+        if (comp) m[i / 32] &= ~(1u << (i % 32)); else m[i / 32] |= 1u << (i % 32);
+      }
+      hipStream_t st;
+      CK(hipExtStreamCreateWithCUMask(&st, 8, m.data()));
+      CK(hipMemset(dout, 0xff, 4096 * 8));
+      hipLaunchKernelGGL(where_kernel, dim3(4096), dim3(64), 0, st, dout);
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned> h(8192);
+      CK(hipMemcpy(h.data(), dout, 8192 * 4, hipMemcpyDeviceToHost));
+      int used[8][8][16] = {};
+      for (int i = 0; i < 4096; i++) used[h[2 * i] & 7][(h[2 * i + 1] >> 13) & 7][(h[2 * i + 1] >> 8) & 15]++;
+      printf("k=%d %s: distinct CUs per XCC:", k, comp ? "complement" : "low bits ");
+      for (int x = 0; x < 8; x++) {
+        int c = 0;
+        for (int se = 0; se < 8; se++) for (int cu = 0; cu < 16; cu++) c += used[x][se][cu] > 0;
+        printf(" %d", c);
+      }
+      printf("\n");
+      CK(hipStreamDestroy(st));
+    }
+  }
+  return 0;
+}
