@@ -75,6 +75,7 @@ SIGNATURES = {
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
     "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
     "bgp_mfma_f64_layout": (C.c_int, [C.c_int, _ip, _ip]),
@@ -362,6 +363,15 @@ class Context:
         _check(self._lib.bgp_sample_y_batch(self._h, B, _p(pidx), _p(H), m, _p(Xq), _p(z), float(jitter), _p(out),
                                             _p(st)), "bgp_sample_y_batch")
         return out, st
+
+    def debug_workspace(self, b):
+        """(L, z) of batch slot b as the last ``lml`` call left them: the (npad, npad) working matrix (factor in its lower
+        triangle) and the working right-hand side."""
+        npad = -(-self.n // 128) * 128
+        L = np.empty((npad, npad))
+        z = np.empty(npad)
+        _check(self._lib.bgp_debug_workspace(self._h, int(b), _p(L), _p(z)), "bgp_debug_workspace")
+        return L, z
 
     def set_streams(self, nstreams):
         _check(self._lib.bgp_set_streams(self._h, int(nstreams)), "bgp_set_streams")

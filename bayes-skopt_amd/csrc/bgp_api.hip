@@ -142,7 +142,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_TIMEOUT_MS", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_AFFINITY", "BGP_PS_GATE", "BGP_PS_K", "BGP_PS_NST", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -288,6 +288,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->ps_eva) (void)hipEventDestroy(c->ps_eva);
   if (c->ps_evb) (void)hipEventDestroy(c->ps_evb);
   free_dev(c->ps_flags);
+  free_dev(c->ps_trace);
   if (c->ps_herr) (void)hipHostFree(c->ps_herr);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
     if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
@@ -630,6 +631,21 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
   BGP_HIP(hipMemcpy2DAsync(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),
                            (size_t)c->n * sizeof(double), c->n, hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
+  return BGP_OK;
+}
+
+// Debugging aid: the working matrix (npad x npad, row-major: the factor L in its lower triangle after an LML call) and
+// the working right-hand side (z = L^-1 y) of batch slot b, as the last bgp_lml_batch call left them.
+extern "C" int bgp_debug_workspace(bgp_ctx* c, int b, double* Lout, double* zout) {
+  BGP_REQUIRE_IDLE(c, "bgp_debug_workspace");
+  if (!c || b < 0 || b >= c->max_batch) {
+    bgp_set_error("bgp_debug_workspace: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  const size_t np = c->npad;
+  if (Lout) BGP_HIP(hipMemcpy(Lout, c->dK + (size_t)b * np * np, np * np * sizeof(double), hipMemcpyDeviceToHost));
+  if (zout) BGP_HIP(hipMemcpy(zout, c->dyw + (size_t)b * np, np * sizeof(double), hipMemcpyDeviceToHost));
   return BGP_OK;
 }
 

@@ -528,6 +528,9 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       accb[b * 4 + 1] = zzt;
     }
     if (k == nblk - 1) {
+      // (no implicit fused multiply-add: this function is inlined into two kernels and the backend decides contraction
+      // per call site -- the launch-free and the multi-launch path rounded this line differently, 0.5 ulp of n log 2 pi)
+#pragma clang fp contract(off)
       double v = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
       if (!(v > -INFINITY && v < INFINITY)) {  // overflow somewhere on the way: report like a failed factorisation
         v = -INFINITY;
@@ -560,9 +563,9 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
 // look-ahead was measured slower than the chain it shortens: events cost more than they hide).  Here the diagonal-block
 // chain and the tile work run SIDE BY SIDE and talk through device-scope flags:
 //   * ps_chain_kernel (this file): one 512-thread workgroup per matrix walks the diagonal blocks J = 0 .. nblk-1: waits
-//     until both row halves of block (J, J) have received their left-looking update, factorises it (pf_block: the same
+//     until block (J, J) has received its left-looking update, factorises it (pf_block: the same
 //     code as potrf_kernel), publishes L_JJ / W_JJ / z_J and raises wready[J];
-//   * ps_tile_kernel (bgp_syrk4.hip): 256-thread workgroups draw tasks from one ticket counter, in an order that is
+//   * ps_tile_kernel (bgp_syrk4.hip): 512-thread workgroups (one per CU) draw tasks from one ticket counter, in an order that is
 //     topological for the dependency graph (column by column), and do the left-looking tile work -- update with all
 //     finished panels to the left, then the panel solve against W_JJ -- waiting on / raising xready, diagcnt, wready.
 // The two kernels run on a pair of CU-masked streams (hipExtStreamCreateWithCUMask; on MI355X mask bit i selects a CU of
@@ -580,22 +583,27 @@ __global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
   unsigned* const err = flags + PS_ERROR;
   unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
   const unsigned* const diagcnt = flags + PS_HDR + (size_t)a.B * a.nblk + (size_t)b * a.nblk;
+  unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 4 : nullptr;
   for (int J = 0; J < a.nblk; J++) {
     if (tid == 0) {
       int ok = 1;
-      if (J > 0) {  // both row halves of (J, J) carry every update from the panels to their left
-        ok = ps_wait_ge(diagcnt + J, 2u, err, a.spin_limit) ? 1 : 0;
+      if (tr) tr[J * 4 + 0] = wall_clock64();
+      if (J > 0) {  // block (J, J) carries every update from the panels to its left
+        ok = ps_wait_ge(diagcnt + J, 1u, err, a.spin_limit) ? 1 : 0;
         ps_acquire();
       }
       ps_ok = ok;
+      if (tr) tr[J * 4 + 1] = wall_clock64();
     }
     __syncthreads();
     if (!ps_ok) return;  // (timed out / abandoned: the host redoes the batch)
     const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
                                          a.nblk, J, PfGen());
+    if (tr && tid == 0) tr[J * 4 + 2] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) {
       ps_release();
+      if (tr) tr[J * 4 + 3] = wall_clock64();
       // a failed matrix (status set above) releases every later column at once: its tile tasks see the status and
       // only pass their own flags on
       for (int j = J; j < (failed ? a.nblk : J + 1); j++) ps_st(wready + j, 1u);
@@ -606,13 +614,37 @@ __global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
 
 int bgp_ps_total_tasks(int B, int nblk);
 
+// BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
+// chain (B x nblk x 4: wait begin, wait end, factorised, published) then tile (total x 8: ticket drawn, first operands ready,
+// update done, stored, W ready, solved, published, XCC id << 32 | J << 16 | I << 8 | b... see tools/persist_trace.py).
+extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out, size_t cap) {
+  if (!c || !dims) return BGP_ERR_INVALID;
+  dims[0] = c->ps_trace_B;
+  dims[1] = c->ps_trace_nblk;
+  dims[2] = c->ps_trace_total;
+  const size_t need = (size_t)c->ps_trace_B * c->ps_trace_nblk * 4 + (size_t)c->ps_trace_total * 8;
+  if (!out || !c->ps_trace || need == 0) return BGP_OK;
+  if (cap < need) return BGP_ERR_INVALID;
+  BGP_HIP(hipSetDevice(c->device));
+  BGP_HIP(hipMemcpy(out, c->ps_trace, need * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return BGP_OK;
+}
+
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
 // this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes
 // c->stream wait for both.  The error word travels to pinned memory behind them (ctx->ps_herr): != 0 after the
 // synchronisation means a wait timed out and the caller redoes the batch on the multi-launch path.
 int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int nblk = c->nblk, ld = c->npad;
-  const int k = (B + 7) / 8;
+  int k = (B + 7) / 8;
+  {
+    static int kforce = -1;  // BGP_PS_K: chain CUs per XCD (experiments)
+    if (kforce < 0) {
+      const char* e = getenv("BGP_PS_K");
+      kforce = e ? atoi(e) : 0;
+    }
+    if (kforce > k && kforce <= 8) k = kforce;
+  }
   if (B < 1 || k > 8 || nblk < 2) {
     bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
     return BGP_ERR_INVALID;
@@ -649,6 +681,8 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   if (!limit) {
     const char* e = getenv("BGP_PS_TIMEOUT_MS");
     limit = 100000ull * (unsigned long long)((e && atoi(e) > 0) ? atoi(e) : 3000);  // 100 MHz wall clock
+    const char* et = getenv("BGP_PS_TIMEOUT_TICKS");  // (tests: a bound no wait can meet)
+    if (et && atoll(et) > 0) limit = (unsigned long long)atoll(et);
   }
   PsArgs a;
   a.K = c->dK;
@@ -666,14 +700,55 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.mstride = (size_t)ld * ld;
   a.total = bgp_ps_total_tasks(B, nblk);
   a.spin_limit = limit;
+  a.trace = nullptr;
+  {
+    static int aff = -1;
+    if (aff < 0) {
+      const char* e = getenv("BGP_PS_AFFINITY");
+      aff = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    a.affinity = aff;
+    static int gate = -1;
+    if (gate < 0) {
+      const char* e = getenv("BGP_PS_GATE");
+      gate = e ? atoi(e) : 0;
+    }
+    a.gate = gate;
+  }
+  {
+    static int want = -1;
+    if (want < 0) {
+      const char* e = getenv("BGP_PS_TRACE");
+      want = (e && atoi(e) != 0) ? 1 : 0;
+    }
+    if (want) {
+      const size_t need = (size_t)B * nblk * 4 + (size_t)a.total * 8;
+      if (need > c->cap_pstrace) {
+        if (c->ps_trace) (void)hipFree(c->ps_trace);
+        c->ps_trace = nullptr;
+        c->cap_pstrace = 0;
+        BGP_HIP(hipMalloc(&c->ps_trace, need * sizeof(unsigned long long)));
+        c->cap_pstrace = need;
+      }
+      BGP_HIP(hipMemsetAsync(c->ps_trace, 0, need * sizeof(unsigned long long), c->stream));
+      a.trace = c->ps_trace;
+      c->ps_trace_B = B;
+      c->ps_trace_nblk = nblk;
+      c->ps_trace_total = a.total;
+    }
+  }
   hipStream_t sa = c->ps_chain[k], sb = c->ps_tile[k];
   BGP_HIP(hipEventRecord(c->ps_ev0, c->stream));
   BGP_HIP(hipStreamWaitEvent(sa, c->ps_ev0, 0));
   BGP_HIP(hipStreamWaitEvent(sb, c->ps_ev0, 0));
   hipLaunchKernelGGL(ps_chain_kernel, dim3(B), dim3(PF_THREADS), 0, sa, a);
   BGP_HIP(hipEventRecord(c->ps_eva, sa));
-  const int grid = std::min(a.total, 3 * 8 * (32 - k));
-  bgp_launch_ps_tile(sb, a, grid);
+  static int nst = 0;
+  if (!nst) {
+    const char* e = getenv("BGP_PS_NST");  // ring depth of the tile workers: 4 (three chunks in flight, one workgroup per CU) or 2
+    nst = (e && atoi(e) == 2) ? 2 : 4;
+  }
+  bgp_launch_ps_tile(sb, a, 8 * (32 - k), nst);
   BGP_HIP(hipEventRecord(c->ps_evb, sb));
   BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_eva, 0));
   BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_evb, 0));

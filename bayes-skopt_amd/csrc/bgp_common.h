@@ -130,6 +130,9 @@ struct bgp_ctx {
   int ps_inflight = 0;          // a persistent call is on the stream (its error word is checked behind the sync)
   int ps_disabled = 0;          // a persistent call timed out: multi-launch path from now on
   int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
+  unsigned long long* ps_trace = nullptr;  // BGP_PS_TRACE=1: device buffer of in-kernel time stamps (bgp_debug_ps_trace)
+  size_t cap_pstrace = 0;
+  int ps_trace_B = 0, ps_trace_nblk = 0, ps_trace_total = 0;
   // timing
   int timing = 0;
   double t_ms[5] = {0, 0, 0, 0, 0};
@@ -182,8 +185,8 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 // Flag block of one persistent factorisation (32-bit words, zeroed by a memset node in front of every call):
 //   [PS_TICKET]  next task of the tile kernel          [PS_ERROR]  != 0: a spin timed out / a rank gave up: everybody leaves
 //   wready[b * nblk + J]          1 when potrf(J) of matrix b has published L_JJ, W_JJ, z_J (or the matrix has failed)
-//   diagcnt[b * nblk + J]         row halves of the diagonal block (J, J) whose left-looking update is complete (0..2)
-//   xready[(b * nblk + I) * nblk + J]   row halves of the panel block X_IJ that are final (0..2), I > J
+//   diagrdy[b * nblk + J]         1 when the left-looking update of the diagonal block (J, J) is complete
+//   xready[(b * nblk + I) * nblk + J]   1 when the panel block X_IJ is final, I > J
 #define PS_TICKET 0
 #define PS_ERROR 1
 #define PS_HDR 16
@@ -199,11 +202,14 @@ struct PsArgs {
   size_t mstride;
   int total;          // tasks of the tile kernel
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
+  int gate;                       // blocks off the critical path stay out of its memory windows (BGP_PS_GATE)
+  int affinity;                   // tile tasks of matrix b on XCD b % 8 (BGP_PS_AFFINITY, experiments)
+  unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 4 per (b, J), tile: 8 per task
 };
 static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (2 + nblk); }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int grid);
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int tile_cus, int nst);
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);

@@ -29,6 +29,7 @@
 #include "bgp_gemm.h"
 #include "bgp_ring.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #define S4_KC 16
@@ -500,24 +501,91 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 
 // ------------------------------------------------------------------------------------------
 // Tile worker of the launch-free factorisation (see ps_chain_kernel, bgp_chol.hip, for the scheme).  Left-looking by
-// tiles: task (b, I, J, h) owns the 64 x 128 row half h of block (I, J) of matrix b and
-//   1. loads it once and applies EVERY finished panel to its left,  C -= X_I,p X_J,p^T  for p = 0 .. J-1, on the ring
-//      (two-stage LDS-DMA pipeline, 64 + 128 operand rows per 16-wide chunk), as far as the panels are final -- it
-//      waits on xready only when it has caught up with the factorisation;
-//   2. I == J: stores the updated diagonal half and raises diagcnt (the chain kernel factorises the block when both
-//      halves are in);  I > J: stores the half, waits for W_JJ (wready), and runs the panel solve X = C W_JJ^T in
-//      place with the fused right-hand-side update y_I -= X z_J (the code of trsm4_kernel), then raises xready.
-// Tasks are drawn from ONE ticket counter in column-major order (per column: every matrix's diagonal halves, then
-// block J+1, J+2, ...), which is a topological order of the dependency graph: the earliest unfinished task always
-// belongs to a running workgroup, so the waits cannot deadlock whatever the number of resident workgroups.
+// blocks: task (b, I, J) owns the 128 x 128 block (I, J) of matrix b, one 512-thread workgroup (8 waves), and
+//   1. loads it once and applies EVERY finished panel to its left,  C -= X_I,p X_J,p^T  for p = 0 .. J-1, on a
+//      FOUR-stage LDS-DMA ring (three 16-wide chunks in flight: a task on the critical path runs alone on its CU, and a
+//      two-stage ring spent an L2 round trip of 2-5 us on every 0.4 us chunk -- tools/persist_trace.py), as far as the
+//      panels are final: it waits on xready only when it has caught up with the factorisation;
+//   2. I == J: stores the updated diagonal block (lower part) and raises diagrdy: the chain kernel factorises it;
+//      I > J: stores the block, waits for W_JJ (wready) and runs the panel solve X = C W_JJ^T in place with the fused
+//      right-hand-side update y_I -= X z_J (the arithmetic of trsm4_kernel), then raises xready.
+// Tasks are drawn from ONE ticket counter.  Order, per block column J and across the matrices of the batch: the panel
+// block (J+1, J) that the next diagonal block waits for, then that diagonal block (J+1, J+1), then the rest of column J
+// -- a topological order of the dependency graph (every task only waits for tasks with smaller tickets and for the
+// chain), so the earliest unfinished task always belongs to a running workgroup: no deadlock whatever the number of
+// resident workgroups; and the diagonal block's workgroup has applied all older panels long before the last one arrives.
 // Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
 // ascending, A-negate): bit-identical factors.
 // ------------------------------------------------------------------------------------------
-static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk) { return B * (nblk - 1) * (nblk + 2); }
+static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk) { return B * ((nblk - 1) * (nblk + 2) / 2); }
 
-__global__ void __launch_bounds__(256, 3) ps_tile_kernel(PsArgs a) {
-  constexpr unsigned AOPB = 64 * S4_ROWB, STAGEB = (64 + 128) * S4_ROWB;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+// vmcnt(N) with a compile-time N
+template <int N>
+static __device__ __forceinline__ void s4_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// eight-wave staging of a 128-row operand chunk: wave w stages rows [16 w, 16 w + 16) = two instructions of 8 rows
+static __device__ __forceinline__ void s8_src(unsigned (&voff)[2], int ld, int w, int lane) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = 16 * w + 8 * i + (lane >> 3);
+    const int g = (lane & 7) ^ ((row >> 1) & 7);
+    voff[i] = (unsigned)(row * ld + g * 2) * 8u;
+  }
+}
+static __device__ __forceinline__ void s8_issue(const double* X, const unsigned (&voff)[2], int k0, unsigned lds_op_base, int w) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) s4_glds(X + k0, voff[i], lds_op_base + (unsigned)((16 * w + 8 * i) * S4_ROWB));
+}
+
+// acc (-)= A B^T over `nch` 16-wide chunks (128 + 128 operand rows per chunk) on an NST-stage ring, eight waves.  Waits
+// are counted: the DMA returns in order, so "at most NST-2 younger chunks outstanding" = vmcnt((NST-2) * 4) (four
+// instructions per chunk and wave); the last chunks wait for fewer.  `skip`: this wave's block lies strictly above the
+// diagonal (it stages and meets the barriers, it does not multiply); `tri`: B is lower triangular (panel solve).
+// SAMEB: B is A (a diagonal block's update): staged once, `pb` points into the A image.
+template <int NST, int NR, int NC, int NEGA, int SAMEB>
+static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsigned (&voffA)[2], const double* XB,
+                                                   const unsigned (&voffB)[2], int nch, unsigned lds0,
+                                                   const unsigned (&pa)[4], const unsigned (&pb)[4], d4 (&acc)[NR][NC],
+                                                   int w, int tri, bool skip) {
+  constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
+  constexpr int NI = SAMEB ? 2 : 4;
+#pragma unroll
+  for (int s = 0; s < NST - 1; s++) {
+    if (s < nch) {
+      s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
+      if (!SAMEB) s8_issue(XB, voffB, s * S4_KC, lds0 + s * STAGEB + AOPB, w);
+    }
+  }
+  for (int c = 0; c < nch; c += NST) {
+#pragma unroll
+    for (int s = 0; s < NST; s++) {
+      if (c + s >= nch) break;            // (wave- and workgroup-uniform)
+      const int rem = nch - (c + s) - 1;  // chunks behind this one
+      if (rem >= NST - 2) {
+        s4_wait_vm<(NST - 2) * NI>();
+      } else if (NST >= 4 && rem == 1) {
+        s4_wait_vm<NI>();
+      } else {
+        s4_wait_vm<0>();
+      }
+      __builtin_amdgcn_s_barrier();  // everybody's share of this chunk has landed; everybody is done with the previous one
+      if (c + s + NST - 1 < nch) {
+        const unsigned nb = lds0 + (unsigned)(((s + NST - 1) % NST) * STAGEB);
+        s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, nb, w);
+        if (!SAMEB) s8_issue(XB, voffB, (c + s + NST - 1) * S4_KC, nb + AOPB, w);
+      }
+      if (!skip) s4_mma<NR, NC, -64, 0, NEGA>(pa, pb, s * STAGEB, acc, tri ? c + s : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+#define PS_NST 4
+__global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
+  constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
+  __shared__ __attribute__((aligned(1024))) char smem[PS_NST * STAGEB];
   __shared__ int sh_t, sh_q;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -525,103 +593,126 @@ __global__ void __launch_bounds__(256, 3) ps_tile_kernel(PsArgs a) {
   const int nblk = a.nblk, B = a.B, ld = a.ld;
   unsigned* const flags = a.flags;
   unsigned* const err = flags + PS_ERROR;
-  unsigned voffA[2], voffB[4], voffW[4];
-  s4_src<64>(voffA, ld, w, lane);
-  s4_src<128>(voffB, ld, w, lane);
-  s4_src<128>(voffW, 128, w, lane);
+  unsigned voffX[2], voffW[2];
+  s8_src(voffX, ld, w, lane);
+  s8_src(voffW, 128, w, lane);
+  // XCD affinity (placement only): matrix b belongs to the ticket list of XCD b % 8 -- where its chain workgroup runs
+  // (block b of the chain kernel is dispatched to XCD b % 8) -- so a matrix's panels, W blocks and flags stay in ONE
+  // XCD's L2 and the hand-offs are same-XCD; a workgroup whose own list is exhausted helps the next lists.
+  const int xcc = a.affinity ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) : (int)((blockIdx.x / 8u + blockIdx.x) & 7u);
+  const int per_matrix = (nblk - 1) * (nblk + 2) / 2;
+  int list = 0;  // lists tried so far (own first)
   for (;;) {
-    if (tid == 0) sh_t = (int)__hip_atomic_fetch_add(flags + PS_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int x = (xcc + list) & 7;
+    const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
+    if (tid == 0) {
+      int tt = -1;
+      if (Bx > 0) {
+        tt = (int)__hip_atomic_fetch_add(flags + PS_TICKET + 2 + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tt >= Bx * per_matrix) tt = -1;
+      }
+      sh_t = tt;
+    }
     __syncthreads();
     int t = sh_t;
-    if (t >= a.total) return;
-    // ---- ticket -> (column J, matrix b, block row I, half h)
+    __syncthreads();
+    if (t < 0) {  // this list is finished: next one, or done
+      if (++list == 8) return;
+      continue;
+    }
+    const int tglobal = (int)(((long long)t * 8 + x) % a.total);  // (trace slot: unique per (list, ticket) while B % 8 == 0)
+    // ---- ticket -> (column J, matrix b, block row I): column J holds nblk - J tasks per matrix
     int J = 0;
     for (;;) {
-      const int c = (J == 0 ? 2 * (nblk - 1) : 2 * (nblk - J)) * B;
+      const int c = (nblk - J) * Bx;
       if (t < c) break;
       t -= c;
       J++;
     }
-    const int q0 = t / B, b = t - q0 * B, h = q0 & 1, I = (J == 0 ? 1 : J) + (q0 >> 1);
-    const bool diag = (I == J);
+    const int q0 = t / Bx, b = x + 8 * (t - q0 * Bx);
+    const int I = (q0 == 0) ? J + 1 : (q0 == 1) ? J + 1 : J + q0;  // (J+1, J), then the diagonal block (J+1, J+1), then J+2 ..
+    const bool diag = (q0 == 1);
+    const bool gate = a.gate && q0 >= 2;
+    const int Jc = diag ? J + 1 : J;  // block column of the task's block
     unsigned* const wready = flags + PS_HDR + (size_t)b * nblk;
-    unsigned* const diagcnt = flags + PS_HDR + (size_t)B * nblk + (size_t)b * nblk;
+    unsigned* const diagrdy = flags + PS_HDR + (size_t)B * nblk + (size_t)b * nblk;
     unsigned* const xrI = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + I) * nblk;
-    unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + J) * nblk;
+    unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + Jc) * nblk;
     const int* const stat = a.status + b;
     double* const M = a.K + (size_t)b * a.mstride;
-    const size_t row0 = (size_t)I * 128 + h * 64;
-    double* const C = M + row0 * ld + J * 128;
+    double* const C = M + (size_t)I * 128 * ld + Jc * 128;
+    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + (size_t)B * nblk * 4 + (size_t)tglobal * 8 : nullptr;
+    if (tr) {
+      tr[0] = wall_clock64();
+      tr[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)Jc << 24) |
+              ((unsigned long long)I << 16) | (unsigned long long)b;
+    }
     if (tid == 0) sh_q = (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
-    if (J > 0 && !dead) {
-      // ---- 1. left-looking update with the panels 0 .. J-1
-      const double* const XA = M + row0 * ld;
-      const double* const XB = M + (size_t)J * 128 * ld;
+    if (Jc > 0 && !dead) {
+      // ---- 1. left-looking update with the panels 0 .. Jc-1: waves as 4 x 2, each 32 rows x 64 columns
+      const double* const XA = M + (size_t)I * 128 * ld;
+      const double* const XB = M + (size_t)Jc * 128 * ld;
+      const bool skip = diag && wc == 1 && wr < 2;  // strictly above the diagonal: never read
       unsigned pa[4], pb[4];
       s4_frag_addr(pa, lds0, wr * 32, lane);
-      s4_frag_addr(pb, lds0 + AOPB, wc * 64, lane);
+      s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
       d4 acc[2][4];
-      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++) asm volatile("" : "+v"(acc[i][j]));
       int q = 0;
-      while (q < J) {
+      while (q < Jc) {
         if (tid == 0) {
+          // (gate: a block off the critical path takes panel p only when the critical path has left it behind --
+          // diagonal block p+1 updated -- so that its operand traffic does not share the memory system with the panel
+          // solve and the diagonal update the chain is waiting for)
           int qq = q;
           bool ok = true;
-          while (qq < J && ps_ld(xrI + qq) >= 2u && (diag || ps_ld(xrJ + qq) >= 2u)) qq++;
+          while (qq < Jc && ps_ld(xrI + qq) >= 1u && (diag || ps_ld(xrJ + qq) >= 1u) && (!gate || ps_ld(diagrdy + qq + 1) >= 1u)) qq++;
           if (qq == q) {  // caught up with the factorisation: wait for the next panel
-            ok = ps_wait_ge(xrI + q, 2u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 2u, err, a.spin_limit));
+            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 1u, err, a.spin_limit)) &&
+                 (!gate || ps_wait_ge(diagrdy + q + 1, 1u, err, a.spin_limit));
             qq = q + 1;
-            while (ok && qq < J && ps_ld(xrI + qq) >= 2u && (diag || ps_ld(xrJ + qq) >= 2u)) qq++;
+            while (ok && qq < Jc && ps_ld(xrI + qq) >= 1u && (diag || ps_ld(xrJ + qq) >= 1u) && (!gate || ps_ld(diagrdy + qq + 1) >= 1u)) qq++;
           }
           ps_acquire();
           sh_q = ok ? qq : -1;
+          if (tr && q == 0) tr[1] = wall_clock64();
+          if (tr && qq == Jc) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
         }
         __syncthreads();
         const int qq = sh_q;
         if (qq < 0) return;  // abandoned
-        const int nch = (qq - q) * 8;
-        const double* const XAq = XA + (size_t)q * 128;
-        const double* const XBq = XB + (size_t)q * 128;
-        s4_issue<64>(XAq, voffA, 0, lds0, w);
-        s4_issue<128>(XBq, voffB, 0, lds0 + AOPB, w);
-        for (int c = 0; c < nch; c += 2) {
-#pragma unroll
-          for (int s2 = 0; s2 < 2; s2++) {
-            S4_WAIT_VM0();
-            __builtin_amdgcn_s_barrier();
-            if (c + s2 + 1 < nch) {
-              const unsigned nb = lds0 + (unsigned)((s2 ^ 1) * STAGEB);
-              s4_issue<64>(XAq, voffA, (c + s2 + 1) * S4_KC, nb, w);
-              s4_issue<128>(XBq, voffB, (c + s2 + 1) * S4_KC, nb + AOPB, w);
-            }
-            s4_mma<2, 4, -64, 0, 1>(pa, pb, s2 * STAGEB, acc);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+        if (diag)
+          s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + (size_t)q * 128, voffX, XA, voffX, (qq - q) * 8, lds0, pa, pb, acc, w, 0, skip);
+        else
+          s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, (qq - q) * 8, lds0, pa, pb, acc, w,
+                                          0, false);
         __syncthreads();  // (the ring and sh_q are free again)
         q = qq;
       }
-      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      if (!skip) gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
     }
+    if (tr) tr[3] = wall_clock64();
     if (diag) {
       ps_publish_barrier();
-      if (tid == 0) ps_signal_add(diagcnt + J);
+      if (tid == 0) ps_signal_add(diagrdy + Jc);
+      if (tr) tr[6] = wall_clock64();
       __syncthreads();
       continue;
     }
-    // ---- 2. panel solve against W_JJ
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this half's updated values have left the wave
+    // ---- 2. panel solve against W_JJ: eight waves stacked along the rows (16 rows x 128 columns each)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
     if (tid == 0) {
-      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit);
+      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit) && (!gate || ps_wait_ge(diagrdy + J + 1, 1u, err, a.spin_limit));
       ps_acquire();
       sh_q = !ok ? -1 : (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : 1);
+      if (tr) tr[4] = wall_clock64();
     }
     __syncthreads();
     if (sh_q < 0) return;
@@ -635,29 +726,19 @@ __global__ void __launch_bounds__(256, 3) ps_tile_kernel(PsArgs a) {
       d4 acc[1][8];
 #pragma unroll
       for (int j = 0; j < 8; j++) acc[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
-      s4_issue<64>(C, voffA, 0, lds0, w);
-      s4_issue<128>(Wm, voffW, 0, lds0 + AOPB, w);
-      for (int c = 0; c < 8; c += 2) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-          S4_WAIT_VM0();
-          __builtin_amdgcn_s_barrier();
-          if (c + s2 + 1 < 8) {
-            const unsigned nb = lds0 + (unsigned)((s2 ^ 1) * STAGEB);
-            s4_issue<64>(C, voffA, (c + s2 + 1) * S4_KC, nb, w);
-            s4_issue_from<128>(Wm, voffW, (c + s2 + 1) * S4_KC, nb + AOPB, w, 16 * (c + s2 + 1));
-          }
-          s4_mma<1, 8, -64, 0, 0>(pa, pb, s2 * STAGEB, acc, c + s2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
-      // one wave per row, fixed shuffle order (as trsm4_kernel)
+      // (W_JJ is lower triangular: chunk c only reaches the column blocks j >= c -- `tri`; its never-written upper
+      // blocks are staged all the same, which keeps the instruction count per chunk fixed for the counted waits)
+      // the right-hand-side operands are fetched under the solve (z_J: this wave's 8 columns; y_I: this lane's rows)
       const double* const zk = a.yw + (size_t)b * a.ystride + J * 128;
-      double zc[8];
+      double zc[8], yv[4];
 #pragma unroll
       for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-      double* const yi = a.yw + (size_t)b * a.ystride + I * 128 + h * 64;
+      double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
+#pragma unroll
+      for (int r = 0; r < 4; r++) yv[r] = yi[GK_ROWB(r0, 0, lane, r)];
+      s8_ring_run<PS_NST, 1, 8, 0, 0>(C, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, false);
+      // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
+      // one wave per row, fixed shuffle order (as trsm4_kernel)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int row = GK_ROWB(r0, 0, lane, r);
@@ -672,17 +753,21 @@ __global__ void __launch_bounds__(256, 3) ps_tile_kernel(PsArgs a) {
         part += __shfl_xor(part, 2);
         part += __shfl_xor(part, 4);
         part += __shfl_xor(part, 8);
-        if ((lane & 15) == 0) yi[row] -= part;
+        if ((lane & 15) == 0) yi[row] = yv[r] - part;
       }
     }
+    if (tr) tr[5] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) ps_signal_add(xrI + J);
+    if (tr) tr[6] = wall_clock64();
     __syncthreads();
   }
 }
 
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int grid) {
-  hipLaunchKernelGGL(ps_tile_kernel, dim3(grid), dim3(256), 0, st, a);
+// one 512-thread workgroup per tile CU
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int tile_cus, int nst) {
+  (void)nst;
+  hipLaunchKernelGGL(ps_tile_kernel, dim3(std::min(a.total, tile_cus)), dim3(512), 0, st, a);
 }
 int bgp_ps_total_tasks(int B, int nblk) { return ps_total_tasks(B, nblk); }
 

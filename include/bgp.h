@@ -231,6 +231,9 @@ int bgp_device_synchronize(int device);
 int bgp_last_timing(bgp_ctx* ctx, double* out_ms, int* counts);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
 int bgp_set_timing(bgp_ctx* ctx, int enable);
+/* Debugging aid: working matrix (npad x npad doubles; L in the lower triangle after an LML call) and working right-hand
+ * side (npad doubles, z = L^-1 y) of batch slot b as the last bgp_lml_batch left them; either pointer may be NULL. */
+int bgp_debug_workspace(bgp_ctx* ctx, int b, double* L, double* z);
 /* fp64 MFMA micro-benchmark: TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on the whole chip. */
 int bgp_bench_mfma_f64(int device, int iters, double* tflops);
 /* HBM copy micro-benchmark: GB/s (read+write) of a streaming double2 copy of `bytes` bytes. */

@@ -1,0 +1,92 @@
+"""Launch-free factorisation of small batches (BGP_PERSIST=1: ps_chain_kernel + ps_tile_kernel on complementary CU-masked
+streams, csrc/bgp_chol.hip / bgp_syrk4.hip): the same arithmetic in the same order as the multi-launch schedule, so the
+log-likelihoods, the failure statuses and a whole MCMC chain must be BIT-identical to it; every in-kernel wait is bounded
+and a timeout falls back to the multi-launch path with the right answer."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import bayes_skopt_amd
+from bayes_skopt_amd import _lib
+out = {}
+for n, d, B in %r:
+    rng = np.random.RandomState(n + B)
+    X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
+    if B > 3:
+        X[5] = X[4]            # coinciding points ...
+    ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
+    H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.1 * rng.randn(B, d + 2)
+    if B > 3:
+        H[2, d + 1] = -np.inf  # ... and no noise on one walker: a singular matrix, factorisation must fail at the same pivot
+    vals = []
+    for rep in range(3):
+        v, st = ctx.lml(H, return_status=True)
+        vals.append([float(x).hex() for x in v])
+    L, z = ctx.debug_workspace(0)
+    out["%%d_%%d_%%d" %% (n, d, B)] = {"lml": vals, "status": st.tolist(), "Lsum": float(np.tril(L).sum()).hex(), "zsum": float(z.sum()).hex()}
+    ctx.close()
+print("RESULT " + json.dumps(out))
+"""
+
+SHAPES = [(300, 3, 8), (1024, 8, 32), (975, 8, 13), (640, 5, 1), (1100, 6, 50), (2048, 16, 9)]
+
+
+def _run(env, shapes=SHAPES):
+    res = subprocess.run([sys.executable, "-c", _CHILD % (ROOT, shapes)], env=dict(os.environ, **env), capture_output=True,
+                         text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
+
+
+def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule():
+    ref, _ = _run({"BGP_PERSIST": "0"})
+    got, err = _run({"BGP_PERSIST": "1"})
+    assert "timed out" not in err, err[-1500:]
+    for k in ref:
+        assert got[k]["lml"] == ref[k]["lml"], k        # every call, every matrix: the same bits
+        assert got[k]["lml"][0] == got[k]["lml"][2], k  # and reproducible
+        assert got[k]["status"] == ref[k]["status"], k
+        assert got[k]["Lsum"] == ref[k]["Lsum"] and got[k]["zsum"] == ref[k]["zsum"], k  # the factor and z themselves
+    st = got["1024_8_32"]["status"]
+    assert st[2] != 0 and all(s == 0 for i, s in enumerate(st) if i != 2)  # the singular walker failed, nobody else
+    assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
+
+
+def test_a_wait_that_times_out_falls_back_with_the_right_answer():
+    """BGP_PS_TIMEOUT_MS bounds every in-kernel wait.  With an absurdly small bound the first waits give up, both
+    kernels drain, the host says so once and redoes the batch on the multi-launch path: same bits, no hang."""
+    shapes = [(1024, 8, 16)]
+    ref, _ = _run({"BGP_PERSIST": "0"}, shapes)
+    # 100 MHz wall clock: a bound far below one potrf (27 us) cannot be met; the limit is given in ms -> use the debug
+    # knob BGP_PS_TIMEOUT_TICKS
+    got, err = _run({"BGP_PERSIST": "1", "BGP_PS_TIMEOUT_TICKS": "200"}, shapes)
+    assert err.count("timed out") == 1, err[-1500:]
+    assert got["1024_8_16"]["lml"] == ref["1024_8_16"]["lml"] and got["1024_8_16"]["status"] == ref["1024_8_16"]["status"]
+
+
+def test_mcmc_chain_is_unchanged_by_the_launch_free_path():
+    code = (
+        "import sys, json; sys.path.insert(0, %r); import numpy as np; import bayes_skopt_amd as bask;"
+        "rng = np.random.RandomState(3); X = rng.uniform(size=(700, 4)); y = np.sin(3 * X.sum(1)) + 0.1 * rng.randn(700);"
+        "gp = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2, 3]), random_state=5, normalize_y=True);"
+        "gp.fit(X, y, n_desired_samples=120, n_burnin=3, n_walkers_per_thread=24, progress=False);"
+        "print('RESULT ' + json.dumps([float(v).hex() for v in gp.chain_.ravel()] + [float(gp.log_marginal_likelihood_value_).hex()]))"
+    ) % ROOT
+    outs = []
+    for env in ({"BGP_PERSIST": "0"}, {"BGP_PERSIST": "1"}):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "timed out" not in res.stderr, res.stderr[-2000:]
+        outs.append([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1])
+    assert outs[0] == outs[1]
