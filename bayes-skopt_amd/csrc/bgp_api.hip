@@ -1,6 +1,7 @@
 // C-ABI entry points of libbgp.so (see include/bgp.h for the contract and the reference seams).
 #include "bgp_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 static thread_local std::string g_err;
@@ -15,6 +16,86 @@ void bgp_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* bgp_last_error(void) { return g_err.c_str(); }
+
+BgpXfer& bgp_xfer() {
+  static thread_local BgpXfer x;
+  return x;
+}
+
+void bgp_xfer_drop_pending() { bgp_xfer().pending.clear(); }
+
+char* BgpXfer::take(size_t bytes) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  for (Block& b : blocks)
+    if (b.cap - b.off >= bytes) {
+      char* p = b.p + b.off;
+      b.off += bytes;
+      return p;
+    }
+  Block nb;
+  nb.cap = std::max(bytes, (size_t)4 << 20);
+  nb.off = bytes;
+  nb.p = nullptr;
+  if (hipHostMalloc((void**)&nb.p, nb.cap, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  blocks.push_back(nb);
+  return nb.p;
+}
+
+void BgpXfer::release(hipStream_t st) {
+  size_t keep = 0;
+  for (size_t i = 0; i < pending.size(); i++) {
+    const Pending& q = pending[i];
+    if (q.st != st) {
+      pending[keep++] = q;
+      continue;
+    }
+    for (size_t r = 0; r < q.height; r++) memcpy(q.host + r * q.hpitch, q.stage + r * q.width, q.width);
+  }
+  pending.resize(keep);
+  busy.erase(std::remove(busy.begin(), busy.end(), st), busy.end());
+  if (pending.empty() && busy.empty()) {  // nothing staged is in flight any more: the arena starts over
+    if (blocks.size() > 1) {              // (several blocks: one of the total size next time)
+      size_t total = 0;
+      for (Block& b : blocks) {
+        total += b.cap;
+        (void)hipHostFree(b.p);
+      }
+      blocks.clear();
+      Block nb;
+      nb.cap = total;
+      nb.off = 0;
+      nb.p = nullptr;
+      if (hipHostMalloc((void**)&nb.p, nb.cap, hipHostMallocDefault) == hipSuccess) blocks.push_back(nb);
+      else (void)hipGetLastError();
+    }
+    for (Block& b : blocks) b.off = 0;
+  }
+}
+
+hipError_t bgp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                              hipMemcpyKind kind, hipStream_t st) {
+  if (width == 0 || height == 0) return hipSuccess;
+  BgpXfer& x = bgp_xfer();
+  if (kind == hipMemcpyHostToDevice) {
+    char* stage = x.take(width * height);
+    if (!stage) return hipErrorOutOfMemory;
+    for (size_t r = 0; r < height; r++) memcpy(stage + r * width, (const char*)src + r * spitch, width);
+    if (std::find(x.busy.begin(), x.busy.end(), st) == x.busy.end()) x.busy.push_back(st);
+    if (height == 1 || dpitch == width) return hipMemcpyAsync(dst, stage, width * height, hipMemcpyHostToDevice, st);
+    return hipMemcpy2DAsync(dst, dpitch, stage, width, width, height, hipMemcpyHostToDevice, st);
+  }
+  if (kind == hipMemcpyDeviceToHost) {
+    char* stage = x.take(width * height);
+    if (!stage) return hipErrorOutOfMemory;
+    x.pending.push_back({st, (char*)dst, dpitch, stage, width, height});
+    if (height == 1 || spitch == width) return hipMemcpyAsync(stage, src, width * height, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync(stage, width, src, spitch, width, height, hipMemcpyDeviceToHost, st);
+  }
+  return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, st);
+}
 
 int bgp_wait_spins() {
   static const int spins = [] {
@@ -102,6 +183,12 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
     bgp_set_error("bgp: n must be > 0 and X, y, alpha_diag non-NULL");
     return BGP_ERR_INVALID;
   }
+  static const bool dbg = getenv("BGP_DEBUG_TIMES") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = now();
   int rc = alloc_data(c, n);
   if (rc) return rc;
   c->n = n;
@@ -109,6 +196,7 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
   c->nblk = c->npad / BGP_NB;
   rc = alloc_work(c);
   if (rc) return rc;
+  const auto t1 = now();
   // Staged through the context's own pinned buffer: copies from pageable memory (numpy arrays, fresh vectors) were
   // measured at 10-20 ms per tell on MI355X for these 80 KB (the runtime locks / unlocks the pages around each copy).
   const size_t nx = (size_t)n * c->d, np_ = c->npad, need = nx + 2 * np_;
@@ -127,7 +215,9 @@ static int upload_data(bgp_ctx* c, int n, const double* X, const double* y, cons
   BGP_HIP(hipMemcpyAsync(c->dX, hx, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(c->dy, hy, np_ * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemcpyAsync(c->dalpha, ha, np_ * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const auto t2 = now();
   BGP_HIP(bgp_stream_sync(c->stream));
+  if (dbg) fprintf(stderr, "upload_data: alloc %.3f ms, stage+enqueue %.3f ms, sync %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
   c->post_B = 0;
   c->has_warp = 0;  // new data: the caller re-installs the warp (bgp_ctx_set_warp)
   c->dXeff = c->dX;
@@ -141,7 +231,7 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
                                 "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_AFFINITY", "BGP_PS_GATE", "BGP_PS_K", "BGP_PS_NST", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
@@ -313,7 +403,7 @@ int bgp_ensure_scratch(bgp_ctx* c, size_t doubles) {
 // Factorise one chunk (<= max_batch) of hyper-parameter vectors already validated by the caller.
 static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
   const size_t p = c->d + 2;
-  BGP_HIP(hipMemcpyAsync(c->dh, h, B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(c->dh, h, B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_HIP(hipMemsetAsync(c->dstatus, 0, B * sizeof(int), c->stream));
   int rc = bgp_launch_kbuild(c, B, full_square, 0, 1);
   if (rc) return rc;
@@ -408,7 +498,12 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       ng = 1;
       gsz = nb;
     }
-    BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    // (the submit path hands over the context's own pinned blocks; a caller's pageable block goes through the arena)
+    const bool own = (h == c->hh);
+    if (own)
+      BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    else
+      BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = BGP_OK;
     const bool fused_small = c->nblk == 1 && !warp && !c->use_small_split;
     const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
@@ -423,8 +518,8 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       if (rc) return rc;
     } else if (warp) {
       // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
-      BGP_HIP(hipMemcpyAsync(c->dwarpB, warp + (size_t)off * 2 * c->d, (size_t)nb * 2 * c->d * sizeof(double),
-                             hipMemcpyHostToDevice, c->stream));
+      BGP_HIP(bgp_memcpy_async(c->dwarpB, warp + (size_t)off * 2 * c->d, (size_t)nb * 2 * c->d * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
       rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
       if (rc) return rc;
       if (fused_gram) {
@@ -478,9 +573,12 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));
       }
     }
-    BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (status) {
-      BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (own) {
+      BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      if (status) BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    } else {
+      BGP_HIP(bgp_memcpy_async(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      if (status) BGP_HIP(bgp_memcpy_async(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
     if (c->timing) (void)hipEventRecord(e1, c->stream);
     if (defer_sync) return BGP_OK;  // (single chunk, timing off: bgp_lml_batch_wait synchronises)
@@ -628,7 +726,7 @@ extern "C" int bgp_kernel_matrix(bgp_ctx* c, const double* h, double* K) {
   BGP_HIP(hipSetDevice(c->device));
   int rc = factor_chunk(c, 1, h, 1);
   if (rc) return rc;
-  BGP_HIP(hipMemcpy2DAsync(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),
+  BGP_HIP(bgp_memcpy2d_async(K, (size_t)c->n * sizeof(double), c->dK, (size_t)c->npad * sizeof(double),
                            (size_t)c->n * sizeof(double), c->n, hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;

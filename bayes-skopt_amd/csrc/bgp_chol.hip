@@ -636,7 +636,11 @@ extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out
 // synchronisation means a wait timed out and the caller redoes the batch on the multi-launch path.
 int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int nblk = c->nblk, ld = c->npad;
+  // chain CUs per XCD: ceil(B / 8), but only 1, 2, 3, 4 or 8 -- with 5, 6 or 7 masked CUs per XCD (unequal counts per
+  // shader engine) the dispatcher does not place one 157 KB workgroup on every masked CU (tools/cumask_probe.hip: 6-15
+  // of 40-56 resident together), and a chain workgroup that is not resident stalls its matrix until another one ends
   int k = (B + 7) / 8;
+  if (k > 4) k = 8;
   {
     static int kforce = -1;  // BGP_PS_K: chain CUs per XCD (experiments)
     if (kforce < 0) {

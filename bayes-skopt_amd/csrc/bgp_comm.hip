@@ -255,9 +255,9 @@ extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count,
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count * c->world);
   if (rc) return rc;
-  BGP_HIP(hipMemcpyAsync(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, count, ncclFloat64, c->comm, c->stream));
-  BGP_HIP(hipMemcpyAsync(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
@@ -271,9 +271,9 @@ extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) 
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count);
   if (rc) return rc;
-  BGP_HIP(hipMemcpyAsync(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllReduce(c->dsend, c->drecv, count, ncclFloat64, ncclMax, c->comm, c->stream));
-  BGP_HIP(hipMemcpyAsync(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
@@ -287,9 +287,9 @@ extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int ro
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count);
   if (rc) return rc;
-  BGP_HIP(hipMemcpyAsync(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.Broadcast(c->dsend, c->drecv, count, ncclFloat64, root, c->comm, c->stream));
-  BGP_HIP(hipMemcpyAsync(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }

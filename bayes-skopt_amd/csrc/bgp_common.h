@@ -21,6 +21,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 void bgp_set_error(const char* fmt, ...);
+void bgp_xfer_drop_pending();
 
 #define BGP_HIP(call)                                                                        \
   do {                                                                                       \
@@ -28,9 +29,44 @@ void bgp_set_error(const char* fmt, ...);
     if (e__ != hipSuccess) {                                                                 \
       bgp_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
       (void)hipGetLastError(); /* clear the sticky error so that later calls are not blamed */  \
+      bgp_xfer_drop_pending(); /* no download of this call may be unpacked into the caller's buffers later */ \
       return BGP_ERR_HIP;                                                                    \
     }                                                                                        \
   } while (0)
+
+// ---- host <-> device transfers through pinned staging, and the active wait ----
+// Every copy between a CALLER's buffer (pageable: numpy arrays) and the device goes through the library's own pinned
+// arena.  An asynchronous copy straight from / to pageable memory makes the runtime lock and unlock the pages around it,
+// and the unlocking was measured to trail the call: after a config-E PVRS tell (640 KB of candidates up, Thompson draws
+// down) the device stayed "busy" for another 27 ms in five of six processes, which the NEXT tell's first synchronisation
+// then paid (41 -> 70 ms per tell; tools/tell_phase_probe.py).  bgp_memcpy_async / bgp_memcpy2d_async take the
+// arguments of their HIP namesakes: host -> device packs the rows into the arena and copies from there; device -> host
+// lands in the arena and is unpacked into the caller's buffer by bgp_stream_sync of that stream (every entry point
+// synchronises before it returns).  Device -> device passes through.
+struct BgpXfer {
+  struct Block {
+    char* p;
+    size_t cap, off;
+  };
+  struct Pending {
+    hipStream_t st;
+    char* host;
+    size_t hpitch;
+    const char* stage;
+    size_t width, height;
+  };
+  std::vector<Block> blocks;
+  std::vector<Pending> pending;
+  std::vector<hipStream_t> busy;  // streams with staged host -> device data not yet known to have been consumed
+  char* take(size_t bytes);
+  void release(hipStream_t st);   // the stream has been synchronised: unpack its downloads, forget its uploads
+};
+BgpXfer& bgp_xfer();
+hipError_t bgp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                              hipMemcpyKind kind, hipStream_t st);
+static inline hipError_t bgp_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  return bgp_memcpy2d_async(dst, bytes, src, bytes, bytes, 1, kind, st);
+}
 
 // Wait for a stream the way the sampler's inner loop needs it: ACTIVELY.  hipStreamSynchronize's default wait parks
 // the thread, and for the 0.5-1 ms device calls of the small-batch regime (config E: 26 calls of 50 proposals at
@@ -40,17 +76,20 @@ void bgp_set_error(const char* fmt, ...);
 // runtime's wait from the start (A/B measurements, oversubscribed hosts).
 int bgp_wait_spins();
 static inline hipError_t bgp_stream_sync(hipStream_t st) {
+  hipError_t e = hipErrorNotReady;
   if (bgp_wait_spins()) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0;; it++) {
-      const hipError_t e = hipStreamQuery(st);
-      if (e != hipErrorNotReady) return e;
+      e = hipStreamQuery(st);
+      if (e != hipErrorNotReady) break;
       (void)hipGetLastError();  // (hipErrorNotReady is recorded as the thread's last error)
       if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
       __builtin_ia32_pause();
     }
   }
-  return hipStreamSynchronize(st);
+  if (e == hipErrorNotReady) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) bgp_xfer().release(st);
+  return e;
 }
 
 struct bgp_ctx {

@@ -183,7 +183,7 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
   chunk = std::min(chunk, c->max_batch);
   for (int off = 0; off < B; off += chunk) {
     const int nb = std::min(chunk, B - off);
-    BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     // zero the bottom halves ([I | 0] rows), then K into the top-left, identity, rhs
     for (int b = 0; b < nb; b++)
@@ -197,15 +197,15 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
     hipLaunchKernelGGL(extract_kinv_kernel, dim3(256, nb), dim3(256), 0, c->stream, c->dK, c->dyw, c->dKinv,
                        c->dalpha_sol, npad, off);
     BGP_HIP(hipGetLastError());
-    if (lml) BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (status) BGP_HIP(hipMemcpyAsync(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (lml) BGP_HIP(bgp_memcpy_async(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (status) BGP_HIP(bgp_memcpy_async(status + off, c->dstatus, nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (alpha)
-      BGP_HIP(hipMemcpy2DAsync(alpha + (size_t)off * n, (size_t)n * sizeof(double),
+      BGP_HIP(bgp_memcpy2d_async(alpha + (size_t)off * n, (size_t)n * sizeof(double),
                                c->dalpha_sol + (size_t)off * npad, (size_t)npad * sizeof(double),
                                (size_t)n * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     if (K_inv)
       for (int b = 0; b < nb; b++)
-        BGP_HIP(hipMemcpy2DAsync(K_inv + (size_t)(off + b) * n * n, (size_t)n * sizeof(double),
+        BGP_HIP(bgp_memcpy2d_async(K_inv + (size_t)(off + b) * n * n, (size_t)n * sizeof(double),
                                  c->dKinv + (size_t)(off + b) * npad * npad, (size_t)npad * sizeof(double),
                                  (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, c->stream));
     if (L) {
@@ -214,7 +214,7 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
       for (int b = 0; b < nb; b++) {
         hipLaunchKernelGGL(extract_L_kernel, dim3(512), dim3(256), 0, c->stream, c->dK, c->dscratch, n, (int)ld,
                            ld * ld, b);
-        BGP_HIP(hipMemcpyAsync(L + (size_t)(off + b) * n * n, c->dscratch, (size_t)n * n * sizeof(double),
+        BGP_HIP(bgp_memcpy_async(L + (size_t)(off + b) * n * n, c->dscratch, (size_t)n * n * sizeof(double),
                                hipMemcpyDeviceToHost, c->stream));
         BGP_HIP(bgp_stream_sync(c->stream));
       }
@@ -311,8 +311,8 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
     dCov = s.take((size_t)chunk * mpad * mpad);
   }
   const size_t sKs = (size_t)mpad * npad, sCv = (size_t)mpad * mpad;
-  BGP_HIP(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (c->has_warp) {  // BayesGPR.predict warps the query points with the current warpers (bask/bayesgpr.py:630-632)
     rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0);
     if (rc) return rc;
@@ -329,7 +329,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
     hipLaunchKernelGGL(rowdot_reduce_kernel, dim3((mpad + 255) / 256, nb), dim3(256), 0, c->stream, dmpart, npad / 128, mpad,
                        dout);
     if (mean)
-      BGP_HIP(hipMemcpy2DAsync(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
+      BGP_HIP(bgp_memcpy2d_async(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
                                (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     // q_i = k_i^T K^-1 k_i  (= rowsum((K_* K^-1) o K_*), evaluated on the lower block triangle of K^-1)
     rc = launch_rowquad(c, dKs, npad, sKs, Kinv, npad, (size_t)npad * npad, nullptr, mpad, npad, nb, dq);
@@ -344,7 +344,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
                          dHc, d);
       bgp_launch_gemm4(c->stream, 2, dP, dKs, npad, mpad, mpad, npad, dCov, mpad, nb, sKs, sKs, sCv, nullptr);
       for (int b = 0; b < nb; b++)
-        BGP_HIP(hipMemcpy2DAsync(cov + (size_t)(off + b) * m * m, (size_t)m * sizeof(double), dCov + (size_t)b * sCv,
+        BGP_HIP(bgp_memcpy2d_async(cov + (size_t)(off + b) * m * m, (size_t)m * sizeof(double), dCov + (size_t)b * sCv,
                                  (size_t)mpad * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost,
                                  c->stream));
     }
@@ -352,7 +352,7 @@ static int predict_run(bgp_ctx* c, int B, const double* h_kernel, int m, const d
                        c->ks.form, m, dq, (size_t)mpad);  // in place
     BGP_HIP(hipGetLastError());
     if (var)
-      BGP_HIP(hipMemcpy2DAsync(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
+      BGP_HIP(bgp_memcpy2d_async(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
                                (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
     // (the next chunk reuses the scratch slices: stream order keeps its launches behind these copies)
   }
@@ -471,8 +471,8 @@ static int acq_run(bgp_ctx* c, hipStream_t st, int B, int m, int mpad, const dou
   int* dkinds = dbad + (size_t)ap.n_acq * B;
   (void)c;
   double* dparams = dmumin + B;  // (mumin slice was taken with B + slack below)
-  BGP_HIP(hipMemcpyAsync(dkinds, ap.kinds, (size_t)ap.n_acq * sizeof(int), hipMemcpyHostToDevice, st));
-  BGP_HIP(hipMemcpyAsync(dparams, ap.params, (size_t)ap.n_acq * sizeof(double), hipMemcpyHostToDevice, st));
+  BGP_HIP(bgp_memcpy_async(dkinds, ap.kinds, (size_t)ap.n_acq * sizeof(int), hipMemcpyHostToDevice, st));
+  BGP_HIP(bgp_memcpy_async(dparams, ap.params, (size_t)ap.n_acq * sizeof(double), hipMemcpyHostToDevice, st));
   BGP_HIP(hipMemsetAsync(dbad, 0, (size_t)ap.n_acq * B * sizeof(int), st));
   hipLaunchKernelGGL(acq_mumin_kernel, dim3(B), dim3(256), 0, st, dmean, (size_t)mpad, m, ap.y_mean, ap.y_std, dmumin);
   hipLaunchKernelGGL(acq_values_kernel, dim3((m + 255) / 256, B), dim3(256), 0, st, dmean, dvar, (size_t)mpad, m, B,
@@ -480,7 +480,7 @@ static int acq_run(bgp_ctx* c, hipStream_t st, int B, int m, int mpad, const dou
   hipLaunchKernelGGL(acq_sum_kernel, dim3((m + 255) / 256, ap.n_acq), dim3(256), 0, st, dT, dbad, (size_t)mpad, m, B,
                      ap.n_samples, dacc);
   BGP_HIP(hipGetLastError());
-  BGP_HIP(hipMemcpy2DAsync(ap.out, (size_t)m * sizeof(double), dacc, (size_t)mpad * sizeof(double),
+  BGP_HIP(bgp_memcpy2d_async(ap.out, (size_t)m * sizeof(double), dacc, (size_t)mpad * sizeof(double),
                            (size_t)m * sizeof(double), ap.n_acq, hipMemcpyDeviceToHost, st));
   return BGP_OK;
 }
@@ -535,9 +535,9 @@ extern "C" int bgp_acq_values(bgp_ctx* c, int B, int m, const double* mu, const 
   double* dacc = s.take((size_t)n_acq * mpad);
   double* dmumin = s.take((size_t)B + BGP_ACQ_MAX);
   int* dbad = reinterpret_cast<int*>(s.take((size_t)n_acq * B / 2 + BGP_ACQ_MAX));
-  BGP_HIP(hipMemcpy2DAsync(dmu, (size_t)mpad * sizeof(double), mu, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
+  BGP_HIP(bgp_memcpy2d_async(dmu, (size_t)mpad * sizeof(double), mu, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
                            B, hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpy2DAsync(dvar, (size_t)mpad * sizeof(double), std_, (size_t)m * sizeof(double),
+  BGP_HIP(bgp_memcpy2d_async(dvar, (size_t)mpad * sizeof(double), std_, (size_t)m * sizeof(double),
                            (size_t)m * sizeof(double), B, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(acq_square_kernel, dim3((m + 255) / 256, B), dim3(256), 0, c->stream, dvar, (size_t)mpad, m);
   AcqPlan ap;
@@ -734,14 +734,14 @@ extern "C" int bgp_lml_grad_batch(bgp_ctx* c, int B, const double* h, double* lm
   double* dH = c->dscratch + (size_t)B * p;
   double* dgpart = c->dscratch + (size_t)B * p * 2;
   BGP_HIP(hipMemsetAsync(dgpart, 0, (size_t)B * p * ntiles * sizeof(double), c->stream));
-  BGP_HIP(hipMemcpyAsync(dH, h, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dH, h, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(lml_grad_kernel, dim3(8 * ((B + 7) / 8) * ntiles), dim3(256), 0, c->stream, c->dXeff, dH, c->dKinv,
                      c->dalpha_sol, dgpart, c->n, c->d, c->npad, c->nblk, c->ks.form, c->ks.stationary, B);
   BGP_HIP(hipGetLastError());
   hipLaunchKernelGGL(grad_reduce_kernel, dim3(B), dim3(((int)p + 63) / 64 * 64), 0, c->stream, dgpart, dgrad, ntiles,
                      (int)p);
   BGP_HIP(hipGetLastError());
-  BGP_HIP(hipMemcpyAsync(grad, dgrad, (size_t)B * p * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(grad, dgrad, (size_t)B * p * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   for (int b = 0; b < B; b++) {
     if (st[b] != 0)
@@ -800,9 +800,9 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   double* dcov = s.take(mpad);
   double* dst = s.take(Tpad);
   const double* Kinv = c->dKinv;
-  BGP_HIP(hipMemcpyAsync(dXc, Xcand, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dXt, Xthompson, (size_t)T * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dXc, Xcand, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dXt, Xthompson, (size_t)T * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
   if (c->has_warp) {  // candidates and Thompson points are compared in the warped space (bask/acquisition.py:324-327)
     rc = bgp_launch_warp(c, c->stream, dXc, c->dwarp, dXc, m, 1, 0);
     if (rc) return rc;
@@ -827,7 +827,7 @@ extern "C" int bgp_pvrs(bgp_ctx* c, const double* h_kernel, int m, const double*
   hipLaunchKernelGGL(pvrs_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, dG, Tpad, dKti, Tpad, du,
                      dst, kernel_diag_value(c, h_kernel), m, T, dcov);
   BGP_HIP(hipGetLastError());
-  BGP_HIP(hipMemcpyAsync(covs, dcov, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(covs, dcov, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }
@@ -967,12 +967,12 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     rc = BGP_ERR_HIP;                  \
     break;                             \
   }
-    SY(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    SY(hipMemcpyAsync(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SY(bgp_memcpy_async(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SY(bgp_memcpy_async(dhk, h_kernel, p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     if (c->has_warp && (rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0))) break;
     SY(hipMemsetAsync(dKs, 0, (size_t)mpad * npad * sizeof(double), c->stream));
     SY(hipMemsetAsync(dZ, 0, (size_t)rpad * mpad * sizeof(double), c->stream));
-    SY(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
+    SY(bgp_memcpy2d_async(dZ, (size_t)mpad * sizeof(double), z, (size_t)m * sizeof(double), (size_t)m * sizeof(double),
                         n_draws, hipMemcpyHostToDevice, c->stream));
     if ((rc = bgp_launch_kcross(c, dhk, m, dXq, n, c->dXeff, dKs, npad, 0))) break;
     hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, 1), dim3(256), 0, c->stream, dKs, npad, (size_t)0, al,
@@ -989,7 +989,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
     if ((rc = bgp_launch_cholesky(w, 1, 0))) break;
     int st = 0;
-    SY(hipMemcpyAsync(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SY(bgp_memcpy_async(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SY(bgp_stream_sync(c->stream));
     if (st != 0) {
       bgp_set_error("bgp_sample_y: predictive covariance not positive definite at pivot %d (jitter %.3g)", st, jitter);
@@ -1000,12 +1000,14 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     hipLaunchKernelGGL(tri_matmul_draws_kernel, dim3((m + 3) / 4), dim3(256), 0, c->stream, w->dK, mpad, dZ, mpad, n_draws,
                        dmean, m, dO);
     SY(hipGetLastError());
-    SY(hipMemcpy2DAsync(out, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
+    SY(bgp_memcpy2d_async(out, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
                         (size_t)m * sizeof(double), n_draws, hipMemcpyDeviceToHost, c->stream));
     SY(bgp_stream_sync(c->stream));
 #undef SY
   } while (0);
   (void)hipStreamSynchronize(c->stream);
+  if (rc) bgp_xfer_drop_pending();  // (a failed call unpacks nothing into the caller's buffers later)
+  bgp_xfer().release(c->stream);
   return rc;
 }
 
@@ -1100,9 +1102,9 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
   double* dZ = s.take((size_t)chunk * mpad);
   double* dO = s.take((size_t)chunk * mpad);
   int* dpidx = reinterpret_cast<int*>(s.take(((size_t)B + 1) / 2 + 1));
-  BGP_HIP(hipMemcpyAsync(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dpidx, pidx, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dXq, Xq, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dH, h_kernel, (size_t)B * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dpidx, pidx, (size_t)B * sizeof(int), hipMemcpyHostToDevice, c->stream));
   if (c->has_warp) {
     rc = bgp_launch_warp(c, c->stream, dXq, c->dwarp, dXq, m, 1, 0);
     if (rc) return rc;
@@ -1112,7 +1114,7 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     const double* dHc = dH + (size_t)off * p;
     const int* dpc = dpidx + off;
     BGP_HIP(hipMemsetAsync(dZ, 0, (size_t)nb * mpad * sizeof(double), c->stream));
-    BGP_HIP(hipMemcpy2DAsync(dZ, (size_t)mpad * sizeof(double), z + (size_t)off * m, (size_t)m * sizeof(double),
+    BGP_HIP(bgp_memcpy2d_async(dZ, (size_t)mpad * sizeof(double), z + (size_t)off * m, (size_t)m * sizeof(double),
                              (size_t)m * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));
     rc = bgp_launch_kcross_batch(c, nb, dHc, m, dXq, n, c->dXeff, dKs, npad, sKs);
     if (rc) return rc;
@@ -1133,8 +1135,8 @@ extern "C" int bgp_sample_y_batch(bgp_ctx* c, int B, const int* pidx, const doub
     if (rc) return rc;
     hipLaunchKernelGGL(tri_matvec_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, w->dK, mpad, dZ, dmean, m, dO);
     BGP_HIP(hipGetLastError());
-    BGP_HIP(hipMemcpyAsync(status + off, w->dstatus, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    BGP_HIP(hipMemcpy2DAsync(out + (size_t)off * m, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
+    BGP_HIP(bgp_memcpy_async(status + off, w->dstatus, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(bgp_memcpy2d_async(out + (size_t)off * m, (size_t)m * sizeof(double), dO, (size_t)mpad * sizeof(double),
                              (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
   }
   BGP_HIP(bgp_stream_sync(c->stream));

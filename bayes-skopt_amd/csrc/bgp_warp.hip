@@ -82,7 +82,7 @@ extern "C" int bgp_ctx_set_warp(bgp_ctx* c, const double* warp) {
   const size_t nd = (size_t)c->cap_n * c->d;
   if (!c->dXw1) BGP_HIP(hipMalloc(&c->dXw1, nd * sizeof(double)));
   if (!c->dwarp) BGP_HIP(hipMalloc(&c->dwarp, 2 * (size_t)c->d * sizeof(double)));
-  BGP_HIP(hipMemcpyAsync(c->dwarp, warp, 2 * (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(c->dwarp, warp, 2 * (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
   int rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarp, c->dXw1, c->n, 1, 0);
   if (rc) return rc;
   BGP_HIP(bgp_stream_sync(c->stream));
@@ -105,11 +105,11 @@ extern "C" int bgp_beta_cdf(bgp_ctx* c, int m, const double* X, const double* wa
   double* dXi = c->dscratch;
   double* dXo = c->dscratch + md;
   double* dW = c->dscratch + 2 * md;
-  BGP_HIP(hipMemcpyAsync(dXi, X, md * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  BGP_HIP(hipMemcpyAsync(dW, warp, 2 * (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dXi, X, md * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(dW, warp, 2 * (size_t)c->d * sizeof(double), hipMemcpyHostToDevice, c->stream));
   rc = bgp_launch_warp(c, c->stream, dXi, dW, dXo, m, 1, 0);
   if (rc) return rc;
-  BGP_HIP(hipMemcpyAsync(out, dXo, md * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  BGP_HIP(bgp_memcpy_async(out, dXo, md * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(bgp_stream_sync(c->stream));
   return BGP_OK;
 }

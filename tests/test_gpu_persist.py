@@ -25,11 +25,12 @@ for n, d, B in %r:
     rng = np.random.RandomState(n + B)
     X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
     if B > 3:
-        X[5] = X[4]            # coinciding points ...
+        X[5] = X[4]            # coinciding points (tiny pivots) ...
     ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
     H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.1 * rng.randn(B, d + 2)
     if B > 3:
-        H[2, d + 1] = -np.inf  # ... and no noise on one walker: a singular matrix, factorisation must fail at the same pivot
+        H[1, d + 1] = -np.inf  # ... no noise on one walker, and
+        H[2, 0] = np.nan       # a walker whose matrix is not a number: its factorisation must fail at the first pivot
     vals = []
     for rep in range(3):
         v, st = ctx.lml(H, return_status=True)
@@ -60,7 +61,7 @@ def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule():
         assert got[k]["status"] == ref[k]["status"], k
         assert got[k]["Lsum"] == ref[k]["Lsum"] and got[k]["zsum"] == ref[k]["zsum"], k  # the factor and z themselves
     st = got["1024_8_32"]["status"]
-    assert st[2] != 0 and all(s == 0 for i, s in enumerate(st) if i != 2)  # the singular walker failed, nobody else
+    assert st[2] == 1 and all(s == 0 for i, s in enumerate(st) if i != 2)  # the NaN walker failed (pivot 1), nobody else
     assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
 
 

@@ -25,6 +25,22 @@ __global__ void spinner(volatile unsigned* flag, unsigned* resident) {
     while (__hip_atomic_load((unsigned*)flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < 200000000ull) __builtin_amdgcn_s_sleep(8);
   }
 }
+// co-residency census: every block announces itself, then waits (bounded) until `want` blocks have announced
+__global__ void __launch_bounds__(512) census(unsigned* cnt, unsigned want, unsigned* ok, unsigned* xccs) {
+  extern __shared__ char big[];
+  if (threadIdx.x == 0) {
+    big[0] = 1;
+    xccs[blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;
+    atomicAdd(cnt, 1u);
+    const unsigned long long t0 = wall_clock64();
+    bool all = false;
+    while (wall_clock64() - t0 < 20000000ull) {  // 200 ms
+      if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { all = true; break; }
+      __builtin_amdgcn_s_sleep(16);
+    }
+    if (all) atomicAdd(ok, 1u);
+  }
+}
 __global__ void worker(unsigned* cnt) { if (threadIdx.x == 0) atomicAdd(cnt, 1u); }
 __global__ void release(unsigned* flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -67,6 +83,30 @@ int main() {
   unsigned hr, hc;
   CK(hipMemcpy(&hr, res, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&hc, cnt, 4, hipMemcpyDeviceToHost));
   printf("complementary masks: %u spinners were resident while %u worker blocks ran and released them: OK\n", hr, hc);
+  // can 8k (and 8k - 3) workgroups of 512 threads + 157 KB LDS (the chain kernel's shape) be resident together on the low 8k bits?
+  CK(hipFuncSetAttribute((const void*)census, hipFuncAttributeMaxDynamicSharedMemorySize, 161000));
+  for (int k = 1; k <= 8; k++) {
+    for (int nb : {8 * k, 8 * k - 3}) {
+      std::vector<uint32_t> m(8, 0u);
+      for (int i = 0; i < 8 * k; i++) m[i / 32] |= 1u << (i % 32);
+      hipStream_t st;
+      CK(hipExtStreamCreateWithCUMask(&st, 8, m.data()));
+      unsigned *c2, *ok2, *xc;
+      CK(hipMalloc(&c2, 4)); CK(hipMalloc(&ok2, 4)); CK(hipMalloc(&xc, 4 * 64));
+      CK(hipMemset(c2, 0, 4)); CK(hipMemset(ok2, 0, 4));
+      hipLaunchKernelGGL(census, dim3(nb), dim3(512), 161000, st, c2, (unsigned)nb, ok2, xc);
+      CK(hipStreamSynchronize(st));
+      unsigned hok, hx[64];
+      CK(hipMemcpy(&hok, ok2, 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hx, xc, 4 * nb, hipMemcpyDeviceToHost));
+      int per[8] = {0};
+      for (int i = 0; i < nb; i++) per[hx[i] & 7]++;
+      printf("k=%d: %2d chain-shaped workgroups: %2u saw all of them resident; per XCC:", k, nb, hok);
+      for (int x = 0; x < 8; x++) printf(" %d", per[x]);
+      printf("\n");
+      CK(hipStreamDestroy(st));
+    }
+  }
   // low 8k bits = k CUs in every XCC?  (bit i -> XCC i % 8, the driver's symmetric map); complement = the other 32 - k
   for (int k : {1, 2, 4, 8}) {
     for (int comp = 0; comp < 2; comp++) {
