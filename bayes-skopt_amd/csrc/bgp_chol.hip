@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
       int ok = 1;
       if (tr) tr[J * 4 + 0] = wall_clock64();
       if (J > 0) {  // block (J, J) carries every update from the panels to its left
-        ok = ps_wait_ge(diagcnt + J, 1u, err, a.spin_limit) ? 1 : 0;
+        ok = ps_wait_ge(diagcnt + J, a.fine ? 4u : 1u, err, a.spin_limit) ? 1 : 0;  // (quarters: four arrivals)
         ps_acquire();
       }
       ps_ok = ok;
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
   }
 }
 
-int bgp_ps_total_tasks(int B, int nblk);
+int bgp_ps_total_tasks(int B, int nblk, int fine);
 
 // BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
 // chain (B x nblk x 4: wait begin, wait end, factorised, published) then tile (total x 8: ticket drawn, first operands ready,
@@ -702,7 +702,19 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.B = B;
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
-  a.total = bgp_ps_total_tasks(B, nblk);
+  {
+    // quarter-row tasks for the two blocks the chain waits for: they cut the chain's wait per block column from 35-41 to
+    // 30-33 us, but every task occupies a whole workgroup while it waits for W_JJ -- with many matrices the 8 critical
+    // tasks per matrix and column exhaust the tile workgroups (32 matrices: 256 of 224) and the column slips.  Default:
+    // up to 8 matrices (n = 4096 x 1: 2.03 -> 1.72 ms; 1024 x 32: 0.70 -> 0.86 ms with them).  BGP_PS_FINE = 0 / 1 fixes it.
+    static int fine = -2;
+    if (fine == -2) {
+      const char* e = getenv("BGP_PS_FINE");
+      fine = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }
+    a.fine = fine >= 0 ? fine : (B <= 8 ? 1 : 0);
+  }
+  a.total = bgp_ps_total_tasks(B, nblk, a.fine);
   a.spin_limit = limit;
   a.trace = nullptr;
   {

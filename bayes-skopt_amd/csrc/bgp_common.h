@@ -241,6 +241,7 @@ struct PsArgs {
   size_t mstride;
   int total;          // tasks of the tile kernel
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
+  int fine;                       // the two critical blocks of every column as four 32-row tasks each (BGP_PS_FINE)
   int gate;                       // blocks off the critical path stay out of its memory windows (BGP_PS_GATE)
   int affinity;                   // tile tasks of matrix b on XCD b % 8 (BGP_PS_AFFINITY, experiments)
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 4 per (b, J), tile: 8 per task

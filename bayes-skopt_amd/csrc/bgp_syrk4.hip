@@ -517,7 +517,12 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
 // ascending, A-negate): bit-identical factors.
 // ------------------------------------------------------------------------------------------
-static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk) { return B * ((nblk - 1) * (nblk + 2) / 2); }
+// tasks per matrix: the blocks (I, J), I > J, and the diagonal blocks 1 .. nblk-1; `fine`: the two blocks the chain waits
+// for in every column -- (J+1, J) and (J+1, J+1) -- are cut into four 32-row tasks each (+6 per column)
+static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk, int fine) {
+  return (nblk - 1) * (nblk + 2) / 2 + (fine ? 6 * (nblk - 1) : 0);
+}
+static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk, int fine) { return B * ps_tasks_per_matrix(nblk, fine); }
 
 // vmcnt(N) with a compile-time N
 template <int N>
@@ -539,22 +544,33 @@ static __device__ __forceinline__ void s8_issue(const double* X, const unsigned 
   for (int i = 0; i < 2; i++) s4_glds(X + k0, voff[i], lds_op_base + (unsigned)((16 * w + 8 * i) * S4_ROWB));
 }
 
-// acc (-)= A B^T over `nch` 16-wide chunks (128 + 128 operand rows per chunk) on an NST-stage ring, eight waves.  Waits
-// are counted: the DMA returns in order, so "at most NST-2 younger chunks outstanding" = vmcnt((NST-2) * 4) (four
-// instructions per chunk and wave); the last chunks wait for fewer.  `skip`: this wave's block lies strictly above the
-// diagonal (it stages and meets the barriers, it does not multiply); `tri`: B is lower triangular (panel solve).
-// SAMEB: B is A (a diagonal block's update): staged once, `pb` points into the A image.
+// vmcnt(2 n) / vmcnt(4 n) for a run-time n in 0 .. 2 (the counted waits of the four-stage ring)
+static __device__ __forceinline__ void s4_wait_vm_n2(int n) {
+  if (n >= 2) s4_wait_vm<4>(); else if (n == 1) s4_wait_vm<2>(); else s4_wait_vm<0>();
+}
+static __device__ __forceinline__ void s4_wait_vm_n4(int n) {
+  if (n >= 2) s4_wait_vm<8>(); else if (n == 1) s4_wait_vm<4>(); else s4_wait_vm<0>();
+}
+
+// acc (-)= A B^T over `nch` 16-wide chunks on a four-stage LDS-DMA ring, eight waves.  A: `arows` rows at XA (128, or 32
+// for a quarter-block task: then only the waves whose 16 rows lie inside stage it), B: 128 rows at XB; SAMEB: B is A (a
+// diagonal block's update): staged once, `pb` points into the A image.  Waits are counted: the DMA returns in order, so
+// "at most r younger chunks outstanding" = vmcnt(r ni), ni = THIS wave's instructions per chunk.  `skip`: this wave's
+// block lies strictly above the diagonal, or the wave has no rows in a quarter task (it stages and meets the barriers, it
+// does not multiply); `tri`: B is lower triangular (panel solve).
 template <int NST, int NR, int NC, int NEGA, int SAMEB>
 static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsigned (&voffA)[2], const double* XB,
                                                    const unsigned (&voffB)[2], int nch, unsigned lds0,
                                                    const unsigned (&pa)[4], const unsigned (&pb)[4], d4 (&acc)[NR][NC],
-                                                   int w, int tri, bool skip) {
+                                                   int w, int tri, bool skip, int arows = 128) {
+  static_assert(NST == 4, "the counted waits are written for four stages");
   constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
-  constexpr int NI = SAMEB ? 2 : 4;
+  const bool stageA = 16 * w < arows;
+  const int ni = (SAMEB ? 0 : 2) + (stageA ? 2 : 0);  // (ni == 0: a wave that stages nothing waits for nothing)
 #pragma unroll
   for (int s = 0; s < NST - 1; s++) {
     if (s < nch) {
-      s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
+      if (stageA) s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
       if (!SAMEB) s8_issue(XB, voffB, s * S4_KC, lds0 + s * STAGEB + AOPB, w);
     }
   }
@@ -563,17 +579,15 @@ static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsig
     for (int s = 0; s < NST; s++) {
       if (c + s >= nch) break;            // (wave- and workgroup-uniform)
       const int rem = nch - (c + s) - 1;  // chunks behind this one
-      if (rem >= NST - 2) {
-        s4_wait_vm<(NST - 2) * NI>();
-      } else if (NST >= 4 && rem == 1) {
-        s4_wait_vm<NI>();
-      } else {
-        s4_wait_vm<0>();
-      }
+      const int out = rem < NST - 2 ? rem : NST - 2;
+      if (ni == 4)
+        s4_wait_vm_n4(out);
+      else
+        s4_wait_vm_n2(out);
       __builtin_amdgcn_s_barrier();  // everybody's share of this chunk has landed; everybody is done with the previous one
       if (c + s + NST - 1 < nch) {
         const unsigned nb = lds0 + (unsigned)(((s + NST - 1) % NST) * STAGEB);
-        s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, nb, w);
+        if (stageA) s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, nb, w);
         if (!SAMEB) s8_issue(XB, voffB, (c + s + NST - 1) * S4_KC, nb + AOPB, w);
       }
       if (!skip) s4_mma<NR, NC, -64, 0, NEGA>(pa, pb, s * STAGEB, acc, tri ? c + s : 0);
@@ -590,7 +604,7 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int nblk = a.nblk, B = a.B, ld = a.ld;
+  const int nblk = a.nblk, B = a.B, ld = a.ld, fine = a.fine;
   unsigned* const flags = a.flags;
   unsigned* const err = flags + PS_ERROR;
   unsigned voffX[2], voffW[2];
@@ -600,7 +614,8 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
   // (block b of the chain kernel is dispatched to XCD b % 8) -- so a matrix's panels, W blocks and flags stay in ONE
   // XCD's L2 and the hand-offs are same-XCD; a workgroup whose own list is exhausted helps the next lists.
   const int xcc = a.affinity ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) : (int)((blockIdx.x / 8u + blockIdx.x) & 7u);
-  const int per_matrix = (nblk - 1) * (nblk + 2) / 2;
+  const int per_matrix = ps_tasks_per_matrix(nblk, fine);
+  const int crit = fine ? 8 : 2;  // critical tasks at the head of every column: (J+1, J) and (J+1, J+1), whole or in quarters
   int list = 0;  // lists tried so far (own first)
   for (;;) {
     const int x = (xcc + list) & 7;
@@ -621,23 +636,29 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
       continue;
     }
     const int tglobal = (int)(((long long)t * 8 + x) % a.total);  // (trace slot: unique per (list, ticket) while B % 8 == 0)
-    // ---- ticket -> (column J, matrix b, block row I): column J holds nblk - J tasks per matrix
+    // ---- ticket -> (column J, matrix b, block row I, quarter): column J holds crit + (nblk - J - 2) tasks per matrix
     int J = 0;
     for (;;) {
-      const int c = (nblk - J) * Bx;
+      const int c = (crit + nblk - J - 2) * Bx;
       if (t < c) break;
       t -= c;
       J++;
     }
     const int q0 = t / Bx, b = x + 8 * (t - q0 * Bx);
-    const int I = (q0 == 0) ? J + 1 : (q0 == 1) ? J + 1 : J + q0;  // (J+1, J), then the diagonal block (J+1, J+1), then J+2 ..
-    const bool diag = (q0 == 1);
-    const bool gate = a.gate && q0 >= 2;
+    const bool critical = q0 < crit;
+    const bool diag = critical && q0 >= crit / 2;                 // (J+1, J) first, then the diagonal block (J+1, J+1)
+    const int I = critical ? J + 1 : J + 2 + (q0 - crit);         // ... then the blocks J+2 .. of column J
+    const int quarter = (fine && critical) ? (q0 & 3) : -1;       // 32-row slice of a critical block, or the whole block
+    const int rows0 = quarter < 0 ? 0 : 32 * quarter;
+    const bool gate = a.gate && !critical;
     const int Jc = diag ? J + 1 : J;  // block column of the task's block
     unsigned* const wready = flags + PS_HDR + (size_t)b * nblk;
     unsigned* const diagrdy = flags + PS_HDR + (size_t)B * nblk + (size_t)b * nblk;
     unsigned* const xrI = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + I) * nblk;
     unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + Jc) * nblk;
+    // a block (r, p) is final when its flag has reached 1 -- or 4, when it is a sub-diagonal block cut into quarters
+    const unsigned full = fine ? 4u : 1u;
+#define PS_NEED(r, p) (((r) == (p) + 1) ? full : 1u)
     const int* const stat = a.status + b;
     double* const M = a.K + (size_t)b * a.mstride;
     double* const C = M + (size_t)I * 128 * ld + Jc * 128;
@@ -645,22 +666,34 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
     if (tr) {
       tr[0] = wall_clock64();
       tr[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)Jc << 24) |
-              ((unsigned long long)I << 16) | (unsigned long long)b;
+              ((unsigned long long)I << 16) | ((unsigned long long)(quarter & 7) << 12) | (unsigned long long)b;
     }
     if (tid == 0) sh_q = (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
     if (Jc > 0 && !dead) {
-      // ---- 1. left-looking update with the panels 0 .. Jc-1: waves as 4 x 2, each 32 rows x 64 columns
-      const double* const XA = M + (size_t)I * 128 * ld;
+      // ---- 1. left-looking update with the panels 0 .. Jc-1
+      //   whole block: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles);
+      //   quarter:     waves as 2 x 4, each 16 rows x 32 columns (1 x 2 tiles) of the 32-row slice.
+      const double* const XA = M + ((size_t)I * 128 + rows0) * ld;
       const double* const XB = M + (size_t)Jc * 128 * ld;
-      const bool skip = diag && wc == 1 && wr < 2;  // strictly above the diagonal: never read
+      const int rt = w >> 2, cg = w & 3;
+      // strictly above the diagonal: never read (whole block: the two upper-right waves; quarter q: column groups > q)
+      const bool skip = diag && (quarter < 0 ? (wc == 1 && wr < 2) : (cg > quarter));
       unsigned pa[4], pb[4];
-      s4_frag_addr(pa, lds0, wr * 32, lane);
-      s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
       d4 acc[2][4];
-      if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      d4(&accq)[1][2] = reinterpret_cast<d4(&)[1][2]>(acc);
+      if (quarter < 0) {
+        s4_frag_addr(pa, lds0, wr * 32, lane);
+        s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
+        if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      } else {
+        // diagonal quarter: ONE image of all 128 rows of X_I: the A fragments are its rows rows0 + 16 rt
+        s4_frag_addr(pa, lds0, (diag ? rows0 : 0) + rt * 16, lane);
+        s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, cg * 32, lane);
+        if (!skip) gk_load_c<1, 2, -64>(C, (size_t)ld, accq, rows0 + rt * 16, cg * 32, lane);
+      }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -673,13 +706,17 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
           // solve and the diagonal update the chain is waiting for)
           int qq = q;
           bool ok = true;
-          while (qq < Jc && ps_ld(xrI + qq) >= 1u && (diag || ps_ld(xrJ + qq) >= 1u) && (!gate || ps_ld(diagrdy + qq + 1) >= 1u)) qq++;
+#define PS_READY(p) (ps_ld(xrI + (p)) >= PS_NEED(I, p) && (diag || ps_ld(xrJ + (p)) >= PS_NEED(Jc, p)) && \
+                     (!gate || ps_ld(diagrdy + (p) + 1) >= full))
+          while (qq < Jc && PS_READY(qq)) qq++;
           if (qq == q) {  // caught up with the factorisation: wait for the next panel
-            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 1u, err, a.spin_limit)) &&
-                 (!gate || ps_wait_ge(diagrdy + q + 1, 1u, err, a.spin_limit));
+            ok = ps_wait_ge(xrI + q, PS_NEED(I, q), err, a.spin_limit) &&
+                 (diag || ps_wait_ge(xrJ + q, PS_NEED(Jc, q), err, a.spin_limit)) &&
+                 (!gate || ps_wait_ge(diagrdy + q + 1, full, err, a.spin_limit));
             qq = q + 1;
-            while (ok && qq < Jc && ps_ld(xrI + qq) >= 1u && (diag || ps_ld(xrJ + qq) >= 1u) && (!gate || ps_ld(diagrdy + qq + 1) >= 1u)) qq++;
+            while (ok && qq < Jc && PS_READY(qq)) qq++;
           }
+#undef PS_READY
           ps_acquire();
           sh_q = ok ? qq : -1;
           if (tr && q == 0) tr[1] = wall_clock64();
@@ -688,15 +725,27 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
         __syncthreads();
         const int qq = sh_q;
         if (qq < 0) return;  // abandoned
-        if (diag)
-          s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + (size_t)q * 128, voffX, XA, voffX, (qq - q) * 8, lds0, pa, pb, acc, w, 0, skip);
-        else
-          s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, (qq - q) * 8, lds0, pa, pb, acc, w,
-                                          0, false);
+        const int nch = (qq - q) * 8;
+        const size_t k0 = (size_t)q * 128;
+        if (quarter < 0) {
+          if (diag)
+            s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + k0, voffX, XA, voffX, nch, lds0, pa, pb, acc, w, 0, skip);
+          else
+            s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, acc, w, 0, false);
+        } else if (diag) {  // (XB = the whole row block J+1: the single image)
+          s8_ring_run<PS_NST, 1, 2, 1, 1>(XB + k0, voffX, XB, voffX, nch, lds0, pa, pb, accq, w, 0, skip);
+        } else {
+          s8_ring_run<PS_NST, 1, 2, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, accq, w, 0, false, 32);
+        }
         __syncthreads();  // (the ring and sh_q are free again)
         q = qq;
       }
-      if (!skip) gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      if (!skip) {
+        if (quarter < 0)
+          gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+        else
+          gk_store_c<1, 2, -64>(C, (size_t)ld, accq, rows0 + rt * 16, cg * 32, lane);
+      }
     }
     if (tr) tr[3] = wall_clock64();
     if (diag) {
@@ -706,10 +755,10 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
       __syncthreads();
       continue;
     }
-    // ---- 2. panel solve against W_JJ: eight waves stacked along the rows (16 rows x 128 columns each)
+    // ---- 2. panel solve against W_JJ: waves stacked along the rows, 16 rows x 128 columns each (a quarter: waves 0, 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
     if (tid == 0) {
-      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit) && (!gate || ps_wait_ge(diagrdy + J + 1, 1u, err, a.spin_limit));
+      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit) && (!gate || ps_wait_ge(diagrdy + J + 1, full, err, a.spin_limit));
       ps_acquire();
       sh_q = !ok ? -1 : (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : 1);
       if (tr) tr[4] = wall_clock64();
@@ -719,7 +768,10 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
     dead = dead || sh_q == 0;
     if (!dead) {
       const double* const Wm = a.W + ((size_t)b * nblk + J) * (128 * 128);
-      const int r0 = w * 16;
+      const int arows = quarter < 0 ? 128 : 32;
+      const bool idle = 16 * w >= arows;  // (a quarter task: six waves only help with W's staging)
+      const int r0 = idle ? 0 : w * 16;   // row of this wave inside the task's slice
+      double* const Cs = C + (size_t)rows0 * ld;
       unsigned pa[4], pb[4];
       s4_frag_addr(pa, lds0, r0, lane);
       s4_frag_addr(pb, lds0 + AOPB, 0, lane);
@@ -733,29 +785,32 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
       double zc[8], yv[4];
 #pragma unroll
       for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-      double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
+      double* const yi = a.yw + (size_t)b * a.ystride + I * 128 + rows0;
 #pragma unroll
       for (int r = 0; r < 4; r++) yv[r] = yi[GK_ROWB(r0, 0, lane, r)];
-      s8_ring_run<PS_NST, 1, 8, 0, 0>(C, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, false);
+      s8_ring_run<PS_NST, 1, 8, 0, 0>(Cs, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, idle, arows);
       // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
       // one wave per row, fixed shuffle order (as trsm4_kernel)
+      if (!idle) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = GK_ROWB(r0, 0, lane, r);
-        double part = 0.0;
+        for (int r = 0; r < 4; r++) {
+          const int row = GK_ROWB(r0, 0, lane, r);
+          double part = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const double x = acc[0][j][r];
-          C[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
-          part += x * zc[j];
+          for (int j = 0; j < 8; j++) {
+            const double x = acc[0][j][r];
+            Cs[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
+            part += x * zc[j];
+          }
+          part += __shfl_xor(part, 1);
+          part += __shfl_xor(part, 2);
+          part += __shfl_xor(part, 4);
+          part += __shfl_xor(part, 8);
+          if ((lane & 15) == 0) yi[row] = yv[r] - part;
         }
-        part += __shfl_xor(part, 1);
-        part += __shfl_xor(part, 2);
-        part += __shfl_xor(part, 4);
-        part += __shfl_xor(part, 8);
-        if ((lane & 15) == 0) yi[row] = yv[r] - part;
       }
     }
+#undef PS_NEED
     if (tr) tr[5] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) ps_signal_add(xrI + J);
@@ -769,7 +824,7 @@ void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int tile_cus, int nst) 
   (void)nst;
   hipLaunchKernelGGL(ps_tile_kernel, dim3(std::min(a.total, tile_cus)), dim3(512), 0, st, a);
 }
-int bgp_ps_total_tasks(int B, int nblk) { return ps_total_tasks(B, nblk); }
+int bgp_ps_total_tasks(int B, int nblk, int fine) { return ps_total_tasks(B, nblk, fine); }
 
 // ------------------------------------------------------------------------------------------
 // General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):

@@ -51,9 +51,14 @@ def _run(env, shapes=SHAPES):
     return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
 
 
-def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule():
+@pytest.mark.parametrize("fine", ["auto", "0", "1"])
+def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(fine):
+    """fine = quarter-row tasks for the two critical blocks of every column (automatic: up to 8 matrices)."""
     ref, _ = _run({"BGP_PERSIST": "0"})
-    got, err = _run({"BGP_PERSIST": "1"})
+    env = {"BGP_PERSIST": "1"}
+    if fine != "auto":
+        env["BGP_PS_FINE"] = fine
+    got, err = _run(env)
     assert "timed out" not in err, err[-1500:]
     for k in ref:
         assert got[k]["lml"] == ref[k]["lml"], k        # every call, every matrix: the same bits
