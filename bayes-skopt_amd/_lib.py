@@ -75,6 +75,7 @@ SIGNATURES = {
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
+    "bgp_set_persist": (C.c_int, [_vp, C.c_int]),
     "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
     "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
@@ -375,6 +376,10 @@ class Context:
 
     def set_streams(self, nstreams):
         _check(self._lib.bgp_set_streams(self._h, int(nstreams)), "bgp_set_streams")
+
+    def set_persist(self, mode):
+        """Launch-free factorisation of small batches: 1 on, 0 off, -1 as BGP_PERSIST says (bgp_set_persist)."""
+        _check(self._lib.bgp_set_persist(self._h, int(mode)), "bgp_set_persist")
 
     def set_timing(self, enable):
         _check(self._lib.bgp_set_timing(self._h, int(bool(enable))), "bgp_set_timing")

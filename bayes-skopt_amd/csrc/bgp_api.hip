@@ -771,6 +771,24 @@ extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
   return BGP_OK;
 }
 
+// Launch-free factorisation of small batches: -1 = as the environment says (BGP_PERSIST; unset:
+// off), 0 = never, 1 = whenever the batch fits (at most 64 matrices, at least two block columns).
+extern "C" int bgp_set_persist(bgp_ctx* c, int mode) {
+  if (!c || mode < -1 || mode > 1) {
+    bgp_set_error("bgp_set_persist: mode must be -1, 0 or 1");
+    return BGP_ERR_INVALID;
+  }
+  BGP_REQUIRE_IDLE(c, "bgp_set_persist");
+  if (mode == -1) {
+    const char* envps = getenv("BGP_PERSIST");
+    c->persist = envps ? (atoi(envps) != 0 ? 1 : 0) : -1;
+  } else {
+    c->persist = mode;
+  }
+  if (mode == 1) c->ps_disabled = 0;
+  return BGP_OK;
+}
+
 extern "C" int bgp_set_timing(bgp_ctx* c, int enable) {
   if (!c) return BGP_ERR_INVALID;
   BGP_REQUIRE_IDLE(c, "bgp_set_timing");

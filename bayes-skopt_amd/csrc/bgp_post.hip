@@ -889,6 +889,16 @@ static void free_child(bgp_ctx* w) {
   if (w->dacc) (void)hipFree(w->dacc);
   if (w->dlml) (void)hipFree(w->dlml);
   if (w->dstatus) (void)hipFree(w->dstatus);
+  for (int k = 0; k < 9; k++) {  // (launch-free factorisation of the covariance: its own masked streams, flags, events)
+    if (w->ps_chain[k]) (void)hipStreamDestroy(w->ps_chain[k]);
+    if (w->ps_tile[k]) (void)hipStreamDestroy(w->ps_tile[k]);
+  }
+  if (w->ps_ev0) (void)hipEventDestroy(w->ps_ev0);
+  if (w->ps_eva) (void)hipEventDestroy(w->ps_eva);
+  if (w->ps_evb) (void)hipEventDestroy(w->ps_evb);
+  if (w->ps_flags) (void)hipFree(w->ps_flags);
+  if (w->ps_trace) (void)hipFree(w->ps_trace);
+  if (w->ps_herr) (void)hipHostFree(w->ps_herr);
   delete w;
 }
 
@@ -987,10 +997,24 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     hipLaunchKernelGGL(cov_prepare_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
     SY(hipMemsetAsync(w->dyw, 0, (size_t)mpad * sizeof(double), c->stream));
     SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
-    if ((rc = bgp_launch_cholesky(w, 1, 0))) break;
+    // (BGP_PERSIST=1: the covariance's factorisation -- ONE matrix of 79 block columns at 10 000 candidates, the longest
+    // launch chain of a tell -- on the launch-free path; a timed-out wait is an error here, the matrix is gone)
+    const bool ps = c->persist == 1 && w->nblk >= 2;
+    if (ps) {
+      w->persist = 1;
+      if ((rc = bgp_launch_cholesky_persist(w, 1))) break;
+    } else if ((rc = bgp_launch_cholesky(w, 1, 0))) {
+      break;
+    }
     int st = 0;
     SY(bgp_memcpy_async(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SY(bgp_stream_sync(c->stream));
+    if (ps && w->ps_herr && *w->ps_herr != 0) {
+      *w->ps_herr = 0;
+      bgp_set_error("bgp_sample_y: the launch-free factorisation timed out (BGP_PS_TIMEOUT_MS)");
+      rc = BGP_ERR_STATE;
+      break;
+    }
     if (st != 0) {
       bgp_set_error("bgp_sample_y: predictive covariance not positive definite at pivot %d (jitter %.3g)", st, jitter);
       rc = BGP_ERR_NOTPD;

@@ -330,6 +330,32 @@ def small_batch_shards(bask_lib, X, y, pos_H, device, sizes=(128, 64, 32, 16), r
     return out
 
 
+def launch_free(bask_lib, device, shapes=((4096, 32, 1), (2048, 16, 16), (1024, 8, 32)), reps=15):
+    """The launch-free factorisation of small batches (opt-in) next to the launch schedule on the
+    same contexts: wall ms per LML call and whether the log-likelihoods are the same bits."""
+    out = {}
+    for n, d, B in shapes:
+        X, y = synth(n, d, seed=0)
+        ctx = bask_lib.Context(X, y, 1e-10, max_batch=B, device=device)
+        H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.05 * np.random.RandomState(5).randn(B, d + 2)
+        rec = {}
+        vals = {}
+        for tag, mode in (("launches", 0), ("launch_free", 1)):
+            ctx.set_persist(mode)
+            for _ in range(3):
+                vals[tag] = ctx.lml(H)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                ctx.lml(H)
+                ts.append(time.perf_counter() - t0)
+            rec[tag + "_ms"] = float(np.median(ts) * 1e3)
+        rec["bit_identical"] = bool(np.array_equal(vals["launches"], vals["launch_free"]))
+        out[f"n{n}_B{B}"] = rec
+        ctx.close()
+    return out
+
+
 def config_b(bask, device, steps=150):
     """BASELINE config B (n = 1024, d = 8, Matern-5/2, 64 walkers; the configuration runs 500 steps, this leg times
     `steps` of them after the start ensemble): MCMC LML-evaluations/s, ms per half-step (32 proposals) and the
@@ -729,6 +755,10 @@ def main():
         line["fit_plus_sample_config"] = f"BayesGPR.fit: MAP start (L-BFGS-B on the device LML + gradient) + {W} walkers x 30 steps"
         del gp2
         line["roofline_n4096"] = config_d_roofline(_lib, device, peak)
+        try:
+            line["launch_free"] = launch_free(_lib, device)
+        except Exception as exc:
+            line["launch_free"] = {"error": repr(exc)}
         for key, fn in (("config_B", config_b), ("config_E", config_e)):
             try:
                 line[key] = fn(bask, device)

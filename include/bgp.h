@@ -229,6 +229,10 @@ int bgp_device_synchronize(int device);
  * bgp_lml_batch call: out[0]=K-build, out[1]=potrf (diagonal blocks), out[2]=trsm (panels),
  * out[3]=syrk (trailing update), out[4]=whole call on device; counts[0..3] = launches. */
 int bgp_last_timing(bgp_ctx* ctx, double* out_ms, int* counts);
+/* Launch-free factorisation of small batches (one persistent kernel pair per bgp_lml_batch call instead of ~3 launches per
+ * block column; same bits): 1 = whenever the batch fits (<= 64 matrices, n > 128), 0 = never, -1 = as BGP_PERSIST says
+ * (unset: off).  Replaces nothing in the reference; a scheduling choice behind cholesky() of sklearn/_gpr.py:587. */
+int bgp_set_persist(bgp_ctx* ctx, int mode);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
 int bgp_set_timing(bgp_ctx* ctx, int enable);
 /* Debugging aid: working matrix (npad x npad doubles; L in the lower triangle after an LML call) and working right-hand

@@ -55,6 +55,9 @@ def test_bench_single_gpu_line():
     sh = d["shard_ms"]
     assert set(sh) == {"128", "64", "32", "16"} and sh["16"] < sh["32"] < sh["64"] < sh["128"]
     assert set(d["shard_projection"]["evals_per_s"]) == {"1", "2", "4", "8"}
+    lf = d["launch_free"]
+    assert set(lf) == {"n4096_B1", "n2048_B16", "n1024_B32"} and all(v["bit_identical"] for v in lf.values())
+    assert all(0 < v["launch_free_ms"] < 3 * v["launches_ms"] for v in lf.values())
     cb = d["config_B"]
     assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9
     ce = d["config_E"]
