@@ -128,7 +128,7 @@ def test_predict_interpolates_smooth_training_points_with_tiny_noise(lib):
     ctx.close()
 
 
-def test_left_looking_and_single_panel_variants_agree(lib, O):
+def test_schedule_variants_agree_bitwise(lib, O):
     """The experimental left-looking update (fused K-generation, 4x4x4 MFMA), the single-panel right-looking schedule,
     other group / panel counts, round 1's kernels and the Gram generation fused into the trailing update must give
     the same LML as the default schedule."""
