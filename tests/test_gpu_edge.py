@@ -129,9 +129,9 @@ def test_predict_interpolates_smooth_training_points_with_tiny_noise(lib):
 
 
 def test_schedule_variants_agree_bitwise(lib, O):
-    """The experimental left-looking update (fused K-generation, 4x4x4 MFMA), the single-panel right-looking schedule,
-    other group / panel counts, round 1's kernels and the Gram generation fused into the trailing update must give
-    the same LML as the default schedule."""
+    """Panel-group sizes (BGP_PANELS), walker-group stream counts, the unpipelined Gram build and the Gram generation
+    fused into the trailing update only regroup the same operations: LML, alpha and K^-1 must come out with the same
+    BITS as the default schedule."""
     import os
     import subprocess
     import sys
