@@ -76,6 +76,7 @@ SIGNATURES = {
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
     "bgp_set_timing": (C.c_int, [_vp, C.c_int]),
     "bgp_set_persist": (C.c_int, [_vp, C.c_int]),
+    "bgp_last_timing_columns": (C.c_int, [_vp, _dp, _ip]),
     "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
     "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
@@ -402,6 +403,10 @@ class Context:
         names = ("kbuild", "potrf", "trsm", "syrk")
         out = {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(names)}
         out["device_total_ms"] = float(ms[4])
+        cms, cn = C.c_double(0.0), C.c_int(0)
+        _check(self._lib.bgp_last_timing_columns(self._h, C.byref(cms), C.byref(cn)), "bgp_last_timing_columns")
+        # the look-ahead column launches inside "syrk" (K = 128 .. 128 (P-1) on one block column)
+        out["syrk_columns"] = {"ms": float(cms.value), "launches": int(cn.value)}
         return out
 
 

@@ -482,8 +482,8 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     if (!c->dwarpB) BGP_HIP(hipMalloc(&c->dwarpB, (size_t)c->max_batch * 2 * c->d * sizeof(double)));
   }
   const size_t p = c->d + 2;
-  for (int k = 0; k < 5; k++) c->t_ms[k] = 0.0;
-  for (int k = 0; k < 4; k++) c->t_cnt[k] = 0;
+  for (int k = 0; k < 6; k++) c->t_ms[k] = 0.0;
+  for (int k = 0; k < 6; k++) c->t_cnt[k] = 0;
   for (int off = 0; off < B; off += c->max_batch) {
     const int nb = std::min(c->max_batch, B - off);
     if (c->timing) {
@@ -773,6 +773,15 @@ extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
 
 // Launch-free factorisation of small batches: -1 = as the environment says (BGP_PERSIST; unset:
 // off), 0 = never, 1 = whenever the batch fits (at most 64 matrices, at least two block columns).
+// The look-ahead column launches of the trailing update (K = 128 .. 128 (P-1) on one 128-wide block column) inside the
+// "syrk" figure of bgp_last_timing: their time and count, so that a caller can rate bulk and column launches apart.
+extern "C" int bgp_last_timing_columns(bgp_ctx* c, double* ms, int* launches) {
+  if (!c || !ms) return BGP_ERR_INVALID;
+  *ms = c->t_ms[5];
+  if (launches) *launches = c->t_cnt[5];
+  return BGP_OK;
+}
+
 extern "C" int bgp_set_persist(bgp_ctx* c, int mode) {
   if (!c || mode < -1 || mode > 1) {
     bgp_set_error("bgp_set_persist: mode must be -1, 0 or 1");

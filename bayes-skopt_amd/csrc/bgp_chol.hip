@@ -850,7 +850,7 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
         bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
-          bgp_tbegin(ctx, 3, st);
+          bgp_tbegin(ctx, 5, st);
           bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
           bgp_tend(ctx, st);
         }

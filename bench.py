@@ -54,6 +54,26 @@ def trailing_flops_per_launch(n, nb=NB):
     return [nb * (n - j * nb) * (n - j * nb + 1) for j in range(1, n // nb)]
 
 
+def trailing_flops_split(n, nb=NB):
+    """The same flops by KIND of launch of the multi-panel schedule (csrc/bgp_chol.hip: P = 4 block columns per group from
+    12 block columns, else 2): look-ahead COLUMN launches (block column c = k+j+1 of a group that started at k gets the
+    panels k .. k+j, K = nb (j+1), on the 128 m_c - 8128 lower elements of that column) and BULK launches (everything
+    to the right of the group with K = nb P).  Returns (F_column, F_bulk) per matrix; their sum is sum(F_trail)."""
+    nblk = n // nb
+    P = 4 if nblk >= 12 else 2
+    total = float(sum(trailing_flops_per_launch(n, nb)))
+    col = 0.0
+    k = 0
+    while k < nblk:
+        np_ = min(P, nblk - k)
+        for j in range(np_ - 1):
+            c = k + j + 1
+            m_c = n - c * nb
+            col += 2.0 * nb * (j + 1) * (nb * m_c - nb * (nb - 1) / 2.0)
+        k += np_
+    return col, total - col
+
+
 def _PROFILER_ENV(k):
     return k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTX_")) or k in ("LD_PRELOAD", "HSA_TOOLS_LIB")
 
@@ -607,7 +627,7 @@ def main():
     # like the rocprofv3 runs under profiles/ (BGP_STREAMS=1).
     gp._ctx.set_streams(1)
     gp._ctx.set_timing(True)
-    acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk")}
+    acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk", "syrk_columns")}
     dev_total = 0.0
     n_calls = 0
     orig = gp._ctx.lml
@@ -664,6 +684,20 @@ def main():
             except Exception:
                 pass
     peak = min(FP64_MFMA_PEAK_TFLOPS, mfma_measured) if mfma_measured else FP64_MFMA_PEAK_TFLOPS
+    # where the fraction is lost: the same kernel's bulk launches (K = 512 at this size) against its look-ahead column
+    # launches (K = 128 / 256 / 384 on one 128-wide block column)
+    f_col, f_bulk = trailing_flops_split(n)
+    col_ms, col_launches = acc["syrk_columns"]
+    by_kind = None
+    if col_ms > 0 and syrk_ms > col_ms:
+        by_kind = {
+            "bulk": {"tflops": f_bulk * B * n_calls / ((syrk_ms - col_ms) * 1e-3) / 1e12, "ms_per_half_step": (syrk_ms - col_ms) / n_calls,
+                     "launches_per_half_step": (syrk_launches - col_launches) / n_calls},
+            "look_ahead_columns": {"tflops": f_col * B * n_calls / (col_ms * 1e-3) / 1e12, "ms_per_half_step": col_ms / n_calls,
+                                   "launches_per_half_step": col_launches / n_calls},
+        }
+        for v in by_kind.values():
+            v["frac_of_peak"] = v["tflops"] / peak
     roofline = {
         "bound": "mfma",
         "kernel": "syrk4_kernel<64> (blocked-Cholesky trailing update, four-panel groups K = 128..512, LDS-DMA ring, fp64 "
@@ -679,6 +713,7 @@ def main():
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
         "launches": syrk_launches,
         "algorithmic_flops_per_factorisation": float(sum(fl)),
+        "by_launch_kind": by_kind,
         "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
         "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x the matrices of a launch (SURVEY "
         "8d); peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
@@ -714,7 +749,7 @@ def main():
             "parallelism": f"ensemble_sharded{ws}" if ensemble else f"chains{ws}",
         },
         "roofline": roofline,
-        "kernel_ms_per_half_step": {k: v[0] / max(n_calls, 1) for k, v in acc.items()},
+        "kernel_ms_per_half_step": {k: v[0] / max(n_calls, 1) for k, v in acc.items() if k != "syrk_columns"},
         "device_ms_per_half_step": dev_total / max(n_calls, 1),
         "instrumented_ms_per_step": dt_instr / args.steps * 1e3,
         "gather_ms": gather_ms,

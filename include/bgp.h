@@ -229,6 +229,9 @@ int bgp_device_synchronize(int device);
  * bgp_lml_batch call: out[0]=K-build, out[1]=potrf (diagonal blocks), out[2]=trsm (panels),
  * out[3]=syrk (trailing update), out[4]=whole call on device; counts[0..3] = launches. */
 int bgp_last_timing(bgp_ctx* ctx, double* out_ms, int* counts);
+/* Time (ms) and count of the look-ahead column launches of the trailing update (K = 128 .. 128 (P-1), one block column)
+ * inside out[3] of bgp_last_timing, for the last timed bgp_lml_batch call. */
+int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
 /* Launch-free factorisation of small batches (one persistent kernel pair per bgp_lml_batch call instead of ~3 launches per
  * block column; same bits): 1 = whenever the batch fits (<= 64 matrices, n > 128), 0 = never, -1 = as BGP_PERSIST says
  * (unset: off).  Replaces nothing in the reference; a scheduling choice behind cholesky() of sklearn/_gpr.py:587. */

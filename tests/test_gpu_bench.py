@@ -47,6 +47,9 @@ def test_bench_single_gpu_line():
     # HBM bytes per launch: collected by two rocprofv3 --pmc child passes of this very run when the profiler is there
     # (else the committed passes); the algorithmic C round trip alone is 0.45 GB per launch
     assert r["traffic_source"].startswith(("live", "profiles/")) and 0.45e9 < r["traffic"] < 2.0e9
+    bk = r["by_launch_kind"]  # the same kernel's bulk launches against its look-ahead column launches
+    assert 0.5 < bk["look_ahead_columns"]["frac_of_peak"] < bk["bulk"]["frac_of_peak"] < 1.0
+    assert abs(bk["bulk"]["ms_per_half_step"] + bk["look_ahead_columns"]["ms_per_half_step"] - d["kernel_ms_per_half_step"]["syrk"]) < 1e-6
     assert "workload" in d["config"] and "model" not in d["config"]
     n4 = d["roofline_n4096"]  # the north star's own target: >= 40 % of fp64 peak on the trailing update at n = 4096
     assert n4["lml_finite"] and n4["peak"] == r["peak"] and 0.4 < n4["frac"] < 1.0
