@@ -364,6 +364,30 @@ def gen_sizes_posterior(out):
     np.savez_compressed(os.path.join(out, "posterior_sizes.npz"), **rec)
 
 
+def gen_sample_y(out):
+    """a8: the call the reference makes for function draws -- sklearn's GaussianProcessRegressor.sample_y
+    (sklearn/_gpr.py:522-526: numpy's legacy multivariate_normal, i.e. an SVD of the predictive covariance), reached from
+    bask/bayesgpr.py:669-678.  Stored: the distribution's parameters as sklearn computes them (predict with return_cov)
+    and the sample mean / covariance of 4000 reference draws: the device draws (Cholesky factor, other variates) must
+    describe the same distribution within Monte-Carlo error."""
+    n, d, m, ndraw = 60, 2, 6, 4000
+    X, y = synth(n, d, 77)
+    k = sk.ConstantKernel(1.3) * sk.Matern(length_scale=[0.35, 0.5], nu=2.5) + sk.WhiteKernel(0.02)
+    gpr = GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
+    Xq = np.random.RandomState(78).uniform(size=(m, d))
+    # the reference draws with the noise switched off (bask/bayesgpr.py:669: noise_set_to_zero)
+    k0 = sk.ConstantKernel(1.3) * sk.Matern(length_scale=[0.35, 0.5], nu=2.5) + sk.WhiteKernel(1e-300)
+    mean, cov = gpr.predict(Xq, return_cov=True)
+    gpr0 = GaussianProcessRegressor(kernel=k0, optimizer=None, alpha=1e-10)
+    gpr0.fit(X, y)
+    gpr0.L_, gpr0.alpha_ = gpr.L_, gpr.alpha_   # factors of the noisy kernel, noise-free prior at the query points
+    mean0, cov0 = gpr0.predict(Xq, return_cov=True)
+    draws = gpr0.sample_y(Xq, n_samples=ndraw, random_state=5)   # (m, ndraw)
+    np.savez(os.path.join(out, "sample_y.npz"), X=X, y=y, Xq=Xq, theta=gpr.kernel_.theta, mean=mean0, cov=cov0,
+             ref_sample_mean=draws.mean(axis=1), ref_sample_cov=np.cov(draws), ndraw=ndraw,
+             mean_noisy=mean, cov_noisy=cov)
+
+
 if __name__ == "__main__":
     gen_lml_small(HERE)
     gen_lml_sizes(HERE)
@@ -371,4 +395,5 @@ if __name__ == "__main__":
     gen_predict(HERE)
     gen_reference_tier1(HERE)
     gen_sizes_posterior(HERE)
+    gen_sample_y(HERE)
     print("done")

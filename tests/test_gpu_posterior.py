@@ -136,3 +136,37 @@ def test_sample_y_moments(lib):
     Lc = np.linalg.cholesky(cov + jit * np.eye(m))
     np.testing.assert_allclose(out, mean[None, :] + z @ Lc.T, rtol=1e-6, atol=1e-7)
     ctx.close()
+
+
+def test_sample_y_is_the_reference_distribution(lib):
+    """a8 against the REFERENCE's own call: scikit-learn's GaussianProcessRegressor.sample_y (sklearn/_gpr.py:522-526, numpy's
+    SVD-based multivariate normal; reached from bask/bayesgpr.py:669-678 with the noise switched off).  The device draws
+    use a Cholesky factor and therefore other variates; what must agree is the distribution:
+    (i) its parameters -- the device mean / covariance reconstructed from unit vectors -- with scikit-learn's
+    predict(return_cov=True) at 1e-6, and (ii) sample mean and covariance of 4000 device draws with them within
+    Monte-Carlo error, exactly as the 4000 reference draws stored in the golden file do."""
+    g = load_golden("sample_y.npz")
+    X, y, Xq, th = g["X"], g["y"], g["Xq"], g["theta"]
+    m, nd = Xq.shape[0], int(g["ndraw"])
+    ctx = lib.Context(X, y, 1e-10, max_batch=2)
+    ctx.posterior(th)
+    hk = th.copy()
+    hk[-1] = -np.inf  # noise_set_to_zero: the white-noise level leaves the kernel, the factors stay
+    # (i) parameters: z = 0 gives the mean, z = e_j the j-th column of the factor
+    out = ctx.sample_y(0, hk, Xq, np.vstack([np.zeros((1, m)), np.eye(m)]), jitter=0.0)
+    mean = out[0]
+    Lf = (out[1:] - mean).T
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(Lf @ Lf.T, g["cov"], rtol=1e-6, atol=1e-9 * np.abs(g["cov"]).max())
+    # (ii) 4000 draws: same Monte-Carlo agreement as the reference's own draws
+    z = np.random.RandomState(11).standard_normal((nd, m))
+    draws = ctx.sample_y(0, hk, Xq, z, jitter=0.0)
+    sd = np.sqrt(np.diag(g["cov"]))
+    zdev = np.abs(draws.mean(axis=0) - g["mean"]) / (sd / np.sqrt(nd))
+    zref = np.abs(g["ref_sample_mean"] - g["mean"]) / (sd / np.sqrt(nd))
+    assert zdev.max() < 4.5 and zref.max() < 4.5
+    cdev, cref = np.cov(draws.T), g["ref_sample_cov"]
+    scale = np.sqrt(np.outer(np.diag(g["cov"]), np.diag(g["cov"])))
+    tol = 6.0 * np.sqrt(2.0 / nd)  # (a sample covariance entry scatters by ~ sqrt((1 + rho^2) / N) of the scale)
+    assert np.abs(cdev - g["cov"]).max() / scale.max() < tol and np.abs(cref - g["cov"]).max() / scale.max() < tol
+    ctx.close()
