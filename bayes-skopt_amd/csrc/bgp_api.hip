@@ -232,7 +232,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_AFFINITY", "BGP_PS_FINE", "BGP_PS_GATE", "BGP_PS_K", "BGP_PS_NST", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_K", "BGP_PS_NCRIT", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -509,7 +509,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
     // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
     // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-    const bool use_ps = !fused_small && !warp && !fused_gram && !c->timing && !c->ps_disabled && c->nblk >= 2 && nb <= 64 &&
+    const bool use_ps = !fused_small && !warp && !fused_gram && !c->timing && !c->ps_disabled && bgp_persist_fits(c, nb) &&
                         (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb)));
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {

@@ -25,6 +25,7 @@
 #include "bgp_gemm.h"
 
 #include <cstdlib>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------
 // potrf: diagonal block k of every walker, one workgroup (4 waves) per walker, block in LDS.
@@ -271,6 +272,36 @@ static __device__ __forceinline__ void pf_generate_tile(double* __restrict__ s, 
 }
 }
 
+// The workgroup's LDS: ONE set of function-scope arrays that pf_block and the chain kernel's own steps (pf_chain_next)
+// both reach through this accessor (157.6 of the 160 KB of a CU).
+struct PfLds {
+  double* s;      // 128 x PF_LD: the diagonal block; lower triangle -> L, upper triangle <- W^T block by block
+  double* Minv;   // 8 inverses of the 16 x 16 diagonal blocks (= the diagonal blocks of W)
+  double* xrow;   // 2 x (16 x PF_MLD): X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
+  double* ylds;   // right-hand side of the block
+  double* zpart;  // 4 x 128 partial sums of z = W y; [0, 128) holds z itself when pf_block returns
+  double* red;
+  int* fail;
+};
+static __device__ __forceinline__ PfLds pf_lds() {
+  __shared__ double s[128 * PF_LD];
+  __shared__ double Minv[8 * 16 * PF_MLD];
+  __shared__ double xrow[2 * 16 * PF_MLD];
+  __shared__ double ylds[128];
+  __shared__ double zpart[4 * 128];
+  __shared__ double red[16];
+  __shared__ int fail_lds;
+  PfLds l;
+  l.s = s;
+  l.Minv = Minv;
+  l.xrow = xrow;
+  l.ylds = ylds;
+  l.zpart = zpart;
+  l.red = red;
+  l.fail = &fail_lds;
+  return l;
+}
+
 // One diagonal block of one walker (the whole workgroup).  Returns 0, or the 1-based pivot index inside the block at
 // which the factorisation failed (status / lml of the walker are set here either way).  Called once per launch by
 // potrf_kernel and once per block column by the persistent chain kernel (ps_chain_kernel): the LDS tile is free again
@@ -279,15 +310,20 @@ template <int GEN, int STAT, int FORM>
 static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                double* __restrict__ yw, double* __restrict__ accb,
                                                double* __restrict__ lml, int* __restrict__ status, int n, int ld,
-                                               size_t mstride, int ystride, int nblk, int k, const PfGen& gen) {
-  __shared__ double s[128 * PF_LD];
-  __shared__ double Minv[8 * 16 * PF_MLD];
-  __shared__ double xrow[2][16 * PF_MLD];  // X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
-  __shared__ double ylds[128];
-  __shared__ double zpart[4 * 128];
-  __shared__ double red[16];
-  __shared__ int fail_lds;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+                                               size_t mstride, int ystride, int nblk, int k, const PfGen& gen,
+                                               bool inlds = false) {
+  // inlds (chain kernel, k > 0): the block and its right-hand side are in LDS already (pf_chain_next left them there)
+  const PfLds lds = pf_lds();
+  double* const s = lds.s;
+  double* const Minv = lds.Minv;
+  double* const xrow0 = lds.xrow;
+  double* const ylds = lds.ylds;
+  double* const zpart = lds.zpart;
+  double* const red = lds.red;
+  int& fail_lds = *lds.fail;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));  // (inside the chain kernel's column loop: nothing derived from the lane id is hoisted out of it)
+  const int tid = tid_, lane = tid & 63, w = tid >> 6;
   const int lr = lane & 15, lk = lane >> 4;
   double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
   double* yk = yw + (size_t)b * ystride + k * 128;
@@ -296,7 +332,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   if (GEN) {
     if (tid == 0) status[b] = 0;
     pf_generate_tile<STAT, FORM>(s, Minv, gen, gen.H + (size_t)b * (gen.d + 2), n, tid);  // (Minv: scratch until step 0)
-  } else {
+  } else if (!inlds) {
     // lower triangle of the tile -> LDS, all 16 16-byte loads of a thread in flight at once (the block is
     // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
     // (t >> 6) + 8 i; pairs entirely above the diagonal are never read.
@@ -313,7 +349,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
     }
   }
-  if (tid < 128) ylds[tid] = GEN ? gen.y[tid] : yk[tid];
+  if (tid < 128 && !inlds) ylds[tid] = GEN ? gen.y[tid] : yk[tid];
   double ld_prev = 0.0, zz_prev = 0.0;  // running log-det and z^T z of the earlier diagonal blocks
   if (tid == 0) {
     fail_lds = 0;
@@ -355,7 +391,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
         for (int kk = 0; kk < 4; kk++) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[kk], xt[kk], dg, 0, 0, 0);
         xpend = xt;
 #pragma unroll
-        for (int r = 0; r < 4; r++) xrow[sb & 1][lr * PF_MLD + lk + 4 * r] = xt[r];
+        for (int r = 0; r < 4; r++) xrow0[(sb & 1) * 16 * PF_MLD + lr * PF_MLD + lk + 4 * r] = xt[r];
       }
       // C layout -> one matrix row per lane through the block's own LDS slot (nobody else touches it)
 #pragma unroll
@@ -436,7 +472,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       // (heavy blocks = small J go to the waves without a phase row: rows occupy update waves 0 .. 5-p)
       for (int J = 5 - u6; J <= p; J += 6) {
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        if (J < p) acc = pf_wsum(acc, s, Minv, xrow[p & 1], p, J, J, p, lane);
+        if (J < p) acc = pf_wsum(acc, s, Minv, xrow0 + (p & 1) * 16 * PF_MLD, p, J, J, p, lane);
         pf_wfinish(acc, s, Minv, Wg, p, J, lane);
       }
       // row block sb-2 of L is final and visible: stream it out now (lower triangle, 16-byte pairs)
@@ -483,11 +519,11 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       for (int r = 0; r < 4; r++) T[(size_t)(7 * 16 + lr) * ld + 6 * 16 + lk + 4 * r] = xpend[r];
     }
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    acc = pf_wsum(acc, s, Minv, xrow[1], 7, 6, 6, 7, lane);
+    acc = pf_wsum(acc, s, Minv, xrow0 + 16 * PF_MLD, 7, 6, 6, 7, lane);
     pf_wfinish(acc, s, Minv, Wg, 7, 6, lane);
     pf_wfinish(acc, s, Minv, Wg, 7, 7, lane);
   } else if (w != 4) {
-    w7 = pf_wsum(w7, s, Minv, xrow[1], 7, u6, 6, 7, lane);
+    w7 = pf_wsum(w7, s, Minv, xrow0 + 16 * PF_MLD, 7, u6, 6, 7, lane);
     pf_wfinish(w7, s, Minv, Wg, 7, u6, lane);
   }
   double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
@@ -513,6 +549,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   if (tid < 128) {
     zv = (zpart[tid] + zpart[128 + tid]) + (zpart[256 + tid] + zpart[384 + tid]);
     if (!GEN) yk[tid] = zv;
+    zpart[tid] = zv;  // (a thread reads and writes its own column only: z stays in LDS for pf_chain_next)
   }
   double zz = zv * zv;
   for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
@@ -575,54 +612,219 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
 // the batch on the multi-launch path.  Arithmetic, operand order and summation order are those of the multi-launch path:
 // the log-likelihoods are bit-identical (tests/test_gpu_persist.py).
 // ------------------------------------------------------------------------------------------
+// dt[u] -= X_ti X_tj^T for this wave's NT tiles of the next diagonal block, X row-major in the LDS tile: the operands of
+// k-step kk+1 are read while k-step kk multiplies (two waves per SIMD cover the rest of the LDS latency).
+template <int NT>
+static __device__ __forceinline__ void pf_diag_update(d4 (&dt)[5], const double* __restrict__ s, const int (&offa)[5],
+                                                      const int (&offb)[5]) {
+  double a0[NT], b0[NT];
+#pragma unroll
+  for (int u = 0; u < NT; u++) {
+    a0[u] = s[offa[u]];
+    b0[u] = s[offb[u]];
+  }
+#pragma unroll 2
+  for (int t = 0; t < 32; t++) {
+    double a1[NT], b1[NT];
+    const int tn = (t + 1 < 32) ? t + 1 : t;
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+      a1[u] = s[offa[u] + 4 * tn];
+      b1[u] = s[offb[u] + 4 * tn];
+    }
+#pragma unroll
+    for (int u = 0; u < NT; u++) dt[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], dt[u], 0, 0, 1);
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+      a0[u] = a1[u];
+      b0[u] = b1[u];
+    }
+  }
+}
+
+// The chain's own share of block column J (PsArgs::fat): the two blocks the next factorisation waits for never leave the
+// chain's workgroup.  W_JJ is still in LDS (transposed in the upper triangle of the tile, diagonal blocks in Minv), z_J in
+// zpart; the tile workers have applied the panels 0 .. J-1 to blocks (J+1, J) and (J+1, J+1) beforehand (subrdy / diagrdy).
+//   1. X = A_{J+1,J} W_JJ^T: wave w owns rows 16 w .. 16 w + 15, the A operand comes from global memory straight into
+//      fragment registers (32 doubles per lane), chunk c of k only reaches the column blocks j >= c; right-hand side
+//      y_{J+1} -= X z_J in the same pass (one row per 16 lanes, fixed shuffle order): the arithmetic of trsm4_kernel;
+//      X goes to global memory for the tile workers (xready[J+1][J]) and, row-major, into the LDS tile;
+//   2. D_{J+1,J+1} -= X X^T on the 36 lower 16 x 16 tiles (accumulator = the block as the tile worker left it, k ascending
+//      in steps of 4, A-negate: the arithmetic of syrk4_kernel), and the result IS the next LDS tile of pf_block: no
+//      flag, no L2 round trip and no other workgroup between two factorisations.
+// Returns 0, or -1 when a wait was abandoned.
+static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr) {
+  const PfLds lds = pf_lds();
+  double* const s = lds.s;
+  const double* const Minv = lds.Minv;
+  double* const ylds = lds.ylds;
+  const double* const zl = lds.zpart;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int I = J + 1, ld = a.ld, nblk = a.nblk;
+  unsigned* const flags = a.flags;
+  unsigned* const err = flags + PS_ERROR;
+  double* const Mb = a.K + (size_t)b * a.mstride;
+  double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
+  const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
+  if (J > 0) {
+    if (tid == 0) {
+      const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
+      const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
+      const bool ok = ps_wait_ge(subrdy + I, 1u, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      ps_acquire();
+      *ok_lds = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!*ok_lds) return -1;
+  }
+  if (tr && tid == 0) tr[J * 8 + 2] = wall_clock64();
+  // ---- operands: A fragments (k = 4 t + lk of row 16 w + lr), this lane's rows of y, the D tiles of this wave
+  double af[32];
+  {
+    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
+#pragma unroll
+    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+  }
+  double yv[4];
+  {
+    const double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
+#pragma unroll
+    for (int r = 0; r < 4; r++) yv[r] = yi[16 * w + lk + 4 * r];
+  }
+  // lower 16 x 16 tiles t = w, w + 8, ... < 36 in row-major order of the triangle (waves 0-3: five, 4-7: four; nine per SIMD)
+  d4 dt[5];
+  int offa[5], offb[5], offc[5], offd[5];
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    const int t = w + 8 * u;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    offa[u] = (ti * 16 + lr) * PF_LD + lk;
+    offb[u] = (tj * 16 + lr) * PF_LD + lk;
+    offc[u] = (ti * 16 + lk) * PF_LD + tj * 16 + lr;
+    offd[u] = (ti * 16 + lk) * ld + tj * 16 + lr;
+  }
+  // ---- 1. panel solve
+  d4 x[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) x[j] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const double av = af[4 * c + kk];
+      // column block c: the diagonal block of W (its upper part holds zeros); j > c: W[j][c]^T in the upper triangle
+      x[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Minv[c * 16 * PF_MLD + lr * PF_MLD + 4 * kk + lk], x[c], 0, 0, 0);
+#pragma unroll
+      for (int j = c + 1; j < 8; j++)
+        x[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s[(c * 16 + 4 * kk + lk) * PF_LD + j * 16 + lr], x[j], 0, 0, 0);
+    }
+  }
+  // (the D tiles are fetched under the epilogue: with them in flight during the solve the kernel spilled)
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    if (w + 8 * u < 36) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) dt[u][r] = Db[(size_t)offd[u] + (size_t)(4 * r) * ld];
+    } else {
+      dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+  }
+  if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
+  {
+    double zc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) zc[j] = zl[16 * j + lr];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * w + lk + 4 * r;
+      double part = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const double xv = x[j][r];
+        Ab[(size_t)row * ld + 16 * j + lr] = xv;
+        part = __builtin_fma(xv, zc[j], part);  // (trsm4_kernel's `part += x * zc[j]` is contracted the same way)
+      }
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      part += __shfl_xor(part, 8);
+      if (lr == 0) ylds[row] = yv[r] - part;
+    }
+  }
+  __syncthreads();  // nobody reads W in the tile any more (X's stores drain while it goes into the tile)
+  if (tr && tid == 0) tr[J * 8 + 5] = wall_clock64();
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) s[(16 * w + lk + 4 * r) * PF_LD + 16 * j + lr] = x[j][r];
+  ps_publish_barrier();  // X is in the tile, and every wave's part of it has reached memory
+  if (tid == 0) ps_signal_add(flags + PS_HDR + (size_t)2 * a.B * nblk + ((size_t)b * nblk + I) * nblk + J);  // xready[I][J]
+  if (tr && tid == 0) tr[J * 8 + 6] = wall_clock64();
+  // ---- 2. the next diagonal block
+  if (w < 4)
+    pf_diag_update<5>(dt, s, offa, offb);
+  else
+    pf_diag_update<4>(dt, s, offa, offb);
+  __syncthreads();  // everybody is done with X in the tile
+  if (tr && tid == 0) tr[J * 8 + 7] = wall_clock64();
+  if (tr && tid == 0) tr[J * 8 + 7] = wall_clock64();
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    if (w + 8 * u < 36) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[offc[u] + 4 * r * PF_LD] = dt[u][r];
+    }
+  }
+  __syncthreads();
+  if (tr && tid == 0) tr[J * 8 + 3] = wall_clock64();
+  return 0;
+}
+
 __global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   __shared__ int ps_ok;
   unsigned* const flags = a.flags;
-  unsigned* const err = flags + PS_ERROR;
   unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
-  const unsigned* const diagcnt = flags + PS_HDR + (size_t)a.B * a.nblk + (size_t)b * a.nblk;
-  unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 4 : nullptr;
+  unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
   for (int J = 0; J < a.nblk; J++) {
-    if (tid == 0) {
-      int ok = 1;
-      if (tr) tr[J * 4 + 0] = wall_clock64();
-      if (J > 0) {  // block (J, J) carries every update from the panels to its left
-        ok = ps_wait_ge(diagcnt + J, a.fine ? 4u : 1u, err, a.spin_limit) ? 1 : 0;  // (quarters: four arrivals)
-        ps_acquire();
-      }
-      ps_ok = ok;
-      if (tr) tr[J * 4 + 1] = wall_clock64();
-    }
-    __syncthreads();
-    if (!ps_ok) return;  // (timed out / abandoned: the host redoes the batch)
+    if (tr && tid == 0) tr[J * 8 + 0] = wall_clock64();
+    // (J > 0: the block and its right-hand side are in LDS, pf_chain_next left them there)
     const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
-                                         a.nblk, J, PfGen());
-    if (tr && tid == 0) tr[J * 4 + 2] = wall_clock64();
+                                         a.nblk, J, PfGen(), J > 0);
+    if (tr && tid == 0) tr[J * 8 + 1] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) {
       ps_release();
-      if (tr) tr[J * 4 + 3] = wall_clock64();
-      // a failed matrix (status set above) releases every later column at once: its tile tasks see the status and
-      // only pass their own flags on
+      // a failed matrix (status set above) releases every later column at once -- and the panel blocks this workgroup owes
+      // the tile tasks: they see the status and only pass their own flags on
       for (int j = J; j < (failed ? a.nblk : J + 1); j++) ps_st(wready + j, 1u);
+      if (failed)
+        for (int j = J; j + 1 < a.nblk; j++)
+          ps_st(flags + PS_HDR + (size_t)2 * a.B * a.nblk + ((size_t)b * a.nblk + j + 1) * a.nblk + j, 1u);
     }
     if (failed) return;
+    if (J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr) < 0) return;  // (abandoned: the host redoes the batch)
   }
 }
 
-int bgp_ps_total_tasks(int B, int nblk, int fine);
+int bgp_ps_total_tasks(int B, int nblk);
 
 // BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
-// chain (B x nblk x 4: wait begin, wait end, factorised, published) then tile (total x 8: ticket drawn, first operands ready,
+// chain (B x nblk x 8: wait begin, wait end, factorised, published -- fat: see tools/persist_trace_fat.py) then tile (total x 8: ticket drawn, first operands ready,
 // update done, stored, W ready, solved, published, XCC id << 32 | J << 16 | I << 8 | b... see tools/persist_trace.py).
 extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out, size_t cap) {
   if (!c || !dims) return BGP_ERR_INVALID;
   dims[0] = c->ps_trace_B;
   dims[1] = c->ps_trace_nblk;
   dims[2] = c->ps_trace_total;
-  const size_t need = (size_t)c->ps_trace_B * c->ps_trace_nblk * 4 + (size_t)c->ps_trace_total * 8;
+  const size_t need = (size_t)c->ps_trace_B * c->ps_trace_nblk * 8 + (size_t)c->ps_trace_total * 8;
   if (!out || !c->ps_trace || need == 0) return BGP_OK;
   if (cap < need) return BGP_ERR_INVALID;
   BGP_HIP(hipSetDevice(c->device));
@@ -630,29 +832,39 @@ extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out
   return BGP_OK;
 }
 
+// chain CUs per XCD for B matrices: ceil(B / 8), but only 1, 2, 3, 4 or 8 -- with 5, 6 or 7 masked CUs per XCD (unequal
+// counts per shader engine) the dispatcher does not place one 157 KB workgroup on every masked CU (tools/cumask_probe.hip:
+// 6-15 of 40-56 resident together), and a chain workgroup that is not resident stalls its matrix until another one ends
+static int ps_chain_k(int B) {
+  int k = (B + 7) / 8;
+  if (k > 4) k = 8;
+  static int kforce = -1;  // BGP_PS_K: chain CUs per XCD (experiments)
+  if (kforce < 0) {
+    const char* e = getenv("BGP_PS_K");
+    kforce = e ? atoi(e) : 0;
+  }
+  if (kforce > k && kforce <= 8) k = kforce;
+  return k;
+}
+
+// Can this batch take the launch-free path?  (at least two block columns; a chain CU per matrix)
+int bgp_persist_fits(bgp_ctx* c, int B) { return B >= 1 && B <= 64 && c->nblk >= 2 && c->nblk <= 255; }
+
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
 // this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes
 // c->stream wait for both.  The error word travels to pinned memory behind them (ctx->ps_herr): != 0 after the
 // synchronisation means a wait timed out and the caller redoes the batch on the multi-launch path.
 int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int nblk = c->nblk, ld = c->npad;
-  // chain CUs per XCD: ceil(B / 8), but only 1, 2, 3, 4 or 8 -- with 5, 6 or 7 masked CUs per XCD (unequal counts per
-  // shader engine) the dispatcher does not place one 157 KB workgroup on every masked CU (tools/cumask_probe.hip: 6-15
-  // of 40-56 resident together), and a chain workgroup that is not resident stalls its matrix until another one ends
-  int k = (B + 7) / 8;
-  if (k > 4) k = 8;
-  {
-    static int kforce = -1;  // BGP_PS_K: chain CUs per XCD (experiments)
-    if (kforce < 0) {
-      const char* e = getenv("BGP_PS_K");
-      kforce = e ? atoi(e) : 0;
-    }
-    if (kforce > k && kforce <= 8) k = kforce;
-  }
-  if (B < 1 || k > 8 || nblk < 2) {
+  if (!bgp_persist_fits(c, B)) {
     bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
     return BGP_ERR_INVALID;
   }
+  const int k = ps_chain_k(B);
+  // (The complement of 8 k' bits holds 8 (32 - k') tile-shaped workgroups TOGETHER only for k' = 4 and 8 -- 28 / 24 CUs per
+  // XCD, the same number in every shader engine; with 31 / 30 / 29 a few of them start when others have ended
+  // (tools/cumask_probe.hip).  The ticket scheme does not need them all resident: it only loses those few workers.)
+  const int tile_wgs = 8 * (32 - k);
   if (!c->ps_chain[k]) {
     // mask bit i selects one CU of XCD i % 8 (the driver's symmetric map; tools/cumask_probe.hip): the low 8k bits are
     // k CUs in every XCD
@@ -702,35 +914,21 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.B = B;
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
+  a.total = bgp_ps_total_tasks(B, nblk);
   {
-    // quarter-row tasks for the two blocks the chain waits for: they cut the chain's wait per block column from 35-41 to
-    // 30-33 us, but every task occupies a whole workgroup while it waits for W_JJ -- with many matrices the 8 critical
-    // tasks per matrix and column exhaust the tile workgroups (32 matrices: 256 of 224) and the column slips.  Default:
-    // up to 8 matrices (n = 4096 x 1: 2.03 -> 1.72 ms; 1024 x 32: 0.70 -> 0.86 ms with them).  BGP_PS_FINE = 0 / 1 fixes it.
-    static int fine = -2;
-    if (fine == -2) {
-      const char* e = getenv("BGP_PS_FINE");
-      fine = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    // critical pool of the tile kernel: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
+    // workgroups of their own, one per task of a column.  Measured: with up to ~10 block columns the chain waits less
+    // (n = 1024 x 32: 0.63 -> 0.59 ms, 975 x 50: 0.93 -> 0.84); with more, these left-looking tasks are long and want the
+    // look-ahead the single list gives them (n = 2048 x 9: 1.20 -> 1.37 ms with the pool).  BGP_PS_NCRIT fixes the number.
+    static int ncf = -2;
+    if (ncf == -2) {
+      const char* e = getenv("BGP_PS_NCRIT");
+      ncf = e ? atoi(e) : -1;
     }
-    a.fine = fine >= 0 ? fine : (B <= 8 ? 1 : 0);
+    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min(3 * B, tile_wgs / 2) : 0);
   }
-  a.total = bgp_ps_total_tasks(B, nblk, a.fine);
   a.spin_limit = limit;
   a.trace = nullptr;
-  {
-    static int aff = -1;
-    if (aff < 0) {
-      const char* e = getenv("BGP_PS_AFFINITY");
-      aff = (e && atoi(e) == 0) ? 0 : 1;
-    }
-    a.affinity = aff;
-    static int gate = -1;
-    if (gate < 0) {
-      const char* e = getenv("BGP_PS_GATE");
-      gate = e ? atoi(e) : 0;
-    }
-    a.gate = gate;
-  }
   {
     static int want = -1;
     if (want < 0) {
@@ -738,7 +936,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       want = (e && atoi(e) != 0) ? 1 : 0;
     }
     if (want) {
-      const size_t need = (size_t)B * nblk * 4 + (size_t)a.total * 8;
+      const size_t need = (size_t)B * nblk * 8 + (size_t)a.total * 8;
       if (need > c->cap_pstrace) {
         if (c->ps_trace) (void)hipFree(c->ps_trace);
         c->ps_trace = nullptr;
@@ -759,15 +957,12 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   BGP_HIP(hipStreamWaitEvent(sb, c->ps_ev0, 0));
   hipLaunchKernelGGL(ps_chain_kernel, dim3(B), dim3(PF_THREADS), 0, sa, a);
   BGP_HIP(hipEventRecord(c->ps_eva, sa));
-  static int nst = 0;
-  if (!nst) {
-    const char* e = getenv("BGP_PS_NST");  // ring depth of the tile workers: 4 (three chunks in flight, one workgroup per CU) or 2
-    nst = (e && atoi(e) == 2) ? 2 : 4;
+  if (a.total > 0) {  // (two block columns: the chain does everything)
+    bgp_launch_ps_tile(sb, a, tile_wgs);
+    BGP_HIP(hipEventRecord(c->ps_evb, sb));
   }
-  bgp_launch_ps_tile(sb, a, 8 * (32 - k), nst);
-  BGP_HIP(hipEventRecord(c->ps_evb, sb));
   BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_eva, 0));
-  BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_evb, 0));
+  if (a.total > 0) BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_evb, 0));
   BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(hipGetLastError());
   return BGP_OK;

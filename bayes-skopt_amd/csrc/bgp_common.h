@@ -227,13 +227,14 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 
 // ---- launch-free factorisation of small batches (bgp_chol.hip: ps_chain_kernel, bgp_syrk4.hip: ps_tile_kernel) ----
 // Flag block of one persistent factorisation (32-bit words, zeroed by a memset node in front of every call):
-//   [PS_TICKET]  next task of the tile kernel          [PS_ERROR]  != 0: a spin timed out / a rank gave up: everybody leaves
+//   [PS_TICKET + 2 + 8 pool + x]  next task of the tile kernel's list (pool, XCD x)      [PS_ERROR]  != 0: a wait timed out: everybody leaves
 //   wready[b * nblk + J]          1 when potrf(J) of matrix b has published L_JJ, W_JJ, z_J (or the matrix has failed)
-//   diagrdy[b * nblk + J]         1 when the left-looking update of the diagonal block (J, J) is complete
+//   diagrdy[b * nblk + I]         1 when the diagonal block (I, I) carries the panels 0 .. I-2 (the chain applies panel I-1)
 //   xready[(b * nblk + I) * nblk + J]   1 when the panel block X_IJ is final, I > J
+//   subrdy[b * nblk + I]          1 when block (I, I-1) carries the panels 0 .. I-2 (the chain solves it)
 #define PS_TICKET 0
 #define PS_ERROR 1
-#define PS_HDR 16
+#define PS_HDR 32
 struct PsArgs {
   double* K;          // B working matrices (ld x ld, row-major), become L in place
   double* W;          // B x nblk inverses of the diagonal blocks
@@ -244,17 +245,16 @@ struct PsArgs {
   unsigned* flags;    // the block above
   int n, ld, nblk, B, ystride;
   size_t mstride;
-  int total;          // tasks of the tile kernel
+  int total;          // tasks of the tile kernel (0: two block columns, the chain does everything)
+  int ncrit;          // workgroups of the tile kernel's critical pool (0: one list)
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
-  int fine;                       // the two critical blocks of every column as four 32-row tasks each (BGP_PS_FINE)
-  int gate;                       // blocks off the critical path stay out of its memory windows (BGP_PS_GATE)
-  int affinity;                   // tile tasks of matrix b on XCD b % 8 (BGP_PS_AFFINITY, experiments)
-  unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 4 per (b, J), tile: 8 per task
+  unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
 };
-static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (2 + nblk); }
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (3 + nblk); }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int tile_cus, int nst);
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg);
+int bgp_persist_fits(bgp_ctx* ctx, int B);
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);

@@ -999,7 +999,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
     // (BGP_PERSIST=1: the covariance's factorisation -- ONE matrix of 79 block columns at 10 000 candidates, the longest
     // launch chain of a tell -- on the launch-free path; a timed-out wait is an error here, the matrix is gone)
-    const bool ps = c->persist == 1 && w->nblk >= 2;
+    const bool ps = c->persist == 1 && bgp_persist_fits(w, 1);
     if (ps) {
       w->persist = 1;
       if ((rc = bgp_launch_cholesky_persist(w, 1))) break;

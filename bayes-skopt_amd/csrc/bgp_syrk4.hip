@@ -501,28 +501,29 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 
 // ------------------------------------------------------------------------------------------
 // Tile worker of the launch-free factorisation (see ps_chain_kernel, bgp_chol.hip, for the scheme).  Left-looking by
-// blocks: task (b, I, J) owns the 128 x 128 block (I, J) of matrix b, one 512-thread workgroup (8 waves), and
-//   1. loads it once and applies EVERY finished panel to its left,  C -= X_I,p X_J,p^T  for p = 0 .. J-1, on a
-//      FOUR-stage LDS-DMA ring (three 16-wide chunks in flight: a task on the critical path runs alone on its CU, and a
-//      two-stage ring spent an L2 round trip of 2-5 us on every 0.4 us chunk -- tools/persist_trace.py), as far as the
-//      panels are final: it waits on xready only when it has caught up with the factorisation;
-//   2. I == J: stores the updated diagonal block (lower part) and raises diagrdy: the chain kernel factorises it;
-//      I > J: stores the block, waits for W_JJ (wready) and runs the panel solve X = C W_JJ^T in place with the fused
-//      right-hand-side update y_I -= X z_J (the arithmetic of trsm4_kernel), then raises xready.
-// Tasks are drawn from ONE ticket counter.  Order, per block column J and across the matrices of the batch: the panel
-// block (J+1, J) that the next diagonal block waits for, then that diagonal block (J+1, J+1), then the rest of column J
-// -- a topological order of the dependency graph (every task only waits for tasks with smaller tickets and for the
-// chain), so the earliest unfinished task always belongs to a running workgroup: no deadlock whatever the number of
-// resident workgroups; and the diagonal block's workgroup has applied all older panels long before the last one arrives.
+// blocks: a task owns one 128 x 128 block (I, Jc) of matrix b, one 512-thread workgroup (8 waves), and
+//   1. loads it once and applies the finished panels to its left,  C -= X_I,p X_Jc,p^T, on a FOUR-stage LDS-DMA ring
+//      (three 16-wide chunks in flight: a two-stage ring spent an L2 round trip of 2-5 us on every 0.4 us chunk --
+//      tools/persist_trace.py), as far as the panels are final: it waits on xready only when it has caught up with the
+//      factorisation;
+//   2. S(I, J), I >= J+2: stores the block, waits for W_JJ (wready) and runs the panel solve X = C W_JJ^T in place with the
+//      fused right-hand-side update y_I -= X z_J (the arithmetic of trsm4_kernel), then raises xready[I][J];
+//      P(I) = block (I, I-1) and Dg(I) = block (I, I), I >= 2: the PRE-updates with the panels 0 .. I-2: they store the block
+//      and raise subrdy[I] / diagrdy[I] -- the chain workgroup applies the last panel, solves and factorises them itself.
+// Tasks are drawn from ticket counters.  Order, per block column J = 0 .. nblk-3 and across the matrices of the batch: the
+// panel solve S(J+2, J) -- the block both pre-updates of the column wait for --, then P(J+2), Dg(J+2), then S(J+3 .., J): a
+// topological order of the dependency graph (every task only waits for tasks with smaller tickets and for the chain), so
+// the earliest unfinished task always belongs to a running workgroup: no deadlock whatever the number of resident
+// workgroups.  With PsArgs::ncrit > 0 the three tasks at the head of every column have ticket lists and workgroups of
+// their own (the first ncrit of the launch): a task the chain is going to wait for never queues behind a long update
+// (each list is in topological order and together they hold every task: still no deadlock; a workgroup whose pool is
+// exhausted helps the other one).
 // Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
 // ascending, A-negate): bit-identical factors.
 // ------------------------------------------------------------------------------------------
-// tasks per matrix: the blocks (I, J), I > J, and the diagonal blocks 1 .. nblk-1; `fine`: the two blocks the chain waits
-// for in every column -- (J+1, J) and (J+1, J+1) -- are cut into four 32-row tasks each (+6 per column)
-static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk, int fine) {
-  return (nblk - 1) * (nblk + 2) / 2 + (fine ? 6 * (nblk - 1) : 0);
-}
-static __host__ __device__ __forceinline__ int ps_total_tasks(int B, int nblk, int fine) { return B * ps_tasks_per_matrix(nblk, fine); }
+static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk) { return nblk > 2 ? 3 * (nblk - 2) : 0; }
+static __host__ __device__ __forceinline__ int ps_bulk_per_matrix(int nblk) { return nblk > 3 ? (nblk - 3) * (nblk - 2) / 2 : 0; }
+static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk) { return ps_crit_per_matrix(nblk) + ps_bulk_per_matrix(nblk); }
 
 // vmcnt(N) with a compile-time N
 template <int N>
@@ -602,28 +603,29 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
   __shared__ __attribute__((aligned(1024))) char smem[PS_NST * STAGEB];
   __shared__ int sh_t, sh_q;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int nblk = a.nblk, B = a.B, ld = a.ld, fine = a.fine;
+  const int nblk = a.nblk, B = a.B, ld = a.ld;
   unsigned* const flags = a.flags;
   unsigned* const err = flags + PS_ERROR;
   unsigned voffX[2], voffW[2];
-  s8_src(voffX, ld, w, lane);
-  s8_src(voffW, 128, w, lane);
-  // XCD affinity (placement only): matrix b belongs to the ticket list of XCD b % 8 -- where its chain workgroup runs
+  s8_src(voffX, ld, w, lane0);
+  s8_src(voffW, 128, w, lane0);
+  // XCD affinity (placement only): matrix b belongs to the ticket lists of XCD b % 8 -- where its chain workgroup runs
   // (block b of the chain kernel is dispatched to XCD b % 8) -- so a matrix's panels, W blocks and flags stay in ONE
   // XCD's L2 and the hand-offs are same-XCD; a workgroup whose own list is exhausted helps the next lists.
-  const int xcc = a.affinity ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) : (int)((blockIdx.x / 8u + blockIdx.x) & 7u);
-  const int per_matrix = ps_tasks_per_matrix(nblk, fine);
-  const int crit = fine ? 8 : 2;  // critical tasks at the head of every column: (J+1, J) and (J+1, J+1), whole or in quarters
+  const int xcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);
+  const bool pools = a.ncrit > 0;
+  int pool = (pools && (int)blockIdx.x < a.ncrit) ? 0 : 1, pools_done = 0;
   int list = 0;  // lists tried so far (own first)
   for (;;) {
     const int x = (xcc + list) & 7;
     const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
+    const int per_matrix = !pools ? ps_tasks_per_matrix(nblk) : (pool == 0 ? ps_crit_per_matrix(nblk) : ps_bulk_per_matrix(nblk));
     if (tid == 0) {
       int tt = -1;
-      if (Bx > 0) {
-        tt = (int)__hip_atomic_fetch_add(flags + PS_TICKET + 2 + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (Bx > 0 && per_matrix > 0) {
+        tt = (int)__hip_atomic_fetch_add(flags + PS_TICKET + 2 + 8 * pool + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tt >= Bx * per_matrix) tt = -1;
       }
       sh_t = tt;
@@ -631,134 +633,117 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
     __syncthreads();
     int t = sh_t;
     __syncthreads();
-    if (t < 0) {  // this list is finished: next one, or done
-      if (++list == 8) return;
+    if (t < 0) {  // this list is finished: next one, then (pools) the other pool, or done
+      if (++list == 8) {
+        if (!pools || ++pools_done == 2) return;
+        pool ^= 1;
+        list = 0;
+      }
       continue;
     }
-    const int tglobal = (int)(((long long)t * 8 + x) % a.total);  // (trace slot: unique per (list, ticket) while B % 8 == 0)
-    // ---- ticket -> (column J, matrix b, block row I, quarter): column J holds crit + (nblk - J - 2) tasks per matrix
-    int J = 0;
-    for (;;) {
-      const int c = (crit + nblk - J - 2) * Bx;
-      if (t < c) break;
-      t -= c;
-      J++;
+    // (trace slot: unique per (pool, list, ticket) while B % 8 == 0)
+    const int tglobal = (pools && pool == 1 ? B * ps_crit_per_matrix(nblk) : 0) + (int)(((long long)t * 8 + x) % ((long long)B * per_matrix));
+    // ---- ticket -> (column J, matrix b, kind, block row I).  kind 0: S(I, J); 1: P(I); 2: Dg(I)
+    int J = 0, kind = 0, I;
+    if (pools && pool == 0) {  // three critical tasks per column and matrix
+      J = t / (3 * Bx);
+      t -= J * 3 * Bx;
+      kind = t / Bx;
+      I = J + 2;
+    } else {
+      const int head = pools ? 0 : 3;  // (one list: the critical tasks lead their column)
+      for (;;) {
+        const int c = (head + nblk - J - 3) * Bx;
+        if (t < c) break;
+        t -= c;
+        J++;
+      }
+      const int q0 = t / Bx;
+      kind = q0 < head ? q0 : 0;
+      I = q0 < head ? J + 2 : J + 3 + (q0 - head);
     }
-    const int q0 = t / Bx, b = x + 8 * (t - q0 * Bx);
-    const bool critical = q0 < crit;
-    const bool diag = critical && q0 >= crit / 2;                 // (J+1, J) first, then the diagonal block (J+1, J+1)
-    const int I = critical ? J + 1 : J + 2 + (q0 - crit);         // ... then the blocks J+2 .. of column J
-    const int quarter = (fine && critical) ? (q0 & 3) : -1;       // 32-row slice of a critical block, or the whole block
-    const int rows0 = quarter < 0 ? 0 : 32 * quarter;
-    const bool gate = a.gate && !critical;
-    const int Jc = diag ? J + 1 : J;  // block column of the task's block
+    const int b = x + 8 * (t % Bx);
+    const bool presub = kind == 1, diag = kind == 2;
+    const int Jc = J + kind;               // block column of the task's block
+    const int npan = kind == 0 ? J : J + 1;  // panels 0 .. npan-1 are applied here
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));  // (per-lane addresses of a task are formed in the task: hoisted out of this loop they spilled)
     unsigned* const wready = flags + PS_HDR + (size_t)b * nblk;
     unsigned* const diagrdy = flags + PS_HDR + (size_t)B * nblk + (size_t)b * nblk;
     unsigned* const xrI = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + I) * nblk;
     unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + Jc) * nblk;
-    // a block (r, p) is final when its flag has reached 1 -- or 4, when it is a sub-diagonal block cut into quarters
-    const unsigned full = fine ? 4u : 1u;
-#define PS_NEED(r, p) (((r) == (p) + 1) ? full : 1u)
+    unsigned* const subrdy = flags + PS_HDR + (size_t)B * nblk * (2 + nblk) + (size_t)b * nblk;
     const int* const stat = a.status + b;
     double* const M = a.K + (size_t)b * a.mstride;
     double* const C = M + (size_t)I * 128 * ld + Jc * 128;
-    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + (size_t)B * nblk * 4 + (size_t)tglobal * 8 : nullptr;
+    unsigned long long* const tr = (a.trace && tid == 0) ? a.trace + (size_t)B * nblk * 8 + (size_t)tglobal * 8 : nullptr;
     if (tr) {
       tr[0] = wall_clock64();
-      tr[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)Jc << 24) |
-              ((unsigned long long)I << 16) | ((unsigned long long)(quarter & 7) << 12) | (unsigned long long)b;
+      tr[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)kind << 28) |
+              ((unsigned long long)Jc << 20) | ((unsigned long long)I << 12) | (unsigned long long)b;
     }
     if (tid == 0) sh_q = (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
-    if (Jc > 0 && !dead) {
-      // ---- 1. left-looking update with the panels 0 .. Jc-1
-      //   whole block: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles);
-      //   quarter:     waves as 2 x 4, each 16 rows x 32 columns (1 x 2 tiles) of the 32-row slice.
-      const double* const XA = M + ((size_t)I * 128 + rows0) * ld;
+    if (npan > 0 && !dead) {
+      // ---- 1. left-looking update with the panels 0 .. npan-1: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles)
+      const double* const XA = M + (size_t)I * 128 * ld;
       const double* const XB = M + (size_t)Jc * 128 * ld;
-      const int rt = w >> 2, cg = w & 3;
-      // strictly above the diagonal: never read (whole block: the two upper-right waves; quarter q: column groups > q)
-      const bool skip = diag && (quarter < 0 ? (wc == 1 && wr < 2) : (cg > quarter));
+      const bool skip = diag && wc == 1 && wr < 2;  // strictly above the diagonal: never read
       unsigned pa[4], pb[4];
       d4 acc[2][4];
-      d4(&accq)[1][2] = reinterpret_cast<d4(&)[1][2]>(acc);
-      if (quarter < 0) {
-        s4_frag_addr(pa, lds0, wr * 32, lane);
-        s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
-        if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
-      } else {
-        // diagonal quarter: ONE image of all 128 rows of X_I: the A fragments are its rows rows0 + 16 rt
-        s4_frag_addr(pa, lds0, (diag ? rows0 : 0) + rt * 16, lane);
-        s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, cg * 32, lane);
-        if (!skip) gk_load_c<1, 2, -64>(C, (size_t)ld, accq, rows0 + rt * 16, cg * 32, lane);
-      }
+      s4_frag_addr(pa, lds0, wr * 32, lane);
+      s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(acc[i][j]));
+        for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};  // (no undefined value travels round the task loop)
+      if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
       int q = 0;
-      while (q < Jc) {
+      while (q < npan) {
         if (tid == 0) {
-          // (gate: a block off the critical path takes panel p only when the critical path has left it behind --
-          // diagonal block p+1 updated -- so that its operand traffic does not share the memory system with the panel
-          // solve and the diagonal update the chain is waiting for)
           int qq = q;
           bool ok = true;
-#define PS_READY(p) (ps_ld(xrI + (p)) >= PS_NEED(I, p) && (diag || ps_ld(xrJ + (p)) >= PS_NEED(Jc, p)) && \
-                     (!gate || ps_ld(diagrdy + (p) + 1) >= full))
-          while (qq < Jc && PS_READY(qq)) qq++;
+#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && (diag || ps_ld(xrJ + (p)) >= 1u))
+          while (qq < npan && PS_READY(qq)) qq++;
           if (qq == q) {  // caught up with the factorisation: wait for the next panel
-            ok = ps_wait_ge(xrI + q, PS_NEED(I, q), err, a.spin_limit) &&
-                 (diag || ps_wait_ge(xrJ + q, PS_NEED(Jc, q), err, a.spin_limit)) &&
-                 (!gate || ps_wait_ge(diagrdy + q + 1, full, err, a.spin_limit));
+            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 1u, err, a.spin_limit));
             qq = q + 1;
-            while (ok && qq < Jc && PS_READY(qq)) qq++;
+            while (ok && qq < npan && PS_READY(qq)) qq++;
           }
 #undef PS_READY
           ps_acquire();
           sh_q = ok ? qq : -1;
           if (tr && q == 0) tr[1] = wall_clock64();
-          if (tr && qq == Jc) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
+          if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
         }
         __syncthreads();
         const int qq = sh_q;
         if (qq < 0) return;  // abandoned
         const int nch = (qq - q) * 8;
         const size_t k0 = (size_t)q * 128;
-        if (quarter < 0) {
-          if (diag)
-            s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + k0, voffX, XA, voffX, nch, lds0, pa, pb, acc, w, 0, skip);
-          else
-            s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, acc, w, 0, false);
-        } else if (diag) {  // (XB = the whole row block J+1: the single image)
-          s8_ring_run<PS_NST, 1, 2, 1, 1>(XB + k0, voffX, XB, voffX, nch, lds0, pa, pb, accq, w, 0, skip);
-        } else {
-          s8_ring_run<PS_NST, 1, 2, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, accq, w, 0, false, 32);
-        }
+        if (diag)
+          s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + k0, voffX, XA, voffX, nch, lds0, pa, pb, acc, w, 0, skip);
+        else
+          s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, acc, w, 0, false);
         __syncthreads();  // (the ring and sh_q are free again)
         q = qq;
       }
-      if (!skip) {
-        if (quarter < 0)
-          gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
-        else
-          gk_store_c<1, 2, -64>(C, (size_t)ld, accq, rows0 + rt * 16, cg * 32, lane);
-      }
+      if (!skip) gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
     }
     if (tr) tr[3] = wall_clock64();
-    if (diag) {
+    if (diag || presub) {
       ps_publish_barrier();
-      if (tid == 0) ps_signal_add(diagrdy + Jc);
+      if (tid == 0) ps_signal_add((diag ? diagrdy : subrdy) + I);
       if (tr) tr[6] = wall_clock64();
       __syncthreads();
       continue;
     }
-    // ---- 2. panel solve against W_JJ: waves stacked along the rows, 16 rows x 128 columns each (a quarter: waves 0, 1)
+    // ---- 2. panel solve against W_JJ: waves stacked along the rows, 16 rows x 128 columns each
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
     if (tid == 0) {
-      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit) && (!gate || ps_wait_ge(diagrdy + J + 1, full, err, a.spin_limit));
+      const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit);
       ps_acquire();
       sh_q = !ok ? -1 : (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : 1);
       if (tr) tr[4] = wall_clock64();
@@ -768,10 +753,7 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
     dead = dead || sh_q == 0;
     if (!dead) {
       const double* const Wm = a.W + ((size_t)b * nblk + J) * (128 * 128);
-      const int arows = quarter < 0 ? 128 : 32;
-      const bool idle = 16 * w >= arows;  // (a quarter task: six waves only help with W's staging)
-      const int r0 = idle ? 0 : w * 16;   // row of this wave inside the task's slice
-      double* const Cs = C + (size_t)rows0 * ld;
+      const int r0 = w * 16;
       unsigned pa[4], pb[4];
       s4_frag_addr(pa, lds0, r0, lane);
       s4_frag_addr(pb, lds0 + AOPB, 0, lane);
@@ -785,32 +767,29 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
       double zc[8], yv[4];
 #pragma unroll
       for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-      double* const yi = a.yw + (size_t)b * a.ystride + I * 128 + rows0;
+      double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
 #pragma unroll
       for (int r = 0; r < 4; r++) yv[r] = yi[GK_ROWB(r0, 0, lane, r)];
-      s8_ring_run<PS_NST, 1, 8, 0, 0>(Cs, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, idle, arows);
+      s8_ring_run<PS_NST, 1, 8, 0, 0>(C, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, false);
       // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
       // one wave per row, fixed shuffle order (as trsm4_kernel)
-      if (!idle) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int row = GK_ROWB(r0, 0, lane, r);
-          double part = 0.0;
+      for (int r = 0; r < 4; r++) {
+        const int row = GK_ROWB(r0, 0, lane, r);
+        double part = 0.0;
 #pragma unroll
-          for (int j = 0; j < 8; j++) {
-            const double x = acc[0][j][r];
-            Cs[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
-            part += x * zc[j];
-          }
-          part += __shfl_xor(part, 1);
-          part += __shfl_xor(part, 2);
-          part += __shfl_xor(part, 4);
-          part += __shfl_xor(part, 8);
-          if ((lane & 15) == 0) yi[row] = yv[r] - part;
+        for (int j = 0; j < 8; j++) {
+          const double x = acc[0][j][r];
+          C[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
+          part += x * zc[j];
         }
+        part += __shfl_xor(part, 1);
+        part += __shfl_xor(part, 2);
+        part += __shfl_xor(part, 4);
+        part += __shfl_xor(part, 8);
+        if ((lane & 15) == 0) yi[row] = yv[r] - part;
       }
     }
-#undef PS_NEED
     if (tr) tr[5] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) ps_signal_add(xrI + J);
@@ -820,11 +799,10 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
 }
 
 // one 512-thread workgroup per tile CU
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int tile_cus, int nst) {
-  (void)nst;
-  hipLaunchKernelGGL(ps_tile_kernel, dim3(std::min(a.total, tile_cus)), dim3(512), 0, st, a);
+void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg) {
+  hipLaunchKernelGGL(ps_tile_kernel, dim3(std::min(a.total, nwg)), dim3(512), 0, st, a);
 }
-int bgp_ps_total_tasks(int B, int nblk, int fine) { return ps_total_tasks(B, nblk, fine); }
+int bgp_ps_total_tasks(int B, int nblk) { return B * ps_tasks_per_matrix(nblk); }
 
 // ------------------------------------------------------------------------------------------
 // General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):

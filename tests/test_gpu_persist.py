@@ -41,7 +41,7 @@ for n, d, B in %r:
 print("RESULT " + json.dumps(out))
 """
 
-SHAPES = [(300, 3, 8), (1024, 8, 32), (975, 8, 13), (640, 5, 1), (1100, 6, 50), (2048, 16, 9)]
+SHAPES = [(300, 3, 8), (1024, 8, 32), (975, 8, 13), (640, 5, 1), (1100, 6, 50), (2048, 16, 9), (200, 3, 5)]
 
 
 def _run(env, shapes=SHAPES):
@@ -51,13 +51,14 @@ def _run(env, shapes=SHAPES):
     return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
 
 
-@pytest.mark.parametrize("fine", ["auto", "0", "1"])
-def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(fine):
-    """fine = quarter-row tasks for the two critical blocks of every column (automatic: up to 8 matrices)."""
+@pytest.mark.parametrize("ncrit", ["auto", "0", "24"])
+def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit):
+    """ncrit = workgroups of the tile kernel's critical pool (automatic: one per critical task of a column up to ten block
+    columns, none beyond; 0: one ticket list; 24: fewer than the critical tasks of a column -- they queue)."""
     ref, _ = _run({"BGP_PERSIST": "0"})
     env = {"BGP_PERSIST": "1"}
-    if fine != "auto":
-        env["BGP_PS_FINE"] = fine
+    if ncrit != "auto":
+        env["BGP_PS_NCRIT"] = ncrit
     got, err = _run(env)
     assert "timed out" not in err, err[-1500:]
     for k in ref:

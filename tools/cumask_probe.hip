@@ -107,6 +107,37 @@ int main() {
       CK(hipStreamDestroy(st));
     }
   }
+  // the COMPLEMENT side (the tile kernel's shape: 512 threads + 128 KB LDS, one workgroup per CU): are 8 (32 - k) such
+  // workgroups resident together on the complement of the low 8k bits -- also with 8 fewer, and with the chain side busy?
+  for (int k : {1, 2, 3, 4, 8}) {
+    for (int less : {0, 8, 16}) {
+      const int nb = 8 * (32 - k) - less;
+      std::vector<uint32_t> m(8, 0xffffffffu), ml(8, 0u);
+      for (int i = 0; i < 8 * k; i++) m[i / 32] &= ~(1u << (i % 32)), ml[i / 32] |= 1u << (i % 32);
+      hipStream_t st, sl;
+      CK(hipExtStreamCreateWithCUMask(&st, 8, m.data()));
+      CK(hipExtStreamCreateWithCUMask(&sl, 8, ml.data()));
+      unsigned *c2, *ok2, *xc, *c3, *ok3, *xc3;
+      CK(hipMalloc(&c2, 4)); CK(hipMalloc(&ok2, 4)); CK(hipMalloc(&xc, 4 * 256));
+      CK(hipMalloc(&c3, 4)); CK(hipMalloc(&ok3, 4)); CK(hipMalloc(&xc3, 4 * 64));
+      CK(hipMemset(c2, 0, 4)); CK(hipMemset(ok2, 0, 4)); CK(hipMemset(c3, 0, 4)); CK(hipMemset(ok3, 0, 4));
+      hipLaunchKernelGGL(census, dim3(8 * k), dim3(512), 161000, sl, c3, (unsigned)(8 * k), ok3, xc3);
+      hipLaunchKernelGGL(census, dim3(nb), dim3(512), 131072, st, c2, (unsigned)nb, ok2, xc);
+      CK(hipStreamSynchronize(st));
+      CK(hipStreamSynchronize(sl));
+      unsigned hok, hok3, hx[256];
+      CK(hipMemcpy(&hok, ok2, 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(&hok3, ok3, 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hx, xc, 4 * nb, hipMemcpyDeviceToHost));
+      int per[8] = {0};
+      for (int i = 0; i < nb; i++) per[hx[i] & 7]++;
+      printf("k=%d complement: %3d tile-shaped workgroups: %3u saw all of them resident (chain side: %u of %d); per XCC:", k, nb, hok, hok3, 8 * k);
+      for (int x = 0; x < 8; x++) printf(" %d", per[x]);
+      printf("\n");
+      CK(hipStreamDestroy(st));
+      CK(hipStreamDestroy(sl));
+    }
+  }
   // low 8k bits = k CUs in every XCC?  (bit i -> XCC i % 8, the driver's symmetric map); complement = the other 32 - k
   for (int k : {1, 2, 4, 8}) {
     for (int comp = 0; comp < 2; comp++) {

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of ONE launch-free factorisation (BGP_PERSIST=1 BGP_PS_TRACE=1 are set here): where the diagonal-block
-chain waits, what the tile tasks spend their time on.  usage: persist_trace.py n d B"""
+"""In-kernel timeline of ONE launch-free factorisation in its default form (the chain workgroup solves block (J+1, J) and
+updates block (J+1, J+1) itself): what a block column costs the chain -- pf_block, the wait for the tile workers'
+pre-updates, its own solve + update -- and what the tile tasks spend their time on.  usage: persist_trace_fat.py n d B"""
 import ctypes as C
 import os
 import sys
@@ -27,55 +28,58 @@ lib.bgp_debug_ps_trace.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c
 dims = (C.c_int * 3)()
 lib.bgp_debug_ps_trace(ctx._h, dims, None, 0)
 Bt, nblk, total = dims[0], dims[1], dims[2]
-buf = np.zeros(Bt * nblk * 4 + total * 8, dtype=np.uint64)
+buf = np.zeros(Bt * nblk * 8 + total * 8, dtype=np.uint64)  # (total = owner slots)
 assert lib.bgp_debug_ps_trace(ctx._h, dims, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size) == 0
-ch = buf[: Bt * nblk * 4].reshape(Bt, nblk, 4).astype(np.int64)
-tl = buf[Bt * nblk * 4:].reshape(total, 8).astype(np.int64)
-t0 = min(ch[:, 0, 0].min(), tl[:, 0][tl[:, 0] > 0].min())
+ch = buf[: Bt * nblk * 8].reshape(Bt, nblk, 8).astype(np.int64)
+tl = buf[Bt * nblk * 8:].reshape(total, 8).astype(np.int64)
+t0 = ch[:, 0, 0].min()
 us = lambda v: (v - t0) / 100.0
-print(f"n={n} B={B} nblk={nblk} tasks={total}; all times in us from the first stamp")
-print("chain (matrix 0):  J | wait begin | wait end (=potrf start) | factorised | published |  wait   potrf  publish")
+print(f"n={n} B={B} nblk={nblk} tile tasks={total}; times in us")
+print("chain, matrix 0:  J | pf_block start | pf_block | wait for pre-updates | own solve + update | column")
 for J in range(nblk):
     a = ch[0, J]
-    print(f"  {J:2d} | {us(a[0]):9.1f} | {us(a[1]):9.1f} | {us(a[2]):9.1f} | {us(a[3]):9.1f} | {(a[1]-a[0])/100:6.1f} {(a[2]-a[1])/100:6.1f} {(a[3]-a[2])/100:6.1f}")
-w = (ch[:, :, 1] - ch[:, :, 0]) / 100.0
-p = (ch[:, :, 2] - ch[:, :, 1]) / 100.0
-r = (ch[:, :, 3] - ch[:, :, 2]) / 100.0
-print("chain means over matrices: wait %.1f us/col (cols>0: %.1f), potrf %.1f, publish %.1f; chain ends at %.1f us" % (
-    w.mean(), w[:, 1:].mean(), p.mean(), r.mean(), us(ch[:, -1, 3].max())))
-meta = tl[:, 7]
-J = (meta >> 24) & 0xff
-I = (meta >> 16) & 0xff
-diag = I == J
-done = tl[:, 6] > 0
-print("tile tasks done:", int(done.sum()), "of", total, " last finishes at %.1f us" % us(tl[:, 6].max()))
-def stat(name, v):
-    v = v[np.isfinite(v)]
-    if len(v):
-        print(f"  {name:46s} mean {v.mean():7.1f}  median {np.median(v):7.1f}  p90 {np.percentile(v, 90):7.1f}  max {v.max():7.1f}")
-od = done & ~diag
-dg = done & diag
-d01 = np.where(tl[:, 1] > 0, (tl[:, 1] - tl[:, 0]) / 100.0, np.nan)
-d12 = np.where((tl[:, 2] > 0) & (tl[:, 1] > 0), (tl[:, 2] - tl[:, 1]) / 100.0, np.nan)
-d23 = np.where(tl[:, 2] > 0, (tl[:, 3] - tl[:, 2]) / 100.0, np.nan)
-stat("off-diag: ticket -> first panels ready", d01[od])
-stat("off-diag: first ready -> last panel ready", d12[od])
-stat("off-diag: last panel ready -> C stored", d23[od])
-stat("off-diag: C stored (or ticket) -> W ready", ((tl[:, 4] - tl[:, 3]) / 100.0)[od])
-stat("off-diag: W ready -> solved", ((tl[:, 5] - tl[:, 4]) / 100.0)[od])
-stat("off-diag: solved -> published", ((tl[:, 6] - tl[:, 5]) / 100.0)[od])
-stat("off-diag: whole task", ((tl[:, 6] - tl[:, 0]) / 100.0)[od])
-stat("diag: last panel ready -> stored", d23[dg])
-stat("diag: stored -> published", ((tl[:, 6] - tl[:, 3]) / 100.0)[dg])
-# critical path of matrix 0: potrf(J) published -> X(J+1,J) published -> diag(J+1) published -> potrf(J+1) starts
-b = meta & 0x7fff
-print("critical path, matrix 0:  J | potrf published -> (J+1,J) W seen | -> solved | -> published | diag(J+1): last ready | -> stored | -> published | -> potrf(J+1) starts")
-for Jc in range(nblk - 1):
-    m1 = np.flatnonzero((b == 0) & (J == Jc) & (I == Jc + 1))
-    m2 = np.flatnonzero((b == 0) & (J == Jc + 1) & (I == Jc + 1))
-    if len(m1) < 1 or len(m2) < 1:
-        continue
-    pub = ch[0, Jc, 3]
-    wseen = tl[m1, 4].max(); solved = tl[m1, 5].max(); xpub = tl[m1, 6].max()
-    lr = tl[m2, 2].max(); st = tl[m2, 3].max(); dp = tl[m2, 6].max()
-    print(f"  {Jc:2d} | {(wseen-pub)/100:6.1f} | {(solved-wseen)/100:6.1f} | {(xpub-solved)/100:6.1f} | {(lr-xpub)/100:6.1f} | {(st-lr)/100:6.1f} | {(dp-st)/100:6.1f} | {(ch[0, Jc+1, 1]-dp)/100:6.1f}   total {(ch[0, Jc+1, 1]-pub)/100:6.1f}")
+    nxt = ch[0, J + 1, 0] if J + 1 < nblk else a[1]
+    last = J + 1 == nblk
+    print(f"  {J:2d} | {us(a[0]):9.1f} | {(a[1]-a[0])/100:6.1f} | " + ("" if last else f"{(a[2]-a[1])/100:6.1f} | {(a[3]-a[2])/100:6.1f} | {(nxt-a[0])/100:6.1f}"))
+for name, i0, i1 in (("flags -> solve issued", 2, 4), ("epilogue + X stored and drained", 4, 5), ("X -> LDS", 5, 6),
+                     ("diagonal update", 6, 7), ("tile -> LDS", 7, 3)):
+    v = (ch[:, :-1, i1] - ch[:, :-1, i0]) / 100.0
+    print(f"  own share: {name:34s} mean {v.mean():6.1f}  max {v.max():6.1f}")
+pf = (ch[:, :, 1] - ch[:, :, 0]) / 100.0
+wt = (ch[:, :-1, 2] - ch[:, :-1, 1]) / 100.0
+cr = (ch[:, :-1, 3] - ch[:, :-1, 2]) / 100.0
+print("means over matrices: pf_block %.1f us, wait %.1f (columns > 0: %.1f, max %.1f), own share %.1f; chains end at %.1f .. %.1f us" % (
+    pf.mean(), wt.mean(), wt[:, 1:].mean() if nblk > 2 else 0.0, wt.max(), cr.mean(), us(ch[:, -1, 1].min()), us(ch[:, -1, 1].max())))
+if total:
+    done = tl[:, 6] > 0
+    print("tile tasks done:", int(done.sum()), "of", total, " last finishes at %.1f us" % us(tl[:, 6].max()))
+    meta = tl[:, 7]
+    kind = (meta >> 28) & 0xf   # 0: panel solve S(I, J), 1: pre-update of block (I, I-1), 2: of block (I, I)
+    Jc = (meta >> 20) & 0xff
+    I = (meta >> 12) & 0xff
+    bm = meta & 0xfff
+
+    def stat(name, v):
+        v = v[np.isfinite(v)]
+        if len(v):
+            print(f"  {name:52s} mean {v.mean():7.1f}  median {np.median(v):7.1f}  p90 {np.percentile(v, 90):7.1f}  max {v.max():7.1f}")
+
+    d01 = np.where(tl[:, 1] > 0, (tl[:, 1] - tl[:, 0]) / 100.0, np.nan)
+    d23 = np.where(tl[:, 2] > 0, (tl[:, 3] - tl[:, 2]) / 100.0, np.nan)
+    for nm, sel in (("S d=2", done & (kind == 0) & (I - Jc == 2)), ("S d>=3", done & (kind == 0) & (I - Jc >= 3)),
+                    ("P", done & (kind == 1)), ("Dg", done & (kind == 2))):
+        if not sel.any():
+            continue
+        stat(f"{nm}: ticket -> first panels ready", d01[sel])
+        stat(f"{nm}: last panel ready -> block stored", d23[sel])
+        if nm.startswith("S"):
+            stat(f"{nm}: stored (or ticket) -> W ready", ((tl[:, 4] - tl[:, 3]) / 100.0)[sel])
+            stat(f"{nm}: W ready -> solved", ((tl[:, 5] - tl[:, 4]) / 100.0)[sel])
+        stat(f"{nm}: whole task", ((tl[:, 6] - tl[:, 0]) / 100.0)[sel])
+    # slack of the two hand-overs to the chain, matrix 0: published this long before pf_block(I-1) ended (the chain asks then)
+    for nm, k in (("P", 1), ("Dg", 2)):
+        sel = np.flatnonzero(done & (kind == k) & (bm == 0))
+        if len(sel):
+            sel = sel[np.argsort(I[sel])]
+            slack = (ch[0, I[sel] - 1, 1] - tl[sel, 6]) / 100.0
+            print(f"  {nm}(I) of matrix 0 published this long before the chain asked (us, I = {I[sel][0]} ..):", " ".join(f"{v:.0f}" for v in slack))
