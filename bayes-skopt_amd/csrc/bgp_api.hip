@@ -370,10 +370,6 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->hstatus) (void)hipHostFree(c->hstatus);
   if (c->hh) (void)hipHostFree(c->hh);
   if (c->hwarp) (void)hipHostFree(c->hwarp);
-  for (int k = 0; k < 9; k++) {
-    if (c->ps_chain[k]) (void)hipStreamDestroy(c->ps_chain[k]);
-    if (c->ps_tile[k]) (void)hipStreamDestroy(c->ps_tile[k]);
-  }
   if (c->ps_ev0) (void)hipEventDestroy(c->ps_ev0);
   if (c->ps_eva) (void)hipEventDestroy(c->ps_eva);
   if (c->ps_evb) (void)hipEventDestroy(c->ps_evb);
@@ -412,12 +408,15 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
 
 static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status);
 
-// Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (measured on MI355X, DESIGN.md
-// section 6): off until measured.
+// Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
+// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free):
+//   n = 1024: 24 matrices 1.06, 32: 1.09, 40: 1.01;  1280: 16: 1.06, 32: 1.10;  1536: 4: 1.01, 8: 1.09, 16: 1.19, 24: 1.12, 32: 1.02;
+//   n = 2048: 1: 0.98, 4: 1.09, 8: 1.23, 9: 1.35, 16: 1.14, 24: 1.05, 32: 1.00;  3072: 1: 1.05, 4: 1.08, 8: 1.18, 16: 1.04;
+//   n = 4096: 1: 1.12, 2: 1.08, 4: 1.05, 8: 1.08;  below n = 1024 (300 x 8: 0.72, 512 x 50: 0.89, 640 x 1: 0.81) and for 975 x 50
+//   (1.01) the launches are as fast or faster.
+// So: at least 8 block columns, at least 4 matrices (or 20 block columns), matrices x block columns <= 384.
 static bool bgp_persist_auto(const bgp_ctx* c, int nb) {
-  (void)c;
-  (void)nb;
-  return false;
+  return c->nblk >= 8 && (nb >= 4 || c->nblk >= 20) && nb * c->nblk <= 384;
 }
 
 // A persistent call whose waits timed out (error word != 0 behind the synchronisation) is redone on the multi-launch
@@ -509,7 +508,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
     // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
     // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-    const bool use_ps = !fused_small && !warp && !fused_gram && !c->timing && !c->ps_disabled && bgp_persist_fits(c, nb) &&
+    const bool use_ps = !fused_small && !fused_gram && !c->timing && !c->ps_disabled && bgp_persist_fits(c, nb) &&
                         (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb)));
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {
@@ -530,7 +529,12 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       } else {
         rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
         if (rc) return rc;
-        rc = bgp_launch_cholesky(c, nb, 0);
+        if (use_ps) {
+          rc = bgp_launch_cholesky_persist(c, nb);
+          if (!rc) c->ps_inflight = 1;
+        } else {
+          rc = bgp_launch_cholesky(c, nb, 0);
+        }
       }
       if (rc) return rc;
     } else if (use_ps) {

@@ -850,6 +850,18 @@ static int ps_chain_k(int B) {
 // Can this batch take the launch-free path?  (at least two block columns; a chain CU per matrix)
 int bgp_persist_fits(bgp_ctx* c, int B) { return B >= 1 && B <= 64 && c->nblk >= 2 && c->nblk <= 255; }
 
+// The CU-masked stream pairs are PROCESS-wide (one pair per device and chain width k), never per context: every such
+// stream is a hardware queue of its own, and with a few dozen of them alive (six contexts that had each used three widths)
+// the queues were time-sliced -- chain and tile kernel of one call no longer ran side by side, the path slowed down and
+// finally timed out (tools/lf_state_probe.py).  Calls of different contexts share the pair; ps_mutex keeps the order of
+// their kernels the same on both streams (chain A, chain B on one and tile B, tile A on the other would wait for each other).
+#include <mutex>
+static std::mutex ps_mutex;
+struct PsStreams {
+  hipStream_t chain[9] = {nullptr}, tile[9] = {nullptr};
+};
+static PsStreams ps_streams[BGP_MAX_DEVICES];
+
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
 // this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes
 // c->stream wait for both.  The error word travels to pinned memory behind them (ctx->ps_herr): != 0 after the
@@ -865,7 +877,13 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   // XCD, the same number in every shader engine; with 31 / 30 / 29 a few of them start when others have ended
   // (tools/cumask_probe.hip).  The ticket scheme does not need them all resident: it only loses those few workers.)
   const int tile_wgs = 8 * (32 - k);
-  if (!c->ps_chain[k]) {
+  if (c->device < 0 || c->device >= BGP_MAX_DEVICES) {
+    bgp_set_error("bgp_launch_cholesky_persist: device %d", c->device);
+    return BGP_ERR_INVALID;
+  }
+  std::lock_guard<std::mutex> guard(ps_mutex);
+  PsStreams& pst = ps_streams[c->device];
+  if (!pst.chain[k]) {
     // mask bit i selects one CU of XCD i % 8 (the driver's symmetric map; tools/cumask_probe.hip): the low 8k bits are
     // k CUs in every XCD
     uint32_t ma[8], mb[8];
@@ -874,8 +892,8 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       ma[i / 32] |= 1u << (i % 32);
       mb[i / 32] &= ~(1u << (i % 32));
     }
-    BGP_HIP(hipExtStreamCreateWithCUMask(&c->ps_chain[k], 8, ma));
-    BGP_HIP(hipExtStreamCreateWithCUMask(&c->ps_tile[k], 8, mb));
+    BGP_HIP(hipExtStreamCreateWithCUMask(&pst.chain[k], 8, ma));
+    BGP_HIP(hipExtStreamCreateWithCUMask(&pst.tile[k], 8, mb));
   }
   if (!c->ps_ev0) {
     BGP_HIP(hipEventCreateWithFlags(&c->ps_ev0, hipEventDisableTiming));
@@ -951,7 +969,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       c->ps_trace_total = a.total;
     }
   }
-  hipStream_t sa = c->ps_chain[k], sb = c->ps_tile[k];
+  hipStream_t sa = pst.chain[k], sb = pst.tile[k];
   BGP_HIP(hipEventRecord(c->ps_ev0, c->stream));
   BGP_HIP(hipStreamWaitEvent(sa, c->ps_ev0, 0));
   BGP_HIP(hipStreamWaitEvent(sb, c->ps_ev0, 0));

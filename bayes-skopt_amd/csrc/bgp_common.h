@@ -161,7 +161,6 @@ struct bgp_ctx {
   // launch-free factorisation of small batches: CU-masked stream pairs (k CUs per XCD for the diagonal-block chain,
   // the other 32 - k for the tile workers), created on first use; flag block; events
   int persist = -1;          // env BGP_PERSIST: 0 never, 1 whenever possible, -1 (unset) automatic by batch size
-  hipStream_t ps_chain[9] = {nullptr}, ps_tile[9] = {nullptr};
   hipEvent_t ps_ev0 = nullptr, ps_eva = nullptr, ps_evb = nullptr;
   unsigned* ps_flags = nullptr;
   size_t cap_psflags = 0;
@@ -225,6 +224,7 @@ static inline void bgp_tcollect(bgp_ctx* c) {
   c->evcat.clear();
 }
 
+#define BGP_MAX_DEVICES 64
 // ---- launch-free factorisation of small batches (bgp_chol.hip: ps_chain_kernel, bgp_syrk4.hip: ps_tile_kernel) ----
 // Flag block of one persistent factorisation (32-bit words, zeroed by a memset node in front of every call):
 //   [PS_TICKET + 2 + 8 pool + x]  next task of the tile kernel's list (pool, XCD x)      [PS_ERROR]  != 0: a wait timed out: everybody leaves

@@ -889,10 +889,7 @@ static void free_child(bgp_ctx* w) {
   if (w->dacc) (void)hipFree(w->dacc);
   if (w->dlml) (void)hipFree(w->dlml);
   if (w->dstatus) (void)hipFree(w->dstatus);
-  for (int k = 0; k < 9; k++) {  // (launch-free factorisation of the covariance: its own masked streams, flags, events)
-    if (w->ps_chain[k]) (void)hipStreamDestroy(w->ps_chain[k]);
-    if (w->ps_tile[k]) (void)hipStreamDestroy(w->ps_tile[k]);
-  }
+  // (launch-free factorisation of the covariance: its own flags and events; the masked streams are process-wide)
   if (w->ps_ev0) (void)hipEventDestroy(w->ps_ev0);
   if (w->ps_eva) (void)hipEventDestroy(w->ps_eva);
   if (w->ps_evb) (void)hipEventDestroy(w->ps_evb);
