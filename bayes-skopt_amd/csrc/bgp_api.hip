@@ -408,16 +408,7 @@ static int factor_chunk(bgp_ctx* c, int B, const double* h, int full_square) {
 
 static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status);
 
-// Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
-// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free):
-//   n = 1024: 24 matrices 1.06, 32: 1.09, 40: 1.01;  1280: 16: 1.06, 32: 1.10;  1536: 4: 1.01, 8: 1.09, 16: 1.19, 24: 1.12, 32: 1.02;
-//   n = 2048: 1: 0.98, 4: 1.09, 8: 1.23, 9: 1.35, 16: 1.14, 24: 1.05, 32: 1.00;  3072: 1: 1.05, 4: 1.08, 8: 1.18, 16: 1.04;
-//   n = 4096: 1: 1.12, 2: 1.08, 4: 1.05, 8: 1.08;  below n = 1024 (300 x 8: 0.72, 512 x 50: 0.89, 640 x 1: 0.81) and for 975 x 50
-//   (1.01) the launches are as fast or faster.
-// So: at least 8 block columns, at least 4 matrices (or 20 block columns), matrices x block columns <= 384.
-static bool bgp_persist_auto(const bgp_ctx* c, int nb) {
-  return c->nblk >= 8 && (nb >= 4 || c->nblk >= 20) && nb * c->nblk <= 384;
-}
+static bool bgp_persist_auto(const bgp_ctx* c, int nb) { return bgp_persist_auto_rule(c->nblk, nb); }
 
 // A persistent call whose waits timed out (error word != 0 behind the synchronisation) is redone on the multi-launch
 // path, once and loudly; the context stays on that path afterwards.

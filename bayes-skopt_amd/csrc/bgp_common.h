@@ -251,6 +251,14 @@ struct PsArgs {
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
 };
 static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (3 + nblk); }
+// Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
+// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free):
+//   n = 1024: 24 matrices 1.06, 32: 1.09, 40: 1.01;  1280: 16: 1.06, 32: 1.10;  1536: 4: 1.01, 8: 1.09, 16: 1.19, 24: 1.12, 32: 1.02;
+//   n = 2048: 1: 0.98, 4: 1.09, 8: 1.23, 9: 1.35, 16: 1.14, 24: 1.05, 32: 1.00;  3072: 1: 1.05, 4: 1.08, 8: 1.18, 16: 1.04;
+//   n = 4096: 1: 1.12, 2: 1.08, 4: 1.05, 8: 1.08;  one 10 112 x 10 112 covariance (sample_y): 1.15;  below n = 1024 (300 x 8:
+//   0.72, 512 x 50: 0.89, 640 x 1: 0.81) and for 975 x 50 (1.01) the launches are as fast or faster.
+// So: at least 8 block columns, at least 4 matrices (or 20 block columns), matrices x block columns <= 384.
+static inline bool bgp_persist_auto_rule(int nblk, int nb) { return nblk >= 8 && (nb >= 4 || nblk >= 20) && nb * nblk <= 384; }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
 void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg);

@@ -987,31 +987,38 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
     // P = K_* K^-1, then cov = K_** - P K_*^T in the child's matrix, lower tiles only (all the factorisation reads):
     // both products on the LDS-DMA ring (gemm4_kernel)
     bgp_launch_gemm4(c->stream, 0, dKs, Kinv, npad, mpad, npad, npad, dP, npad, 1, 0, 0, 0, nullptr);
-    if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, w->dK, mpad, 0))) break;
-    hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, w->dK, mpad, m,
-                       std::exp(h_kernel[d + 1]));
-    bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, 1, 0, 0, 0, nullptr);
-    hipLaunchKernelGGL(cov_prepare_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
-    SY(hipMemsetAsync(w->dyw, 0, (size_t)mpad * sizeof(double), c->stream));
-    SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
-    // (BGP_PERSIST=1: the covariance's factorisation -- ONE matrix of 79 block columns at 10 000 candidates, the longest
-    // launch chain of a tell -- on the launch-free path; a timed-out wait is an error here, the matrix is gone)
-    const bool ps = c->persist == 1 && bgp_persist_fits(w, 1);
-    if (ps) {
-      w->persist = 1;
-      if ((rc = bgp_launch_cholesky_persist(w, 1))) break;
-    } else if ((rc = bgp_launch_cholesky(w, 1, 0))) {
-      break;
-    }
     int st = 0;
-    SY(bgp_memcpy_async(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    SY(bgp_stream_sync(c->stream));
-    if (ps && w->ps_herr && *w->ps_herr != 0) {
-      *w->ps_herr = 0;
-      bgp_set_error("bgp_sample_y: the launch-free factorisation timed out (BGP_PS_TIMEOUT_MS)");
-      rc = BGP_ERR_STATE;
+    for (int attempt = 0; attempt < 2 && !rc; attempt++) {
+      if ((rc = bgp_launch_kcross(c, dhk, m, dXq, m, dXq, w->dK, mpad, 0))) break;
+      hipLaunchKernelGGL(add_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, c->stream, w->dK, mpad, m,
+                         std::exp(h_kernel[d + 1]));
+      bgp_launch_gemm4(c->stream, 1, dP, dKs, npad, mpad, mpad, npad, w->dK, mpad, 1, 0, 0, 0, nullptr);
+      hipLaunchKernelGGL(cov_prepare_kernel, dim3(1024), dim3(256), 0, c->stream, w->dK, m, mpad, jitter);
+      SY(hipMemsetAsync(w->dyw, 0, (size_t)mpad * sizeof(double), c->stream));
+      SY(hipMemsetAsync(w->dstatus, 0, sizeof(int), c->stream));
+      // the covariance's factorisation -- ONE matrix of 79 block columns at 10 000 candidates, the longest launch chain of
+      // a tell -- on the launch-free path (12.6 -> 10.9 ms per call, same draws); should a wait time out, the covariance
+      // is rebuilt and factorised by launches, and the context stays on them
+      const bool ps = !c->ps_disabled && bgp_persist_fits(w, 1) &&
+                      (c->persist == 1 || (c->persist == -1 && bgp_persist_auto_rule(w->nblk, 1)));
+      if (ps) {
+        w->persist = 1;
+        if ((rc = bgp_launch_cholesky_persist(w, 1))) break;
+      } else if ((rc = bgp_launch_cholesky(w, 1, 0))) {
+        break;
+      }
+      SY(bgp_memcpy_async(&st, w->dstatus, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      SY(bgp_stream_sync(c->stream));
+      if (ps && w->ps_herr && *w->ps_herr != 0) {
+        *w->ps_herr = 0;
+        c->ps_disabled = 1;
+        fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); the "
+                        "covariance is rebuilt and factorised on the multi-launch path, which this context keeps from now on\n");
+        continue;
+      }
       break;
     }
+    if (rc) break;
     if (st != 0) {
       bgp_set_error("bgp_sample_y: predictive covariance not positive definite at pivot %d (jitter %.3g)", st, jitter);
       rc = BGP_ERR_NOTPD;

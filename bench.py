@@ -351,8 +351,8 @@ def small_batch_shards(bask_lib, X, y, pos_H, device, sizes=(128, 64, 32, 16), r
 
 
 def launch_free(bask_lib, device, shapes=((4096, 32, 1), (2048, 16, 16), (1024, 8, 32)), reps=15):
-    """The launch-free factorisation of small batches (opt-in) next to the launch schedule on the
-    same contexts: wall ms per LML call and whether the log-likelihoods are the same bits."""
+    """The launch-free factorisation of small batches (automatic at these sizes) next to the launch
+    schedule on the same contexts: wall ms per LML call and whether the log-likelihoods are the same bits."""
     out = {}
     for n, d, B in shapes:
         X, y = synth(n, d, seed=0)

@@ -97,3 +97,39 @@ def test_mcmc_chain_is_unchanged_by_the_launch_free_path():
         assert res.returncode == 0 and "timed out" not in res.stderr, res.stderr[-2000:]
         outs.append([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1])
     assert outs[0] == outs[1]
+
+
+_SY_CHILD = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import bayes_skopt_amd
+from bayes_skopt_amd import _lib
+rng = np.random.RandomState(0)
+n, d, m = 300, 3, 1500
+X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
+ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=4)
+h = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+ctx.posterior(h[None, :])
+hk = h.copy(); hk[-1] = -np.inf
+Xq = rng.uniform(size=(m, d)); z = rng.randn(3, m)
+outs = [ctx.sample_y(0, hk, Xq, z, jitter=1e-8) for _ in range(3)]
+print("RESULT " + json.dumps([[float(v).hex() for v in o.ravel()[::97]] + [float(o.sum()).hex()] for o in outs]))
+"""
+
+
+def test_sample_y_covariance_on_the_launch_free_path_and_its_fallback():
+    """The m x m predictive covariance of sample_y (one matrix, 12 block columns here, 79 at config E's 10 000 candidates)
+    factorised launch-free: same draws, bit for bit; and when a wait times out the covariance is rebuilt and factorised by
+    launches -- same draws again, one warning."""
+    def run(env):
+        res = subprocess.run([sys.executable, "-c", _SY_CHILD % ROOT], env=dict(os.environ, **env), capture_output=True, text=True,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
+
+    ref, _ = run({"BGP_PERSIST": "0"})
+    got, err = run({"BGP_PERSIST": "1"})
+    assert "timed out" not in err and got == ref
+    got, err = run({"BGP_PERSIST": "1", "BGP_PS_TIMEOUT_TICKS": "200"})
+    assert err.count("timed out") == 1 and got == ref, err[-1500:]

@@ -12,6 +12,10 @@ def show(tag):
     print(f"{tag:40s}", "  ".join(f"{k}: {v['launches_ms']:.3f} / {v['launch_free_ms']:.3f}" for k, v in r.items()), flush=True)
 
 show("fresh")
+from bayes_skopt_amd import distributed
+distributed.init_process_group(device=0)
+print("group:", distributed.group_info(0))
+show("after init_process_group (one rank)")
 X, y = bench.synth(2048, 16, seed=0)
 ctx = _lib.Context(X, y, 1e-10, max_batch=128, device=0)
 H = np.concatenate([[0.0], np.full(16, np.log(0.3)), [np.log(0.01)]]) + 0.05 * np.random.RandomState(5).randn(128, 18)
@@ -30,6 +34,15 @@ show("after the MFMA peak probe")
 t0 = time.time()
 a = np.random.rand(3000, 3000); (a @ a).sum()
 show("after a host BLAS call")
+gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(16))), random_state=0, device=0)
+gp2.fit(X, y, n_desired_samples=256 * 5, n_burnin=2, n_walkers_per_thread=256, progress=False)
+show("after a BayesGPR.fit at n = 2048 (alive)")
+del gp2
+show("... deleted")
+bench.config_d_roofline(_lib, 0, 76.0)
+show("after config D's timed pass")
+sh = bench.small_batch_shards(_lib, X, y, H[:128], 0)
+show("after small_batch_shards")
 keep = []
 for i in range(6):
     Xs, ys = bench.synth(1024, 8, seed=i)
