@@ -4,6 +4,8 @@ The library is built in-tree by ``__graft_entry__.build()`` / ``make -C bayes-sk
 There is NO CPU fallback: if the shared object is missing, or no gfx950 device is visible when
 a context is created, the product path raises.
 """
+import atexit
+import weakref
 import ctypes as C
 import os
 
@@ -131,6 +133,20 @@ ACQ_EI, ACQ_MEAN, ACQ_LCB, ACQ_STD = 0, 1, 2, 3  # include/bgp.h BGP_ACQ_*
 ACQ_MAX = 8
 
 
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_contexts():
+    # contexts still alive when the interpreter goes down are closed while the HIP runtime is still there (the last one
+    # takes the library's process-wide streams with it: left alive they crashed a profiler's teardown)
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
 class Context:
     """Owns one device context: training set resident in HBM + the batched-Cholesky workspace."""
 
@@ -152,6 +168,7 @@ class Context:
                                   C.byref(h)), "bgp_ctx_create")
         self._h = h
         self._lib = lib
+        _live_contexts.add(self)
         self._pending, self._pending_H = 0, None  # batch handed to lml_submit and not yet collected
         self._timing = False
         # canonical vectors of the posteriors whose K^-1 / alpha are resident on the device

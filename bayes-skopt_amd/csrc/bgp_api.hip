@@ -279,6 +279,7 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     delete c;
     return BGP_ERR_HIP;
   }
+  bgp_ps_streams_retain();
   {
     // walker-group streams: BGP_STREAMS=k forces k groups; unset = automatic (two groups for batches of
     // >= 64 matrices, where the second group's kernels fill the tail of the first group's launches: +3.7 %
@@ -382,6 +383,7 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  bgp_ps_streams_release();  // (the last context takes the process-wide masked streams of the launch-free path with it)
   delete c;
 }
 

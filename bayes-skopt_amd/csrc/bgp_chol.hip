@@ -861,6 +861,28 @@ struct PsStreams {
   hipStream_t chain[9] = {nullptr}, tile[9] = {nullptr};
 };
 static PsStreams ps_streams[BGP_MAX_DEVICES];
+static int ps_live_contexts = 0;
+void bgp_ps_streams_retain() {
+  std::lock_guard<std::mutex> guard(ps_mutex);
+  ps_live_contexts++;
+}
+// (they go with the last context: a masked stream left alive at process exit crashed rocprofv3's teardown)
+void bgp_ps_streams_release() {
+  std::lock_guard<std::mutex> guard(ps_mutex);
+  if (--ps_live_contexts > 0) return;
+  ps_live_contexts = 0;
+  int cur = 0;
+  const bool have = hipGetDevice(&cur) == hipSuccess;
+  for (int dev = 0; dev < BGP_MAX_DEVICES; dev++)
+    for (int k = 0; k < 9; k++) {
+      if (!ps_streams[dev].chain[k] && !ps_streams[dev].tile[k]) continue;
+      (void)hipSetDevice(dev);
+      if (ps_streams[dev].chain[k]) (void)hipStreamDestroy(ps_streams[dev].chain[k]);
+      if (ps_streams[dev].tile[k]) (void)hipStreamDestroy(ps_streams[dev].tile[k]);
+      ps_streams[dev].chain[k] = ps_streams[dev].tile[k] = nullptr;
+    }
+  if (have) (void)hipSetDevice(cur);
+}
 
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
 // this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes

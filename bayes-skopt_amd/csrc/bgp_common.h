@@ -263,6 +263,8 @@ int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
 void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg);
 int bgp_persist_fits(bgp_ctx* ctx, int B);
+void bgp_ps_streams_retain();
+void bgp_ps_streams_release();
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);
