@@ -232,7 +232,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_K", "BGP_PS_NCRIT", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_NCRIT", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -279,7 +279,6 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     delete c;
     return BGP_ERR_HIP;
   }
-  bgp_ps_streams_retain();
   {
     // walker-group streams: BGP_STREAMS=k forces k groups; unset = automatic (two groups for batches of
     // >= 64 matrices, where the second group's kernels fill the tail of the first group's launches: +3.7 %
@@ -371,9 +370,6 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->hstatus) (void)hipHostFree(c->hstatus);
   if (c->hh) (void)hipHostFree(c->hh);
   if (c->hwarp) (void)hipHostFree(c->hwarp);
-  if (c->ps_ev0) (void)hipEventDestroy(c->ps_ev0);
-  if (c->ps_eva) (void)hipEventDestroy(c->ps_eva);
-  if (c->ps_evb) (void)hipEventDestroy(c->ps_evb);
   free_dev(c->ps_flags);
   free_dev(c->ps_trace);
   if (c->ps_herr) (void)hipHostFree(c->ps_herr);
@@ -383,7 +379,6 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  bgp_ps_streams_release();  // (the last context takes the process-wide masked streams of the launch-free path with it)
   delete c;
 }
 

@@ -56,530 +56,7 @@ extern "C" int bgp_debug_potrf_trace(unsigned long long* out) {
 #else
 #define PF_T(i)
 #endif
-#define PF_LD 130   // LDS leading dimension of the 128x128 block (== 2 mod 32: conflict-free MFMA operand reads)
-#define PF_MLD 18   // leading dimension of the 16x16 inverse blocks
-
-// 16x16 micro-Cholesky fused with the inverse of its factor, one matrix row per lane (lane & 15), all
-// 16 pivots unrolled at compile time.  Pivot J broadcasts L[c][J] (lane c of register a[J]) to the whole
-// 16-lane row with ONE 64-bit DPP move (row_newbcast) and uses it twice:
-//   a[c]    -= L[lane][J] * L[c][J]          right-looking update of the block (lane = row)
-//   macc[c] += L[c][J] * M[J][lane]          forward substitution for M = L^-1 (lane = column of M)
-// so no SGPR round trip (v_readlane pairs) and the two dependency chains interleave.
-template <int C>
-static __device__ __forceinline__ double bc16(double v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xF, 0xF, false);  // row_newbcast:C (all lanes written)
-}
-
-// One fused instruction per update: v_fmac_f64 with a DPP row broadcast on its first source (64-bit DPP
-// supports exactly this control on gfx90a+):  D += bcast_C(a[J]) * S1.
-#define PF_FMAC_BCAST(D, SRC, S1, C)                                                                  \
-  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(D) : "v"(SRC), "v"(S1), "n"(C))
-
-template <int J, int C>
-static __device__ __forceinline__ void micro_cols(double (&a)[16], double (&macc)[16], double naj, double mj) {
-  if constexpr (C < 16) {
-    PF_FMAC_BCAST(a[C], a[J], naj, C);     // a[C]    -= L[lane][J] * L[C][J]
-    PF_FMAC_BCAST(macc[C], a[J], mj, C);   // macc[C] += L[C][J] * M[J][lane]
-    micro_cols<J, C + 1>(a, macc, naj, mj);
-  }
-}
-
-template <int J>
-static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr,
-                                                      int& bad) {
-  if constexpr (J < 16) {
-    asm volatile("s_nop 1");  // a[J] was last written by the inline-asm updates above: DPP read hazard (2 wait states)
-    const double djj = bc16<J>(a[J]);
-    bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
-    // sqrt and 1/sqrt together from the hardware seed by one coupled (Goldschmidt) step: three dependent
-    // operations on the pivot chain instead of the library rsqrt's six
-    const double y0 = __builtin_amdgcn_rsq(djj);
-    const double g = djj * y0, h = 0.5 * y0;
-    const double r = fma(-g, h, 0.5);
-    const double dj = fma(g, r, g);        // sqrt(djj)
-    const double hh = fma(h, r, h);
-    const double inv = hh + hh;            // 1 / sqrt(djj)
-    a[J] = (lr == J) ? dj : a[J] * inv;
-    const double naj = -a[J];
-    const double mj = (((lr == J) ? 1.0 : 0.0) - macc[J]) * inv;  // M[J][lane]
-    mrow[J] = mj;
-    if constexpr (J < 15) asm volatile("s_nop 1" ::"v"(a[J]), "v"(naj), "v"(mj));  // VALU write -> DPP read
-    micro_cols<J, J + 1>(a, macc, naj, mj);
-    micro_chol_inv<J + 1>(a, macc, mrow, lr, bad);
-  }
-}
-
-// acc (+/-)= sum_{t < nt} A_t B_t^T for 16x16 blocks whose operands sit in LDS rows `pa` / `pb` (pointers
-// already offset to the lane's row and k-group) and advance by one 16-wide block column per term.  The
-// next term's eight operand reads are issued before the current term's four MFMAs (one wave per SIMD
-// here: nothing else hides the LDS latency).
-template <int NEG>
-static __device__ __forceinline__ d4 mma_run(d4 acc, const double* __restrict__ pa, const double* __restrict__ pb,
-                                             int nt) {
-  if (nt <= 0) return acc;
-  double a0[4], b0[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; kk++) {
-    a0[kk] = pa[kk * 4];
-    b0[kk] = pb[kk * 4];
-  }
-  for (int t = 0; t < nt; t++) {
-    double a1[4], b1[4];
-    const int tn = (t + 1 < nt) ? t + 1 : t;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      a1[kk] = pa[tn * 16 + kk * 4];
-      b1[kk] = pb[tn * 16 + kk * 4];
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -a0[kk] : a0[kk], b0[kk], acc, 0, 0, 0);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      a0[kk] = a1[kk];
-      b0[kk] = b1[kk];
-    }
-  }
-  return acc;
-}
-
-// Row I of W = L^-1, block J <= I:  W[I][I] = M_I,  W[I][J] = -M_I * S,  S = sum_{K=J}^{I-1} L[I][K] W[K][J].
-// pf_wsum forms the terms K = J .. Kend-1 of S (L[I][I-1] comes from `xrow` while the panel wave's in-place
-// write of that block is still pending); pf_wfinish multiplies by -M_I (the C-layout sum is directly the B
-// operand), writes the block to global memory (row-major W, lower blocks only: the panel solves skip k-steps
-// beyond a column block) and transposed into LDS block (J, I).
-static __device__ __forceinline__ d4 pf_wsum(d4 acc, const double* __restrict__ s, const double* __restrict__ Minv,
-                                             const double* __restrict__ xrow, int I, int J, int Kbeg, int Kend,
-                                             int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  if (Kbeg == J && Kbeg < Kend) {  // W[J][J] = M_J
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const double av = (J == I - 1 && xrow) ? xrow[lr * PF_MLD + kk * 4 + lk] : s[(I * 16 + lr) * PF_LD + J * 16 + kk * 4 + lk];
-      const double bv = Minv[J * 16 * PF_MLD + (kk * 4 + lk) * PF_MLD + lr];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-    Kbeg++;
-  }
-  int Kmid = Kend;
-  if (xrow && Kend == I) Kmid = I - 1;  // the last term's A operand lives in xrow
-  if (Kmid > Kbeg)
-    acc = mma_run<0>(acc, &s[(I * 16 + lr) * PF_LD + Kbeg * 16 + lk], &s[(J * 16 + lr) * PF_LD + Kbeg * 16 + lk],
-                     Kmid - Kbeg);
-  if (Kmid < Kend && Kmid >= Kbeg) {
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const double av = xrow[lr * PF_MLD + kk * 4 + lk];
-      const double bv = s[(J * 16 + lr) * PF_LD + Kmid * 16 + kk * 4 + lk];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-  }
-  return acc;
-}
-
-static __device__ __forceinline__ void pf_wfinish(d4 acc, double* __restrict__ s, const double* __restrict__ Minv,
-                                                  double* __restrict__ Wg, int I, int J, int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  d4 wn;
-  if (J == I) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) wn[r] = Minv[I * 16 * PF_MLD + (lk + 4 * r) * PF_MLD + lr];
-  } else {
-    wn = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const double av = -Minv[I * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
-      wn = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[kk], wn, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) s[(J * 16 + lr) * PF_LD + I * 16 + lk + 4 * r] = wn[r];
-  }
-  if (Wg) {
-#pragma unroll
-    for (int r = 0; r < 4; r++) Wg[(I * 16 + lk + 4 * r) * 128 + J * 16 + lr] = wn[r];
-  }
-}
-
-#define PF_THREADS 512
-// GEN (fused small-n LML, n <= 128: SURVEY.md section 7 step 5): the workgroup GENERATES the jittered Gram matrix of
-// its walker straight into the LDS tile (same arithmetic, in the same order, as kbuild_tile: scaled inputs, squared
-// differences in dimension order, stationary kernel, exact diagonal, identity padding) instead of loading a tile
-// another launch wrote, takes y from the context and stores nothing but lml / status: ONE launch per LML batch, no
-// Gram matrix in HBM.  `gen` carries the extra inputs.
-struct PfGen {
-  const double* X;      // n x d training inputs (original or warped)
-  const double* alpha;  // n diagonal terms
-  const double* H;      // B x (d + 2) canonical hyper-parameters
-  const double* y;      // npad right-hand side (zero padded)
-  int d;
-};
-
-template <int STAT, int FORM>
-static __device__ __forceinline__ void pf_generate_tile(double* __restrict__ s, double* __restrict__ xs,
-                                                        const PfGen& g, const double* __restrict__ h, int n, int tid) {
-  // thread (tx, ty) of a 16 x 32 grid owns rows ty + 32 r (r < 4) and columns tx + 16 c (c < 8)
-  const int tx = tid & 15, ty = tid >> 4;
-  double acc[4][8];
-#pragma unroll
-  for (int r = 0; r < 4; r++)
-#pragma unroll
-    for (int c = 0; c < 8; c++) acc[r][c] = 0.0;
-  const int d = g.d;
-  for (int k0 = 0; k0 < d; k0 += 16) {
-    const int kc = min(16, d - k0);
-    __syncthreads();
-    for (int idx = tid; idx < kc * 128; idx += PF_THREADS) {
-      const int row = idx / kc, kk = idx - row * kc;
-      xs[kk * 128 + row] = (row < n) ? g.X[(size_t)row * d + k0 + kk] / exp(h[1 + k0 + kk]) : 0.0;
-    }
-    __syncthreads();
-    for (int kk = 0; kk < kc; kk++) {
-      double a[4], bb[8];
-#pragma unroll
-      for (int r = 0; r < 4; r++) a[r] = xs[kk * 128 + ty + 32 * r];
-#pragma unroll
-      for (int c = 0; c < 8; c++) bb[c] = xs[kk * 128 + tx + 16 * c];
-#pragma unroll
-      for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const double df = a[r] - bb[c];
-          acc[r][c] = fma(df, df, acc[r][c]);
-        }
-    }
-  }
-  {
-#pragma clang fp contract(off)
-  const double cst = exp(h[0]), s2 = exp(h[d + 1]);
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int gi = ty + 32 * r;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int gj = tx + 16 * c;
-      double v;
-      if (gi >= n || gj >= n) {
-        v = (gi == gj) ? 1.0 : 0.0;
-      } else if (gi == gj) {
-        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
-        v = (base + s2) + g.alpha[gi];
-      } else {
-        const double sv = kb_stationary<STAT>(acc[r][c]);
-        v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
-      }
-      s[gi * PF_LD + gj] = v;
-    }
-  }
-}
-}
-
-// The workgroup's LDS: ONE set of function-scope arrays that pf_block and the chain kernel's own steps (pf_chain_next)
-// both reach through this accessor (157.6 of the 160 KB of a CU).
-struct PfLds {
-  double* s;      // 128 x PF_LD: the diagonal block; lower triangle -> L, upper triangle <- W^T block by block
-  double* Minv;   // 8 inverses of the 16 x 16 diagonal blocks (= the diagonal blocks of W)
-  double* xrow;   // 2 x (16 x PF_MLD): X_{sb,sb-1} in operand layout, double-buffered by the parity of sb
-  double* ylds;   // right-hand side of the block
-  double* zpart;  // 4 x 128 partial sums of z = W y; [0, 128) holds z itself when pf_block returns
-  double* red;
-  int* fail;
-};
-static __device__ __forceinline__ PfLds pf_lds() {
-  __shared__ double s[128 * PF_LD];
-  __shared__ double Minv[8 * 16 * PF_MLD];
-  __shared__ double xrow[2 * 16 * PF_MLD];
-  __shared__ double ylds[128];
-  __shared__ double zpart[4 * 128];
-  __shared__ double red[16];
-  __shared__ int fail_lds;
-  PfLds l;
-  l.s = s;
-  l.Minv = Minv;
-  l.xrow = xrow;
-  l.ylds = ylds;
-  l.zpart = zpart;
-  l.red = red;
-  l.fail = &fail_lds;
-  return l;
-}
-
-// One diagonal block of one walker (the whole workgroup).  Returns 0, or the 1-based pivot index inside the block at
-// which the factorisation failed (status / lml of the walker are set here either way).  Called once per launch by
-// potrf_kernel and once per block column by the persistent chain kernel (ps_chain_kernel): the LDS tile is free again
-// when the function returns through its trailing barrier.
-template <int GEN, int STAT, int FORM>
-static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf, double* __restrict__ Wbuf,
-                                               double* __restrict__ yw, double* __restrict__ accb,
-                                               double* __restrict__ lml, int* __restrict__ status, int n, int ld,
-                                               size_t mstride, int ystride, int nblk, int k, const PfGen& gen,
-                                               bool inlds = false) {
-  // inlds (chain kernel, k > 0): the block and its right-hand side are in LDS already (pf_chain_next left them there)
-  const PfLds lds = pf_lds();
-  double* const s = lds.s;
-  double* const Minv = lds.Minv;
-  double* const xrow0 = lds.xrow;
-  double* const ylds = lds.ylds;
-  double* const zpart = lds.zpart;
-  double* const red = lds.red;
-  int& fail_lds = *lds.fail;
-  int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));  // (inside the chain kernel's column loop: nothing derived from the lane id is hoisted out of it)
-  const int tid = tid_, lane = tid & 63, w = tid >> 6;
-  const int lr = lane & 15, lk = lane >> 4;
-  double* T = Kbuf + (size_t)b * mstride + (size_t)(k * 128) * ld + k * 128;
-  double* yk = yw + (size_t)b * ystride + k * 128;
-  PF_T(0);
-
-  if (GEN) {
-    if (tid == 0) status[b] = 0;
-    pf_generate_tile<STAT, FORM>(s, Minv, gen, gen.H + (size_t)b * (gen.d + 2), n, tid);  // (Minv: scratch until step 0)
-  } else if (!inlds) {
-    // lower triangle of the tile -> LDS, all 16 16-byte loads of a thread in flight at once (the block is
-    // latency-bound: one workgroup streams 64 KB).  Thread t owns column pair seg = t & 63 of rows
-    // (t >> 6) + 8 i; pairs entirely above the diagonal are never read.
-    const int seg = tid & 63, rbase = tid >> 6;
-    d2 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int row = rbase + 8 * u;
-      v[u] = (2 * seg <= row + 15) ? *reinterpret_cast<const d2*>(T + (size_t)row * ld + seg * 2) : (d2){0.0, 0.0};
-    }
-#pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int row = rbase + 8 * u;
-      *reinterpret_cast<d2*>(&s[row * PF_LD + seg * 2]) = v[u];
-    }
-  }
-  if (tid < 128 && !inlds) ylds[tid] = GEN ? gen.y[tid] : yk[tid];
-  double ld_prev = 0.0, zz_prev = 0.0;  // running log-det and z^T z of the earlier diagonal blocks
-  if (tid == 0) {
-    fail_lds = 0;
-    if (k > 0) {
-      ld_prev = accb[b * 4 + 0];
-      zz_prev = accb[b * 4 + 1];
-    }
-  }
-  __syncthreads();
-  PF_T(1);
-
-  double* Wg = GEN ? nullptr : Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  int failed = 0;
-  d4 xpend = (d4){0.0, 0.0, 0.0, 0.0};  // wave 0: X_{sb,sb-1}^T, written in place one step later (the update
-                                        // waves still read the unscaled block T_{sb,sb-1} during this step)
-  d4 w7 = (d4){0.0, 0.0, 0.0, 0.0};     // update waves: partial sum of one block of row 7 of W, finished after the loop
-  // update waves: 1-3 and 5-7 (two per SIMD so that one's LDS latency hides behind the other's MFMAs); wave 4
-  // shares the panel wave's SIMD and stays idle (every VALU / MFMA issue there would delay the pivot chain)
-  const int u6 = (w < 4) ? w - 1 : w - 2;  // 0..5 for the update waves
-#pragma unroll 1
-  for (int sb = 0; sb < 8; sb++) {
-    if (w == 0) {
-      if (sb > 1) {  // pending panel block of the previous row
-#pragma unroll
-        for (int r = 0; r < 4; r++) s[((sb - 1) * 16 + lr) * PF_LD + (sb - 2) * 16 + lk + 4 * r] = xpend[r];
-      }
-      d4 dg;
-#pragma unroll
-      for (int r = 0; r < 4; r++) dg[r] = s[(sb * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr];
-      if (sb > 0) {
-        d4 xt = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const double av = Minv[(sb - 1) * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
-          const double bv = s[(sb * 16 + lr) * PF_LD + (sb - 1) * 16 + kk * 4 + lk];
-          xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) dg = __builtin_amdgcn_mfma_f64_16x16x4f64(-xt[kk], xt[kk], dg, 0, 0, 0);
-        xpend = xt;
-#pragma unroll
-        for (int r = 0; r < 4; r++) xrow0[(sb & 1) * 16 * PF_MLD + lr * PF_MLD + lk + 4 * r] = xt[r];
-      }
-      // C layout -> one matrix row per lane through the block's own LDS slot (nobody else touches it)
-#pragma unroll
-      for (int r = 0; r < 4; r++) s[(sb * 16 + lk + 4 * r) * PF_LD + sb * 16 + lr] = dg[r];
-      double a[16], mrow[16], macc[16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
-        macc[c] = 0.0;
-      }
-      int bad = 0;
-#ifdef PF_TRACE
-      asm volatile("s_nop 0" ::"v"(a[0]), "v"(a[15]));
-#endif
-      PF_T(3 + sb * 3);
-      micro_chol_inv<0>(a, macc, mrow, lr, bad);
-#ifdef PF_TRACE
-      asm volatile("s_nop 0" ::"v"(a[15]), "v"(mrow[15]), "v"(mrow[14]));
-#endif
-      PF_T(4 + sb * 3);
-      const int bad_u = __builtin_amdgcn_readfirstlane(bad);
-      if (bad_u) {
-        if (lane == 0) fail_lds = sb * 16 + bad_u;
-      } else if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) Minv[sb * 16 * PF_MLD + j * PF_MLD + lr] = mrow[j];
-#pragma unroll
-        for (int c = 0; c < 16; c++) s[(sb * 16 + lr) * PF_LD + sb * 16 + c] = (c <= lr) ? a[c] : 0.0;
-      }
-    } else if (sb > 0 && w != 4) {
-      const int p = sb - 1;  // phase: M_p was published at the previous barrier
-      d4 xt = (d4){0.0, 0.0, 0.0, 0.0};  // X_{p+1,p}^T (every update wave forms its own copy)
-      if (p + 2 < 8) {
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const double av = Minv[p * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
-          const double bv = s[((p + 1) * 16 + lr) * PF_LD + p * 16 + kk * 4 + lk];
-          xt = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xt, 0, 0, 0);
-        }
-      }
-      for (int I = p + 2 + u6; I < 8; I += 6) {  // at most one row per update wave
-        d4 xi = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          const double av = Minv[p * 16 * PF_MLD + lr * PF_MLD + kk * 4 + lk];
-          const double bv = s[(I * 16 + lr) * PF_LD + p * 16 + kk * 4 + lk];
-          xi = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, xi, 0, 0, 0);
-        }
-        // column p+1: terms p-1 (operands from LDS) and p (registers)
-        d4 acc;
-#pragma unroll
-        for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 1) * 16 + lr];
-        if (p > 0)
-          acc = mma_run<1>(acc, &s[(I * 16 + lr) * PF_LD + (p - 1) * 16 + lk],
-                           &s[((p + 1) * 16 + lr) * PF_LD + (p - 1) * 16 + lk], 1);
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[kk], xt[kk], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + (p + 1) * 16 + lr] = acc[r];
-        // the row's own panel block (its unscaled values were last read just above)
-#pragma unroll
-        for (int r = 0; r < 4; r++) s[(I * 16 + lr) * PF_LD + p * 16 + lk + 4 * r] = xi[r];
-        // column p+2: terms t <= p-1, and on the row's own diagonal block (I == p+2) also term p, so the
-        // panel wave is left with a single rank-16 term
-        if (p > 0 || I == p + 2) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) acc[r] = s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr];
-          acc = mma_run<1>(acc, &s[(I * 16 + lr) * PF_LD + lk], &s[((p + 2) * 16 + lr) * PF_LD + lk], p);
-          if (I == p + 2) {
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xi[kk], xi[kk], acc, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; r++) s[(I * 16 + lk + 4 * r) * PF_LD + (p + 2) * 16 + lr] = acc[r];
-        }
-      }
-      // row p of W = L^-1: M_p, its panel blocks (the last one via xrow) and rows < p of W are visible
-      // (heavy blocks = small J go to the waves without a phase row: rows occupy update waves 0 .. 5-p)
-      for (int J = 5 - u6; J <= p; J += 6) {
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        if (J < p) acc = pf_wsum(acc, s, Minv, xrow0 + (p & 1) * 16 * PF_MLD, p, J, J, p, lane);
-        pf_wfinish(acc, s, Minv, Wg, p, J, lane);
-      }
-      // row block sb-2 of L is final and visible: stream it out now (lower triangle, 16-byte pairs)
-      if (!GEN && sb >= 2 && sb <= 6) {  // (the last step is the update waves' busiest: blocks 5..7 go out after the loop)
-        const int R = sb - 2, ut = u6 * 64 + lane;  // 384 update threads: 24 per row
-        const int rr = ut / 24, c0 = ut - 24 * rr, row = R * 16 + rr;
-        for (int seg = c0; seg < 8 * R + 8; seg += 24) {
-          if (2 * seg <= row)
-            *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
-        }
-      }
-      // last step: rows <= 5 of W are complete -> the terms K <= 5 of row 7 (one block per update wave)
-      if (sb == 7) w7 = pf_wsum(w7, s, Minv, nullptr, 7, u6, u6, 6, lane);  // block J = u6 (W row 6 went 5 - u6)
-    }
-    __syncthreads();
-    PF_T(2 + sb * 3);
-    failed = fail_lds;
-    if (failed) break;  // uniform across the workgroup
-  }
-  if (failed) {
-    if (tid == 0) {
-      status[b] = k * 128 + failed;  // 1-based index of the failing pivot
-      lml[b] = -INFINITY;            // sklearn/_gpr.py:588-589
-    }
-    return failed;
-  }
-  PF_T(26);
-  // ---- L_kk out.  Only the lower triangle is written (16-byte stores; the element right of the diagonal in
-  // a straddling pair is junk nobody reads: every consumer of this tile masks j <= i).  Block (7, 6) is still
-  // in the panel wave's registers and goes out from there.  The stores drain while row 7 of W is formed.
-  if (!GEN) {
-    const int seg = tid & 63, rbase = tid >> 6;
-#pragma unroll
-    for (int i = 10; i < 16; i++) {  // row blocks 5, 6 and 7 (0..4 went out inside the loop)
-      const int row = rbase + 8 * i;
-      if (2 * seg <= row && !(row >= 112 && seg >= 48 && seg < 56))
-        *reinterpret_cast<d2*>(T + (size_t)row * ld + seg * 2) = *reinterpret_cast<const d2*>(&s[row * PF_LD + seg * 2]);
-    }
-  }
-  // ---- row 7 of W: last term (K = 6) and the multiplication by -M_7
-  if (w == 0) {
-    if (!GEN) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) T[(size_t)(7 * 16 + lr) * ld + 6 * 16 + lk + 4 * r] = xpend[r];
-    }
-    d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-    acc = pf_wsum(acc, s, Minv, xrow0 + 16 * PF_MLD, 7, 6, 6, 7, lane);
-    pf_wfinish(acc, s, Minv, Wg, 7, 6, lane);
-    pf_wfinish(acc, s, Minv, Wg, 7, 7, lane);
-  } else if (w != 4) {
-    w7 = pf_wsum(w7, s, Minv, xrow0 + 16 * PF_MLD, 7, u6, 6, 7, lane);
-    pf_wfinish(w7, s, Minv, Wg, 7, u6, lane);
-  }
-  double ldv = (tid < 128) ? log(s[tid * PF_LD + tid]) : 0.0;
-  for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
-  if (lane == 0) red[w] = ldv;
-  __syncthreads();
-  PF_T(27);
-  // ---- z = W y from the LDS copy of W (transposed in the upper triangle, diagonal blocks in Minv); four
-  // threads per row, fixed summation order (bitwise reproducible)
-  {
-    const int row = tid & 127, h = tid >> 7, Ib = row >> 4, ri = row & 15;  // h = 0..3
-    double z0 = 0.0, z1 = 0.0;  // two chains (16 Ib is a multiple of 8), fixed order
-    for (int j = h; j < 16 * Ib; j += 8) {
-      z0 = fma(s[j * PF_LD + row], ylds[j], z0);
-      z1 = fma(s[(j + 4) * PF_LD + row], ylds[j + 4], z1);
-    }
-    double zs = z0 + z1;
-    for (int jj = h; jj <= ri; jj += 4) zs = fma(Minv[Ib * 16 * PF_MLD + ri * PF_MLD + jj], ylds[16 * Ib + jj], zs);
-    zpart[h * 128 + row] = zs;
-  }
-  __syncthreads();
-  double zv = 0.0;
-  if (tid < 128) {
-    zv = (zpart[tid] + zpart[128 + tid]) + (zpart[256 + tid] + zpart[384 + tid]);
-    if (!GEN) yk[tid] = zv;
-    zpart[tid] = zv;  // (a thread reads and writes its own column only: z stays in LDS for pf_chain_next)
-  }
-  double zz = zv * zv;
-  for (int o = 32; o > 0; o >>= 1) zz += __shfl_xor(zz, o);
-  if (lane == 0) red[8 + w] = zz;
-  __syncthreads();
-  if (tid == 0) {
-    double ldt = red[0] + red[1];  // threads 0..127 (waves 0 and 1) hold the diagonal and z
-    double zzt = red[8] + red[9];
-    ldt += ld_prev;
-    zzt += zz_prev;
-    if (!GEN) {
-      accb[b * 4 + 0] = ldt;
-      accb[b * 4 + 1] = zzt;
-    }
-    if (k == nblk - 1) {
-      // (no implicit fused multiply-add: this function is inlined into two kernels and the backend decides contraction
-      // per call site -- the launch-free and the multi-launch path rounded this line differently, 0.5 ulp of n log 2 pi)
-#pragma clang fp contract(off)
-      double v = -0.5 * zzt - ldt - 0.5 * (double)n * 1.8378770664093453;  // log(2 pi)
-      if (!(v > -INFINITY && v < INFINITY)) {  // overflow somewhere on the way: report like a failed factorisation
-        v = -INFINITY;
-        status[b] = n + 1;
-      }
-      lml[b] = v;
-    }
-  }
-  PF_T(28);
-  __syncthreads();  // (every wave is past its last LDS read: a caller may run the next block in this workgroup)
-  return 0;
-}
+#include "bgp_pf.h"
 
 template <int GEN, int STAT, int FORM>
 __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
@@ -592,233 +69,33 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Launch-free factorisation of SMALL batches (B <= 64 matrices, or one large matrix): ONE pair of persistent kernels per
-// batch instead of ~3 dependent launches per block column.
+// Launch-free factorisation of SMALL batches (B <= 64 matrices, or one large matrix): ONE persistent kernel per batch
+// instead of ~3 dependent launches per block column (ps_kernel, bgp_syrk4.hip; the diagonal-block code is bgp_pf.h).
 //
 // Why: with few matrices the chain of dependent launches is the critical path -- potrf(k) keeps B of the 256 CUs busy
 // for 30 us while the rest idle, and the trailing update of step k cannot overlap the next panel (stream / event
 // look-ahead was measured slower than the chain it shortens: events cost more than they hide).  Here the diagonal-block
-// chain and the tile work run SIDE BY SIDE and talk through device-scope flags:
-//   * ps_chain_kernel (this file): one 512-thread workgroup per matrix walks the diagonal blocks J = 0 .. nblk-1: waits
-//     until block (J, J) has received its left-looking update, factorises it (pf_block: the same
-//     code as potrf_kernel), publishes L_JJ / W_JJ / z_J and raises wready[J];
-//   * ps_tile_kernel (bgp_syrk4.hip): 512-thread workgroups (one per CU) draw tasks from one ticket counter, in an order that is
-//     topological for the dependency graph (column by column), and do the left-looking tile work -- update with all
-//     finished panels to the left, then the panel solve against W_JJ -- waiting on / raising xready, diagcnt, wready.
-// The two kernels run on a pair of CU-masked streams (hipExtStreamCreateWithCUMask; on MI355X mask bit i selects a CU of
-// XCD i % 8: the low 8k bits give the chain k CUs in every XCD, the complement gives the tile kernel the other 32 - k), so
-// the chain's workgroups -- 133 KB of LDS each, one per CU -- are resident by construction whatever the tile kernel does.
-// Every wait is bounded (PsArgs::spin_limit): a timeout raises the error word, both kernels drain, and the host redoes
+// chain and the tile work run SIDE BY SIDE inside one launch and talk through device-scope flags:
+//   * chain role (workgroups 0 .. B-1, one per matrix; ps_chain_role, bgp_pf.h): walks the block columns J = 0 .. nblk-1:
+//     factorises block (J, J) (pf_block: the same code as potrf_kernel), publishes L_JJ / W_JJ / z_J (wready[J]), then
+//     solves block (J+1, J) and applies the last panel to block (J+1, J+1) ITSELF -- the next tile never leaves its LDS;
+//   * tile role (the other workgroups, one per remaining CU; ps_tile_role, bgp_syrk4.hip): draw left-looking block tasks
+//     from ticket counters in an order that is topological for the dependency graph -- panel solves S(I, J), I >= J+2, and
+//     the pre-updates that hand blocks (I, I-1) and (I, I) to the chain -- waiting on / raising xready, subrdy, diagrdy.
+// Both roles need a whole CU (157 / 128 KB of LDS, one array), the grid has at most one workgroup per CU and the
+// dispatcher places workgroups in index order: the chain's B workgroups are resident before any tile workgroup, whatever
+// else the GPU is doing.  (Round 3's first version ran two kernels on a pair of CU-masked streams: event hops, cold
+// hardware queues -- ~45 us per call -- masks that only place properly for 1-4 or 8 CUs per XCD, and time-sliced queues
+// once a few dozen masked streams were alive.)
+// Every wait is bounded (PsArgs::spin_limit): a timeout raises the error word, both roles drain, and the host redoes
 // the batch on the multi-launch path.  Arithmetic, operand order and summation order are those of the multi-launch path:
 // the log-likelihoods are bit-identical (tests/test_gpu_persist.py).
 // ------------------------------------------------------------------------------------------
-// dt[u] -= X_ti X_tj^T for this wave's NT tiles of the next diagonal block, X row-major in the LDS tile: the operands of
-// k-step kk+1 are read while k-step kk multiplies (two waves per SIMD cover the rest of the LDS latency).
-template <int NT>
-static __device__ __forceinline__ void pf_diag_update(d4 (&dt)[5], const double* __restrict__ s, const int (&offa)[5],
-                                                      const int (&offb)[5]) {
-  double a0[NT], b0[NT];
-#pragma unroll
-  for (int u = 0; u < NT; u++) {
-    a0[u] = s[offa[u]];
-    b0[u] = s[offb[u]];
-  }
-#pragma unroll 2
-  for (int t = 0; t < 32; t++) {
-    double a1[NT], b1[NT];
-    const int tn = (t + 1 < 32) ? t + 1 : t;
-#pragma unroll
-    for (int u = 0; u < NT; u++) {
-      a1[u] = s[offa[u] + 4 * tn];
-      b1[u] = s[offb[u] + 4 * tn];
-    }
-#pragma unroll
-    for (int u = 0; u < NT; u++) dt[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], dt[u], 0, 0, 1);
-#pragma unroll
-    for (int u = 0; u < NT; u++) {
-      a0[u] = a1[u];
-      b0[u] = b1[u];
-    }
-  }
-}
-
-// The chain's own share of block column J (PsArgs::fat): the two blocks the next factorisation waits for never leave the
-// chain's workgroup.  W_JJ is still in LDS (transposed in the upper triangle of the tile, diagonal blocks in Minv), z_J in
-// zpart; the tile workers have applied the panels 0 .. J-1 to blocks (J+1, J) and (J+1, J+1) beforehand (subrdy / diagrdy).
-//   1. X = A_{J+1,J} W_JJ^T: wave w owns rows 16 w .. 16 w + 15, the A operand comes from global memory straight into
-//      fragment registers (32 doubles per lane), chunk c of k only reaches the column blocks j >= c; right-hand side
-//      y_{J+1} -= X z_J in the same pass (one row per 16 lanes, fixed shuffle order): the arithmetic of trsm4_kernel;
-//      X goes to global memory for the tile workers (xready[J+1][J]) and, row-major, into the LDS tile;
-//   2. D_{J+1,J+1} -= X X^T on the 36 lower 16 x 16 tiles (accumulator = the block as the tile worker left it, k ascending
-//      in steps of 4, A-negate: the arithmetic of syrk4_kernel), and the result IS the next LDS tile of pf_block: no
-//      flag, no L2 round trip and no other workgroup between two factorisations.
-// Returns 0, or -1 when a wait was abandoned.
-static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr) {
-  const PfLds lds = pf_lds();
-  double* const s = lds.s;
-  const double* const Minv = lds.Minv;
-  double* const ylds = lds.ylds;
-  const double* const zl = lds.zpart;
-  int tid_ = threadIdx.x;
-  asm volatile("" : "+v"(tid_));
-  const int tid = tid_, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lk = lane >> 4;
-  const int I = J + 1, ld = a.ld, nblk = a.nblk;
-  unsigned* const flags = a.flags;
-  unsigned* const err = flags + PS_ERROR;
-  double* const Mb = a.K + (size_t)b * a.mstride;
-  double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
-  const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
-  if (J > 0) {
-    if (tid == 0) {
-      const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
-      const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-      const bool ok = ps_wait_ge(subrdy + I, 1u, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
-      ps_acquire();
-      *ok_lds = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!*ok_lds) return -1;
-  }
-  if (tr && tid == 0) tr[J * 8 + 2] = wall_clock64();
-  // ---- operands: A fragments (k = 4 t + lk of row 16 w + lr), this lane's rows of y, the D tiles of this wave
-  double af[32];
-  {
-    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
-#pragma unroll
-    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
-  }
-  double yv[4];
-  {
-    const double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
-#pragma unroll
-    for (int r = 0; r < 4; r++) yv[r] = yi[16 * w + lk + 4 * r];
-  }
-  // lower 16 x 16 tiles t = w, w + 8, ... < 36 in row-major order of the triangle (waves 0-3: five, 4-7: four; nine per SIMD)
-  d4 dt[5];
-  int offa[5], offb[5], offc[5], offd[5];
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    const int t = w + 8 * u;
-    int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
-    const int tj = t - ti * (ti + 1) / 2;
-    offa[u] = (ti * 16 + lr) * PF_LD + lk;
-    offb[u] = (tj * 16 + lr) * PF_LD + lk;
-    offc[u] = (ti * 16 + lk) * PF_LD + tj * 16 + lr;
-    offd[u] = (ti * 16 + lk) * ld + tj * 16 + lr;
-  }
-  // ---- 1. panel solve
-  d4 x[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) x[j] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const double av = af[4 * c + kk];
-      // column block c: the diagonal block of W (its upper part holds zeros); j > c: W[j][c]^T in the upper triangle
-      x[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Minv[c * 16 * PF_MLD + lr * PF_MLD + 4 * kk + lk], x[c], 0, 0, 0);
-#pragma unroll
-      for (int j = c + 1; j < 8; j++)
-        x[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s[(c * 16 + 4 * kk + lk) * PF_LD + j * 16 + lr], x[j], 0, 0, 0);
-    }
-  }
-  // (the D tiles are fetched under the epilogue: with them in flight during the solve the kernel spilled)
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    if (w + 8 * u < 36) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) dt[u][r] = Db[(size_t)offd[u] + (size_t)(4 * r) * ld];
-    } else {
-      dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
-    }
-  }
-  if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
-  {
-    double zc[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) zc[j] = zl[16 * j + lr];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = 16 * w + lk + 4 * r;
-      double part = 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const double xv = x[j][r];
-        Ab[(size_t)row * ld + 16 * j + lr] = xv;
-        part = __builtin_fma(xv, zc[j], part);  // (trsm4_kernel's `part += x * zc[j]` is contracted the same way)
-      }
-      part += __shfl_xor(part, 1);
-      part += __shfl_xor(part, 2);
-      part += __shfl_xor(part, 4);
-      part += __shfl_xor(part, 8);
-      if (lr == 0) ylds[row] = yv[r] - part;
-    }
-  }
-  __syncthreads();  // nobody reads W in the tile any more (X's stores drain while it goes into the tile)
-  if (tr && tid == 0) tr[J * 8 + 5] = wall_clock64();
-#pragma unroll
-  for (int j = 0; j < 8; j++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) s[(16 * w + lk + 4 * r) * PF_LD + 16 * j + lr] = x[j][r];
-  ps_publish_barrier();  // X is in the tile, and every wave's part of it has reached memory
-  if (tid == 0) ps_signal_add(flags + PS_HDR + (size_t)2 * a.B * nblk + ((size_t)b * nblk + I) * nblk + J);  // xready[I][J]
-  if (tr && tid == 0) tr[J * 8 + 6] = wall_clock64();
-  // ---- 2. the next diagonal block
-  if (w < 4)
-    pf_diag_update<5>(dt, s, offa, offb);
-  else
-    pf_diag_update<4>(dt, s, offa, offb);
-  __syncthreads();  // everybody is done with X in the tile
-  if (tr && tid == 0) tr[J * 8 + 7] = wall_clock64();
-  if (tr && tid == 0) tr[J * 8 + 7] = wall_clock64();
-#pragma unroll
-  for (int u = 0; u < 5; u++) {
-    if (w + 8 * u < 36) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) s[offc[u] + 4 * r * PF_LD] = dt[u][r];
-    }
-  }
-  __syncthreads();
-  if (tr && tid == 0) tr[J * 8 + 3] = wall_clock64();
-  return 0;
-}
-
-__global__ void __launch_bounds__(PF_THREADS) ps_chain_kernel(PsArgs a) {
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  __shared__ int ps_ok;
-  unsigned* const flags = a.flags;
-  unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
-  unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
-  for (int J = 0; J < a.nblk; J++) {
-    if (tr && tid == 0) tr[J * 8 + 0] = wall_clock64();
-    // (J > 0: the block and its right-hand side are in LDS, pf_chain_next left them there)
-    const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
-                                         a.nblk, J, PfGen(), J > 0);
-    if (tr && tid == 0) tr[J * 8 + 1] = wall_clock64();
-    ps_publish_barrier();
-    if (tid == 0) {
-      ps_release();
-      // a failed matrix (status set above) releases every later column at once -- and the panel blocks this workgroup owes
-      // the tile tasks: they see the status and only pass their own flags on
-      for (int j = J; j < (failed ? a.nblk : J + 1); j++) ps_st(wready + j, 1u);
-      if (failed)
-        for (int j = J; j + 1 < a.nblk; j++)
-          ps_st(flags + PS_HDR + (size_t)2 * a.B * a.nblk + ((size_t)b * a.nblk + j + 1) * a.nblk + j, 1u);
-    }
-    if (failed) return;
-    if (J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr) < 0) return;  // (abandoned: the host redoes the batch)
-  }
-}
-
 int bgp_ps_total_tasks(int B, int nblk);
+void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg);
 
 // BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
-// chain (B x nblk x 8: wait begin, wait end, factorised, published -- fat: see tools/persist_trace_fat.py) then tile (total x 8: ticket drawn, first operands ready,
-// update done, stored, W ready, solved, published, XCC id << 32 | J << 16 | I << 8 | b... see tools/persist_trace.py).
+// chain (B x nblk x 8) then tile (total x 8): see tools/persist_trace.py.
 extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out, size_t cap) {
   if (!c || !dims) return BGP_ERR_INVALID;
   dims[0] = c->ps_trace_B;
@@ -832,95 +109,26 @@ extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out
   return BGP_OK;
 }
 
-// chain CUs per XCD for B matrices: ceil(B / 8), but only 1, 2, 3, 4 or 8 -- with 5, 6 or 7 masked CUs per XCD (unequal
-// counts per shader engine) the dispatcher does not place one 157 KB workgroup on every masked CU (tools/cumask_probe.hip:
-// 6-15 of 40-56 resident together), and a chain workgroup that is not resident stalls its matrix until another one ends
-static int ps_chain_k(int B) {
-  int k = (B + 7) / 8;
-  if (k > 4) k = 8;
-  static int kforce = -1;  // BGP_PS_K: chain CUs per XCD (experiments)
-  if (kforce < 0) {
-    const char* e = getenv("BGP_PS_K");
-    kforce = e ? atoi(e) : 0;
-  }
-  if (kforce > k && kforce <= 8) k = kforce;
-  return k;
-}
-
-// Can this batch take the launch-free path?  (at least two block columns; a chain CU per matrix)
+// Can this batch take the launch-free path?  (at least two block columns; a CU per matrix and enough left for the tiles)
 int bgp_persist_fits(bgp_ctx* c, int B) { return B >= 1 && B <= 64 && c->nblk >= 2 && c->nblk <= 255; }
 
-// The CU-masked stream pairs are PROCESS-wide (one pair per device and chain width k), never per context: every such
-// stream is a hardware queue of its own, and with a few dozen of them alive (six contexts that had each used three widths)
-// the queues were time-sliced -- chain and tile kernel of one call no longer ran side by side, the path slowed down and
-// finally timed out (tools/lf_state_probe.py).  Calls of different contexts share the pair; ps_mutex keeps the order of
-// their kernels the same on both streams (chain A, chain B on one and tile B, tile A on the other would wait for each other).
-#include <mutex>
-static std::mutex ps_mutex;
-struct PsStreams {
-  hipStream_t chain[9] = {nullptr}, tile[9] = {nullptr};
-};
-static PsStreams ps_streams[BGP_MAX_DEVICES];
-static int ps_live_contexts = 0;
-void bgp_ps_streams_retain() {
-  std::lock_guard<std::mutex> guard(ps_mutex);
-  ps_live_contexts++;
-}
-// (they go with the last context: a masked stream left alive at process exit crashed rocprofv3's teardown)
-void bgp_ps_streams_release() {
-  std::lock_guard<std::mutex> guard(ps_mutex);
-  if (--ps_live_contexts > 0) return;
-  ps_live_contexts = 0;
-  int cur = 0;
-  const bool have = hipGetDevice(&cur) == hipSuccess;
-  for (int dev = 0; dev < BGP_MAX_DEVICES; dev++)
-    for (int k = 0; k < 9; k++) {
-      if (!ps_streams[dev].chain[k] && !ps_streams[dev].tile[k]) continue;
-      (void)hipSetDevice(dev);
-      if (ps_streams[dev].chain[k]) (void)hipStreamDestroy(ps_streams[dev].chain[k]);
-      if (ps_streams[dev].tile[k]) (void)hipStreamDestroy(ps_streams[dev].tile[k]);
-      ps_streams[dev].chain[k] = ps_streams[dev].tile[k] = nullptr;
-    }
-  if (have) (void)hipSetDevice(cur);
-}
-
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
-// this enqueues the chain / tile kernel pair on the CU-masked streams for k = ceil(B / 8) chain CUs per XCD and makes
-// c->stream wait for both.  The error word travels to pinned memory behind them (ctx->ps_herr): != 0 after the
-// synchronisation means a wait timed out and the caller redoes the batch on the multi-launch path.
+// this enqueues ONE kernel behind them -- B chain workgroups + one tile workgroup for every other CU -- and the copy of
+// the error word to pinned memory (ctx->ps_herr): != 0 after the synchronisation means a wait timed out and the caller
+// redoes the batch on the multi-launch path.
 int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int nblk = c->nblk, ld = c->npad;
   if (!bgp_persist_fits(c, B)) {
     bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
     return BGP_ERR_INVALID;
   }
-  const int k = ps_chain_k(B);
-  // (The complement of 8 k' bits holds 8 (32 - k') tile-shaped workgroups TOGETHER only for k' = 4 and 8 -- 28 / 24 CUs per
-  // XCD, the same number in every shader engine; with 31 / 30 / 29 a few of them start when others have ended
-  // (tools/cumask_probe.hip).  The ticket scheme does not need them all resident: it only loses those few workers.)
-  const int tile_wgs = 8 * (32 - k);
-  if (c->device < 0 || c->device >= BGP_MAX_DEVICES) {
-    bgp_set_error("bgp_launch_cholesky_persist: device %d", c->device);
-    return BGP_ERR_INVALID;
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    BGP_HIP(hipGetDeviceProperties(&prop, c->device));
+    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  std::lock_guard<std::mutex> guard(ps_mutex);
-  PsStreams& pst = ps_streams[c->device];
-  if (!pst.chain[k]) {
-    // mask bit i selects one CU of XCD i % 8 (the driver's symmetric map; tools/cumask_probe.hip): the low 8k bits are
-    // k CUs in every XCD
-    uint32_t ma[8], mb[8];
-    for (int i = 0; i < 8; i++) ma[i] = 0u, mb[i] = 0xffffffffu;
-    for (int i = 0; i < 8 * k; i++) {
-      ma[i / 32] |= 1u << (i % 32);
-      mb[i / 32] &= ~(1u << (i % 32));
-    }
-    BGP_HIP(hipExtStreamCreateWithCUMask(&pst.chain[k], 8, ma));
-    BGP_HIP(hipExtStreamCreateWithCUMask(&pst.tile[k], 8, mb));
-  }
-  if (!c->ps_ev0) {
-    BGP_HIP(hipEventCreateWithFlags(&c->ps_ev0, hipEventDisableTiming));
-    BGP_HIP(hipEventCreateWithFlags(&c->ps_eva, hipEventDisableTiming));
-    BGP_HIP(hipEventCreateWithFlags(&c->ps_evb, hipEventDisableTiming));
+  if (!c->ps_herr) {
     BGP_HIP(hipHostMalloc((void**)&c->ps_herr, sizeof(unsigned), hipHostMallocDefault));
     *c->ps_herr = 0;
   }
@@ -957,8 +165,9 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
   a.total = bgp_ps_total_tasks(B, nblk);
+  const int tile_wgs = std::min(a.total, ncu - B);
   {
-    // critical pool of the tile kernel: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
+    // critical pool of the tile role: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
     // workgroups of their own, one per task of a column.  Measured: with up to ~10 block columns the chain waits less
     // (n = 1024 x 32: 0.63 -> 0.59 ms, 975 x 50: 0.93 -> 0.84); with more, these left-looking tasks are long and want the
     // look-ahead the single list gives them (n = 2048 x 9: 1.20 -> 1.37 ms with the pool).  BGP_PS_NCRIT fixes the number.
@@ -993,18 +202,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       c->ps_trace_total = a.total;
     }
   }
-  hipStream_t sa = pst.chain[k], sb = pst.tile[k];
-  BGP_HIP(hipEventRecord(c->ps_ev0, c->stream));
-  BGP_HIP(hipStreamWaitEvent(sa, c->ps_ev0, 0));
-  BGP_HIP(hipStreamWaitEvent(sb, c->ps_ev0, 0));
-  hipLaunchKernelGGL(ps_chain_kernel, dim3(B), dim3(PF_THREADS), 0, sa, a);
-  BGP_HIP(hipEventRecord(c->ps_eva, sa));
-  if (a.total > 0) {  // (two block columns: the chain does everything)
-    bgp_launch_ps_tile(sb, a, tile_wgs);
-    BGP_HIP(hipEventRecord(c->ps_evb, sb));
-  }
-  BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_eva, 0));
-  if (a.total > 0) BGP_HIP(hipStreamWaitEvent(c->stream, c->ps_evb, 0));
+  bgp_launch_ps(c->stream, a, B + tile_wgs);
   BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(hipGetLastError());
   return BGP_OK;

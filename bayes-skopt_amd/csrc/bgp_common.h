@@ -161,7 +161,6 @@ struct bgp_ctx {
   // launch-free factorisation of small batches: CU-masked stream pairs (k CUs per XCD for the diagonal-block chain,
   // the other 32 - k for the tile workers), created on first use; flag block; events
   int persist = -1;          // env BGP_PERSIST: 0 never, 1 whenever possible, -1 (unset) automatic by batch size
-  hipEvent_t ps_ev0 = nullptr, ps_eva = nullptr, ps_evb = nullptr;
   unsigned* ps_flags = nullptr;
   size_t cap_psflags = 0;
   unsigned* ps_herr = nullptr;  // pinned: error word of the last persistent call
@@ -261,10 +260,7 @@ static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B 
 static inline bool bgp_persist_auto_rule(int nblk, int nb) { return nblk >= 8 && (nb >= 4 || nblk >= 20) && nb * nblk <= 384; }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg);
 int bgp_persist_fits(bgp_ctx* ctx, int B);
-void bgp_ps_streams_retain();
-void bgp_ps_streams_release();
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);

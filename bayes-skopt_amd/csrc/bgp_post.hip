@@ -890,9 +890,6 @@ static void free_child(bgp_ctx* w) {
   if (w->dlml) (void)hipFree(w->dlml);
   if (w->dstatus) (void)hipFree(w->dstatus);
   // (launch-free factorisation of the covariance: its own flags and events; the masked streams are process-wide)
-  if (w->ps_ev0) (void)hipEventDestroy(w->ps_ev0);
-  if (w->ps_eva) (void)hipEventDestroy(w->ps_eva);
-  if (w->ps_evb) (void)hipEventDestroy(w->ps_evb);
   if (w->ps_flags) (void)hipFree(w->ps_flags);
   if (w->ps_trace) (void)hipFree(w->ps_trace);
   if (w->ps_herr) (void)hipHostFree(w->ps_herr);

@@ -28,6 +28,7 @@
 #include "bgp_device.h"
 #include "bgp_gemm.h"
 #include "bgp_ring.h"
+#include "bgp_pf.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -598,11 +599,12 @@ static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsig
 }
 
 #define PS_NST 4
-__global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
+// wg = this workgroup's index among the tile workgroups of the launch
+static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
-  __shared__ __attribute__((aligned(1024))) char smem[PS_NST * STAGEB];
+  static_assert(PS_NST * STAGEB <= PF_LDS_BYTES, "the operand ring lives in the chain role's LDS array");
   __shared__ int sh_t, sh_q;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)pf_lds_raw();
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
   const int nblk = a.nblk, B = a.B, ld = a.ld;
@@ -616,7 +618,7 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
   // XCD's L2 and the hand-offs are same-XCD; a workgroup whose own list is exhausted helps the next lists.
   const int xcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);
   const bool pools = a.ncrit > 0;
-  int pool = (pools && (int)blockIdx.x < a.ncrit) ? 0 : 1, pools_done = 0;
+  int pool = (pools && wg < a.ncrit) ? 0 : 1, pools_done = 0;
   int list = 0;  // lists tried so far (own first)
   for (;;) {
     const int x = (xcc + list) & 7;
@@ -798,9 +800,18 @@ __global__ void __launch_bounds__(512, 1) ps_tile_kernel(PsArgs a) {
   }
 }
 
-// one 512-thread workgroup per tile CU
-void bgp_launch_ps_tile(hipStream_t st, const PsArgs& a, int nwg) {
-  hipLaunchKernelGGL(ps_tile_kernel, dim3(std::min(a.total, nwg)), dim3(512), 0, st, a);
+// The launch-free factorisation: workgroups 0 .. B-1 are the chain (one per matrix, bgp_pf.h), the others the tile workers.
+// One LDS array serves both roles (157 KB: one workgroup per CU); workgroups are placed in index order, so the chain is
+// resident before any tile worker starts to spin.
+__global__ void __launch_bounds__(512, 1) ps_kernel(PsArgs a) {
+  if ((int)blockIdx.x < a.B)
+    ps_chain_role(a, (int)blockIdx.x);
+  else
+    ps_tile_role(a, (int)blockIdx.x - a.B);
+}
+
+void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg) {
+  hipLaunchKernelGGL(ps_kernel, dim3(nwg), dim3(512), 0, st, a);
 }
 int bgp_ps_total_tasks(int B, int nblk) { return B * ps_tasks_per_matrix(nblk); }
 
