@@ -158,8 +158,7 @@ struct bgp_ctx {
   size_t cap_pinned = 0;
   int pending_B = 0;
   bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
-  // launch-free factorisation of small batches: CU-masked stream pairs (k CUs per XCD for the diagonal-block chain,
-  // the other 32 - k for the tile workers), created on first use; flag block; events
+  // launch-free factorisation of small batches (ps_kernel): flag block, pinned error word, trace buffer
   int persist = -1;          // env BGP_PERSIST: 0 never, 1 whenever possible, -1 (unset) automatic by batch size
   unsigned* ps_flags = nullptr;
   size_t cap_psflags = 0;
@@ -251,13 +250,17 @@ struct PsArgs {
 };
 static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (3 + nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
-// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free):
-//   n = 1024: 24 matrices 1.06, 32: 1.09, 40: 1.01;  1280: 16: 1.06, 32: 1.10;  1536: 4: 1.01, 8: 1.09, 16: 1.19, 24: 1.12, 32: 1.02;
-//   n = 2048: 1: 0.98, 4: 1.09, 8: 1.23, 9: 1.35, 16: 1.14, 24: 1.05, 32: 1.00;  3072: 1: 1.05, 4: 1.08, 8: 1.18, 16: 1.04;
-//   n = 4096: 1: 1.12, 2: 1.08, 4: 1.05, 8: 1.08;  one 10 112 x 10 112 covariance (sample_y): 1.15;  below n = 1024 (300 x 8:
-//   0.72, 512 x 50: 0.89, 640 x 1: 0.81) and for 975 x 50 (1.01) the launches are as fast or faster.
-// So: at least 8 block columns, at least 4 matrices (or 20 block columns), matrices x block columns <= 384.
-static inline bool bgp_persist_auto_rule(int nblk, int nb) { return nblk >= 8 && (nb >= 4 || nblk >= 20) && nb * nblk <= 384; }
+// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
+//   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11
+//   n = 1024: 1: 0.93, 4: 0.95, 8: 0.98, 16: 1.06, 24: 1.12, 32: 1.19, 48: 1.09, 64: 0.97;  975 x 50 (config E): 1.10
+//   n = 1280: 8: 1.04, 32: 1.15, 48: 0.96;   1536: 1: 1.01, 4: 1.06, 16: 1.29, 32: 1.06, 48: 0.92
+//   n = 2048: 1: 1.02, 4: 1.12, 9: 1.40, 16: 1.22, 24: 1.07, 32: 0.99, 48: 0.88;   3072: 1: 1.08, 8: 1.25, 16: 1.06, 24: 0.95
+//   n = 4096: 1: 1.15, 2: 1.12, 4: 1.08, 8: 1.13, 16: 0.98;  one 10 112 x 10 112 covariance (sample_y): 1.15;  n <= 640: 0.92-0.97
+// So: at least 6 block columns, matrices x block columns <= 400 (beyond that the tile side is the bound and the launch
+// schedule's kernels are the better tile workers), and >= 100 unless there are at least 12 block columns.
+static inline bool bgp_persist_auto_rule(int nblk, int nb) {
+  return nblk >= 6 && nb * nblk <= 400 && (nblk >= 12 || nb * nblk >= 100);
+}
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
 int bgp_persist_fits(bgp_ctx* ctx, int B);

@@ -889,7 +889,7 @@ static void free_child(bgp_ctx* w) {
   if (w->dacc) (void)hipFree(w->dacc);
   if (w->dlml) (void)hipFree(w->dlml);
   if (w->dstatus) (void)hipFree(w->dstatus);
-  // (launch-free factorisation of the covariance: its own flags and events; the masked streams are process-wide)
+  // (launch-free factorisation of the covariance: its own flag block)
   if (w->ps_flags) (void)hipFree(w->ps_flags);
   if (w->ps_trace) (void)hipFree(w->ps_trace);
   if (w->ps_herr) (void)hipHostFree(w->ps_herr);

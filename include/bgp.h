@@ -232,10 +232,10 @@ int bgp_last_timing(bgp_ctx* ctx, double* out_ms, int* counts);
 /* Time (ms) and count of the look-ahead column launches of the trailing update (K = 128 .. 128 (P-1), one block column)
  * inside out[3] of bgp_last_timing, for the last timed bgp_lml_batch call. */
 int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
-/* Launch-free factorisation of small batches (one persistent kernel pair per bgp_lml_batch call -- and per covariance of
+/* Launch-free factorisation of small batches (one persistent kernel per bgp_lml_batch call -- and per covariance of
  * bgp_sample_y -- instead of ~3 launches per block column; same bits): 1 = whenever the batch fits (<= 64 matrices,
- * n > 128), 0 = never, -1 = as BGP_PERSIST says (unset: where it measured faster on MI355X: at least 8 block columns of
- * 128, matrices x block columns <= 384).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
+ * n > 128), 0 = never, -1 = as BGP_PERSIST says (unset: where it measured faster on MI355X: at least 6 block columns of
+ * 128, matrices x block columns <= 400).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
  * sklearn/_gpr.py:587. */
 int bgp_set_persist(bgp_ctx* ctx, int mode);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
