@@ -274,6 +274,7 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
   c->d = d;
   c->ks = *ks;
   c->max_batch = max_batch;
+  if (hipDeviceGetAttribute(&c->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->ncu = 0;
   if (hipStreamCreate(&c->stream) != hipSuccess) {
     bgp_set_error("hipStreamCreate failed");
     delete c;

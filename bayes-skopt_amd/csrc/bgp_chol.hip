@@ -109,8 +109,11 @@ extern "C" int bgp_debug_ps_trace(bgp_ctx* c, int* dims, unsigned long long* out
   return BGP_OK;
 }
 
-// Can this batch take the launch-free path?  (at least two block columns; a CU per matrix and enough left for the tiles)
-int bgp_persist_fits(bgp_ctx* c, int B) { return B >= 1 && B <= 64 && c->nblk >= 2 && c->nblk <= 255; }
+// Can this batch take the launch-free path?  (at least two block columns; a CU per matrix and at least as many, and at
+// least 32, left for the tile workers -- a partitioned device with 32 CUs never takes it)
+int bgp_persist_fits(bgp_ctx* c, int B) {
+  return B >= 1 && B <= 64 && c->nblk >= 2 && c->nblk <= 255 && c->ncu - B >= std::max(32, B);
+}
 
 // Host side of the launch-free factorisation: the B Gram matrices of the batch are already on c->stream (K-build);
 // this enqueues ONE kernel behind them -- B chain workgroups + one tile workgroup for every other CU -- and the copy of
@@ -122,12 +125,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
     return BGP_ERR_INVALID;
   }
-  static int ncu = 0;
-  if (!ncu) {
-    hipDeviceProp_t prop;
-    BGP_HIP(hipGetDeviceProperties(&prop, c->device));
-    ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int ncu = c->ncu;
   if (!c->ps_herr) {
     BGP_HIP(hipHostMalloc((void**)&c->ps_herr, sizeof(unsigned), hipHostMallocDefault));
     *c->ps_herr = 0;

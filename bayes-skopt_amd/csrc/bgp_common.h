@@ -159,6 +159,7 @@ struct bgp_ctx {
   int pending_B = 0;
   bgp_ctx* child = nullptr;  // cached workspace of bgp_sample_y (covariance Cholesky)
   // launch-free factorisation of small batches (ps_kernel): flag block, pinned error word, trace buffer
+  int ncu = 0;               // CUs of the device (the launch-free kernel takes one workgroup per CU)
   int persist = -1;          // env BGP_PERSIST: 0 never, 1 whenever possible, -1 (unset) automatic by batch size
   unsigned* ps_flags = nullptr;
   size_t cap_psflags = 0;

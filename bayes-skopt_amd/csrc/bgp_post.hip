@@ -1062,6 +1062,7 @@ static int ensure_child(bgp_ctx* c, int mpad, int nb, bgp_ctx** out) {
     w = new bgp_ctx();
     w->device = c->device;
     w->stream = c->stream;
+    w->ncu = c->ncu;
     w->d = c->d;
     w->max_batch = nb;
     const size_t B8 = 8 * ((size_t)(nb + 7) / 8);
