@@ -24,13 +24,19 @@ out = {}
 for n, d, B in %r:
     rng = np.random.RandomState(n + B)
     X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
+    ad = np.full(n, 1e-10)
     if B > 3:
         X[5] = X[4]            # coinciding points (tiny pivots) ...
-    ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
+    if B > 3 and n > 300:
+        X[200] = X[100]        # ... and a coinciding pair across two diagonal blocks whose second point carries a NEGATIVE
+        ad[200] = -1e-3        # diagonal term: a walker with (almost) no noise fails at pivot 201, in block column 1
+    ctx = _lib.Context(X, y, ad, max_batch=B)
     H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.1 * rng.randn(B, d + 2)
     if B > 3:
-        H[1, d + 1] = -np.inf  # ... no noise on one walker, and
+        H[1, d + 1] = -np.inf if n <= 300 else np.log(0.02)  # no noise on one walker (where that still factorises), and
         H[2, 0] = np.nan       # a walker whose matrix is not a number: its factorisation must fail at the first pivot
+    if B > 3 and n > 300:
+        H[3, d + 1] = np.log(1e-6)  # the walker that fails in the middle of the matrix
     vals = []
     for rep in range(3):
         v, st = ctx.lml(H, return_status=True)
@@ -67,7 +73,9 @@ def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit
         assert got[k]["status"] == ref[k]["status"], k
         assert got[k]["Lsum"] == ref[k]["Lsum"] and got[k]["zsum"] == ref[k]["zsum"], k  # the factor and z themselves
     st = got["1024_8_32"]["status"]
-    assert st[2] == 1 and all(s == 0 for i, s in enumerate(st) if i != 2)  # the NaN walker failed (pivot 1), nobody else
+    # the NaN walker failed at pivot 1, the noise-free one at the second point of the coinciding pair, nobody else
+    assert st[2] == 1 and st[3] == 201 and all(s == 0 for i, s in enumerate(st) if i not in (2, 3))
+    assert got["1024_8_32"]["lml"][0][3] == float("-inf").hex()
     assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
 
 
