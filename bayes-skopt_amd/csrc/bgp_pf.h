@@ -635,16 +635,26 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   d4 x[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) x[j] = (d4){0.0, 0.0, 0.0, 0.0};
+  // (the W operands of k-step t+1 are read while k-step t multiplies: with the reads placed just in front of their MFMAs the
+  // two waves of a SIMD stalled on LDS together -- the second one finished its 144 MFMAs 5.6 us after the first)
+  {
+    double bq[2][8];
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
+    for (int j = 1; j < 8; j++) bq[0][j] = s[lk * PF_LD + j * 16 + lr];
+    bq[0][0] = Minv[lr * PF_MLD + lk];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const double av = af[4 * c + kk];
-      // column block c: the diagonal block of W (its upper part holds zeros); j > c: W[j][c]^T in the upper triangle
-      x[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Minv[c * 16 * PF_MLD + lr * PF_MLD + 4 * kk + lk], x[c], 0, 0, 0);
+    for (int t = 0; t < 32; t++) {
+      const int c = t >> 2, cur = t & 1, nxt = cur ^ 1;
+      if (t + 1 < 32) {
+        const int cn = (t + 1) >> 2, kn = (t + 1) & 3;
+        // column block cn: the diagonal block of W (its upper part holds zeros); j > cn: W[j][cn]^T in the upper triangle
+        bq[nxt][cn] = Minv[cn * 16 * PF_MLD + lr * PF_MLD + 4 * kn + lk];
 #pragma unroll
-      for (int j = c + 1; j < 8; j++)
-        x[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, s[(c * 16 + 4 * kk + lk) * PF_LD + j * 16 + lr], x[j], 0, 0, 0);
+        for (int j = cn + 1; j < 8; j++) bq[nxt][j] = s[(cn * 16 + 4 * kn + lk) * PF_LD + j * 16 + lr];
+      }
+      const double av = af[t];
+#pragma unroll
+      for (int j = c; j < 8; j++) x[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bq[cur][j], x[j], 0, 0, 0);
     }
   }
   // (the D tiles are fetched under the epilogue: with them in flight during the solve the kernel spilled)
