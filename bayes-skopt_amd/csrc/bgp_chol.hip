@@ -16,7 +16,9 @@
 //   * LML path (bgp_lml_batch; the MCMC hot loop): scheduled in groups of P block columns by bgp_launch_cholesky_gen;
 //   * posterior builds on the augmented matrix (bgp_post.hip; once per sample(), per hyper-posterior draw of an
 //     acquisition and per gradient evaluation): the same kernels in single-panel mode with the active-row remap of
-//     bgp_rowblk (bgp_device.h).
+//     bgp_rowblk (bgp_device.h);
+//   * small batches of the LML path and sample_y's covariance: ONE persistent kernel instead of the launches
+//     (bgp_launch_cholesky_persist below, ps_kernel in bgp_syrk4.hip, the diagonal-block code of both in bgp_pf.h).
 // (Round 1's VGPR-staged trsm_kernel / syrk_kernel / syrk2_kernel / trsm8_kernel and the left-looking variant are A/B
 // references of the benches under tools/legacy/ now; they are not part of libbgp.so.)
 #include "bgp_common.h"
@@ -28,13 +30,13 @@
 #include <vector>
 
 // ------------------------------------------------------------------------------------------
-// potrf: diagonal block k of every walker, one workgroup (4 waves) per walker, block in LDS.
+// potrf: diagonal block k of every walker, one workgroup (8 waves) per walker, block in LDS (pf_block, bgp_pf.h).
 //
 // The 128x128 block is processed as 8x8 sub-blocks of 16 by a two-stage software pipeline inside the
 // workgroup.  Wave 0 is the PANEL wave: per step sb it completes row block sb (panel product with the
 // previous 16x16 inverse, last rank-16 term of the diagonal block), factorises the diagonal block in
-// registers (one matrix row per lane, 64-bit DPP row broadcasts) and publishes its inverse M_sb.  Waves 1-3
-// are UPDATE waves running one phase behind: phase p (after M_p is published) forms the panel blocks X_{I,p}
+// registers (one matrix row per lane, 64-bit DPP row broadcasts) and publishes its inverse M_sb.  Waves 1-3 and
+// 5-7 are UPDATE waves running one phase behind: phase p (after M_p is published) forms the panel blocks X_{I,p}
 // of the rows I >= p+2 and applies
 //     column p+1: terms t = p-1, p        column p+2: terms t <= p-1  (and t = p on its diagonal block)
 // so every block column c is complete (terms t <= c-3 in phase c-2, t = c-2, c-1 in phase c-1) when the
