@@ -141,3 +141,45 @@ def test_sample_y_covariance_on_the_launch_free_path_and_its_fallback():
     assert "timed out" not in err and got == ref
     got, err = run({"BGP_PERSIST": "1", "BGP_PS_TIMEOUT_TICKS": "200"})
     assert err.count("timed out") == 1 and got == ref, err[-1500:]
+
+
+def test_launch_free_path_against_the_sklearn_goldens():
+    """The launch-free factorisation forced on (bgp_set_persist(1)) for every golden case with at least two block columns:
+    ragged n with a per-point diagonal (M1-M4), BASELINE configs B / C / D at full size, a matrix that is singular at its
+    second pivot -- log-likelihoods against scikit-learn 1.7.2 at 1e-6, statuses as the reference's LinAlgError cases."""
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import _lib
+    from conftest import load_golden, synth
+
+    g = load_golden("lml_sizes.npz")
+    seen = 0
+    for tag in ("M1", "M2", "M3", "M4", "B", "C", "D"):
+        n, d, seed = [int(v) for v in g[tag + "_nd_seed"]]
+        if n <= 128:
+            continue
+        X, y = synth(n, d, seed)
+        ad = g[tag + "_alpha_diag"] if (tag + "_alpha_diag") in g.files else 1e-10
+        ctx = _lib.Context(X, y, ad, max_batch=8)
+        ctx.set_persist(1)
+        got, status = ctx.lml(g[tag + "_theta"], return_status=True)
+        assert np.all(status == 0), tag
+        np.testing.assert_allclose(got, g[tag + "_lml"], rtol=1e-6, err_msg=tag)
+        ctx.set_persist(0)
+        np.testing.assert_array_equal(ctx.lml(g[tag + "_theta"]), got)  # and the launch schedule: the same bits
+        ctx.close()
+        seen += 1
+    assert seen >= 5
+    # not positive definite at a pivot inside block column 1: point 200 is a copy of point 150 and carries a negative
+    # diagonal term (LinAlgError in the reference: -inf, sklearn/_gpr.py:588-589); with enough noise the matrix is fine
+    rng = np.random.RandomState(4)
+    X = rng.uniform(size=(300, 2))
+    X[200] = X[150]
+    yv = rng.randn(300)
+    ad = np.full(300, 1e-10)
+    ad[200] = -1e-3
+    ctx = _lib.Context(X, yv, ad, max_batch=4)
+    ctx.set_persist(1)
+    H = np.array([[0.0, np.log(0.3), np.log(0.3), np.log(1e-6)], [0.0, np.log(0.3), np.log(0.3), np.log(0.1)]])
+    got, status = ctx.lml(H, return_status=True)
+    assert got[0] == -np.inf and status[0] == 201 and status[1] == 0 and np.isfinite(got[1])
+    ctx.close()
