@@ -554,26 +554,21 @@ static __device__ __forceinline__ void s4_wait_vm_n4(int n) {
   if (n >= 2) s4_wait_vm<8>(); else if (n == 1) s4_wait_vm<4>(); else s4_wait_vm<0>();
 }
 
-// acc (-)= A B^T over `nch` 16-wide chunks on a four-stage LDS-DMA ring, eight waves.  A: `arows` rows at XA (128, or 32
-// for a quarter-block task: then only the waves whose 16 rows lie inside stage it), B: 128 rows at XB; SAMEB: B is A (a
-// diagonal block's update): staged once, `pb` points into the A image.  Waits are counted: the DMA returns in order, so
-// "at most r younger chunks outstanding" = vmcnt(r ni), ni = THIS wave's instructions per chunk.  `skip`: this wave's
-// block lies strictly above the diagonal, or the wave has no rows in a quarter task (it stages and meets the barriers, it
-// does not multiply); `tri`: B is lower triangular (panel solve).
-template <int NST, int NR, int NC, int NEGA, int SAMEB>
+// acc (-)= A B^T over `nch` 16-wide chunks on a four-stage LDS-DMA ring, eight waves: 128 rows of A at XA, 128 rows of B at
+// XB.  Waits are counted: the DMA returns in order, so "at most r younger chunks outstanding" = vmcnt(4 r) (four
+// instructions per wave and chunk).  `tri`: B is lower triangular (panel solve: chunk c only reaches the column blocks >= c).
+template <int NST, int NR, int NC, int NEGA>
 static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsigned (&voffA)[2], const double* XB,
                                                    const unsigned (&voffB)[2], int nch, unsigned lds0,
                                                    const unsigned (&pa)[4], const unsigned (&pb)[4], d4 (&acc)[NR][NC],
-                                                   int w, int tri, bool skip, int arows = 128) {
+                                                   int w, int tri) {
   static_assert(NST == 4, "the counted waits are written for four stages");
   constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
-  const bool stageA = 16 * w < arows;
-  const int ni = (SAMEB ? 0 : 2) + (stageA ? 2 : 0);  // (ni == 0: a wave that stages nothing waits for nothing)
 #pragma unroll
   for (int s = 0; s < NST - 1; s++) {
     if (s < nch) {
-      if (stageA) s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
-      if (!SAMEB) s8_issue(XB, voffB, s * S4_KC, lds0 + s * STAGEB + AOPB, w);
+      s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
+      s8_issue(XB, voffB, s * S4_KC, lds0 + s * STAGEB + AOPB, w);
     }
   }
   for (int c = 0; c < nch; c += NST) {
@@ -581,18 +576,61 @@ static __device__ __forceinline__ void s8_ring_run(const double* XA, const unsig
     for (int s = 0; s < NST; s++) {
       if (c + s >= nch) break;            // (wave- and workgroup-uniform)
       const int rem = nch - (c + s) - 1;  // chunks behind this one
-      const int out = rem < NST - 2 ? rem : NST - 2;
-      if (ni == 4)
-        s4_wait_vm_n4(out);
-      else
-        s4_wait_vm_n2(out);
+      s4_wait_vm_n4(rem < NST - 2 ? rem : NST - 2);
       __builtin_amdgcn_s_barrier();  // everybody's share of this chunk has landed; everybody is done with the previous one
       if (c + s + NST - 1 < nch) {
         const unsigned nb = lds0 + (unsigned)(((s + NST - 1) % NST) * STAGEB);
-        if (stageA) s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, nb, w);
-        if (!SAMEB) s8_issue(XB, voffB, (c + s + NST - 1) * S4_KC, nb + AOPB, w);
+        s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, nb, w);
+        s8_issue(XB, voffB, (c + s + NST - 1) * S4_KC, nb + AOPB, w);
       }
-      if (!skip) s4_mma<NR, NC, -64, 0, NEGA>(pa, pb, s * STAGEB, acc, tri ? c + s : 0);
+      s4_mma<NR, NC, -64, 0, NEGA>(pa, pb, s * STAGEB, acc, tri ? c + s : 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// The same ring for a DIAGONAL block's update, dt[u] -= X_ti X_tj^T on this wave's lower 16 x 16 tiles (t = w, w + 8, ... < 36
+// in row-major order of the triangle: waves 0-3 five, 4-7 four): only what the factorisation reads is computed -- 36 tiles
+// instead of the 48 that a 4 x 2 arrangement of 32 x 64 wave blocks covers with six busy waves of eight tiles each -- and all
+// eight waves share it: 5 instead of 8 tiles on the busiest wave.  One image of the 128 rows per chunk (X_I is both operands).
+// oa / ob: byte offsets of the tile's row blocks inside the image; per element the k order of every other update path.
+template <int NST, int NT>
+static __device__ __forceinline__ void s8_ring_run_diag(const double* XA, const unsigned (&voffA)[2], int nch, unsigned lds0,
+                                                        const unsigned (&p0)[4], const unsigned (&oa)[5], const unsigned (&ob)[5],
+                                                        d4 (&dt)[5], int w) {
+  static_assert(NST == 4, "the counted waits are written for four stages");
+  typedef __attribute__((address_space(3))) const double* lds_cdp;
+  constexpr unsigned STAGEB = 256 * S4_ROWB;
+#pragma unroll
+  for (int s = 0; s < NST - 1; s++)
+    if (s < nch) s8_issue(XA, voffA, s * S4_KC, lds0 + s * STAGEB, w);
+  for (int c = 0; c < nch; c += NST) {
+#pragma unroll
+    for (int s = 0; s < NST; s++) {
+      if (c + s >= nch) break;            // (wave- and workgroup-uniform)
+      const int rem = nch - (c + s) - 1;  // chunks behind this one
+      s4_wait_vm_n2(rem < NST - 2 ? rem : NST - 2);
+      __builtin_amdgcn_s_barrier();  // everybody's share of this chunk has landed; everybody is done with the previous one
+      if (c + s + NST - 1 < nch) s8_issue(XA, voffA, (c + s + NST - 1) * S4_KC, lds0 + (unsigned)(((s + NST - 1) % NST) * STAGEB), w);
+      double a[2][NT], b[2][NT];
+#pragma unroll
+      for (int u = 0; u < NT; u++) {
+        a[0][u] = *(lds_cdp)(uintptr_t)(p0[0] + s * STAGEB + oa[u]);
+        b[0][u] = *(lds_cdp)(uintptr_t)(p0[0] + s * STAGEB + ob[u]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3) {
+#pragma unroll
+          for (int u = 0; u < NT; u++) {
+            a[nxt][u] = *(lds_cdp)(uintptr_t)(p0[kk + 1] + s * STAGEB + oa[u]);
+            b[nxt][u] = *(lds_cdp)(uintptr_t)(p0[kk + 1] + s * STAGEB + ob[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NT; u++) dt[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][u], b[cur][u], dt[u], 0, 0, 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -688,29 +726,81 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
-    if (npan > 0 && !dead) {
-      // ---- 1. left-looking update with the panels 0 .. npan-1: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles)
+    if (npan > 0 && !dead && diag) {
+      // ---- 1d. a diagonal block: its 36 lower 16 x 16 tiles, dealt to the eight waves
       const double* const XA = M + (size_t)I * 128 * ld;
-      const double* const XB = M + (size_t)Jc * 128 * ld;
-      const bool skip = diag && wc == 1 && wr < 2;  // strictly above the diagonal: never read
-      unsigned pa[4], pb[4];
-      d4 acc[2][4];
-      s4_frag_addr(pa, lds0, wr * 32, lane);
-      s4_frag_addr(pb, diag ? lds0 : lds0 + AOPB, wc * 64, lane);  // (diagonal block: X_I is both operands, staged once)
+      const int lr = lane & 15, lk = lane >> 4;
+      unsigned p0[4], oa[5], ob[5];
+      s4_frag_addr(p0, lds0, 0, lane);
+      d4 dt[5];
+      int offc[5];
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int u = 0; u < 5; u++) {
+        const int tt = w + 8 * u;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tt) ti++;
+        const int tj = tt - ti * (ti + 1) / 2;
+        oa[u] = (unsigned)(ti * 16 * S4_ROWB);
+        ob[u] = (unsigned)(tj * 16 * S4_ROWB);
+        offc[u] = (ti * 16 + lk) * ld + tj * 16 + lr;
+        if (tt < 36) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};  // (no undefined value travels round the task loop)
-      if (!skip) gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+          for (int r = 0; r < 4; r++) dt[u][r] = C[(size_t)offc[u] + (size_t)(4 * r) * ld];
+        } else {
+          dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
+        }
+      }
       int q = 0;
       while (q < npan) {
         if (tid == 0) {
           int qq = q;
           bool ok = true;
-#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && (diag || ps_ld(xrJ + (p)) >= 1u))
+          while (qq < npan && ps_ld(xrI + qq) >= 1u) qq++;
+          if (qq == q) {  // caught up with the factorisation: wait for the next panel
+            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit);
+            qq = q + 1;
+            while (ok && qq < npan && ps_ld(xrI + qq) >= 1u) qq++;
+          }
+          ps_acquire();
+          sh_q = ok ? qq : -1;
+          if (tr && q == 0) tr[1] = wall_clock64();
+          if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
+        }
+        __syncthreads();
+        const int qq = sh_q;
+        if (qq < 0) return;  // abandoned
+        if (w < 4)
+          s8_ring_run_diag<PS_NST, 5>(XA + (size_t)q * 128, voffX, (qq - q) * 8, lds0, p0, oa, ob, dt, w);
+        else
+          s8_ring_run_diag<PS_NST, 4>(XA + (size_t)q * 128, voffX, (qq - q) * 8, lds0, p0, oa, ob, dt, w);
+        __syncthreads();  // (the ring and sh_q are free again)
+        q = qq;
+      }
+#pragma unroll
+      for (int u = 0; u < 5; u++) {
+        if (w + 8 * u < 36) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) C[(size_t)offc[u] + (size_t)(4 * r) * ld] = dt[u][r];
+        }
+      }
+    } else if (npan > 0 && !dead) {
+      // ---- 1. left-looking update with the panels 0 .. npan-1: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles)
+      const double* const XA = M + (size_t)I * 128 * ld;
+      const double* const XB = M + (size_t)Jc * 128 * ld;
+      unsigned pa[4], pb[4];
+      d4 acc[2][4];
+      s4_frag_addr(pa, lds0, wr * 32, lane);
+      s4_frag_addr(pb, lds0 + AOPB, wc * 64, lane);
+      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      int q = 0;
+      while (q < npan) {
+        if (tid == 0) {
+          int qq = q;
+          bool ok = true;
+#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
           while (qq < npan && PS_READY(qq)) qq++;
           if (qq == q) {  // caught up with the factorisation: wait for the next panel
-            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && (diag || ps_wait_ge(xrJ + q, 1u, err, a.spin_limit));
+            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
             qq = q + 1;
             while (ok && qq < npan && PS_READY(qq)) qq++;
           }
@@ -723,16 +813,11 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
         __syncthreads();
         const int qq = sh_q;
         if (qq < 0) return;  // abandoned
-        const int nch = (qq - q) * 8;
-        const size_t k0 = (size_t)q * 128;
-        if (diag)
-          s8_ring_run<PS_NST, 2, 4, 1, 1>(XA + k0, voffX, XA, voffX, nch, lds0, pa, pb, acc, w, 0, skip);
-        else
-          s8_ring_run<PS_NST, 2, 4, 1, 0>(XA + k0, voffX, XB + k0, voffX, nch, lds0, pa, pb, acc, w, 0, false);
+        s8_ring_run<PS_NST, 2, 4, 1>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, (qq - q) * 8, lds0, pa, pb, acc, w, 0);
         __syncthreads();  // (the ring and sh_q are free again)
         q = qq;
       }
-      if (!skip) gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
     }
     if (tr) tr[3] = wall_clock64();
     if (diag || presub) {
@@ -772,7 +857,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
 #pragma unroll
       for (int r = 0; r < 4; r++) yv[r] = yi[GK_ROWB(r0, 0, lane, r)];
-      s8_ring_run<PS_NST, 1, 8, 0, 0>(C, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1, false);
+      s8_ring_run<PS_NST, 1, 8, 0>(C, voffX, Wm, voffW, 8, lds0, pa, pb, acc, w, 1);
       // in place (every read of these rows was staged before the last barrier), right-hand side in the same pass:
       // one wave per row, fixed shuffle order (as trsm4_kernel)
 #pragma unroll
