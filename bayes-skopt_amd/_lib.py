@@ -80,6 +80,7 @@ SIGNATURES = {
     "bgp_set_persist": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing_columns": (C.c_int, [_vp, _dp, _ip]),
     "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "bgp_debug_ps_trace": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.c_size_t]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
     "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
     "bgp_mfma_f64_layout": (C.c_int, [C.c_int, _ip, _ip]),
@@ -391,6 +392,20 @@ class Context:
         z = np.empty(npad)
         _check(self._lib.bgp_debug_workspace(self._h, int(b), _p(L), _p(z)), "bgp_debug_workspace")
         return L, z
+
+    def ps_trace(self):
+        """In-kernel timeline of the last launch-free call (needs BGP_PS_TRACE=1 at context creation): (chain, tile) --
+        wall-clock stamps (100 MHz), 8 per (matrix, block column) of the chain role and 8 per tile task; None without a
+        trace (bgp_debug_ps_trace)."""
+        dims = (C.c_int * 3)()
+        _check(self._lib.bgp_debug_ps_trace(self._h, dims, None, 0), "bgp_debug_ps_trace")
+        B, nblk, total = dims[0], dims[1], dims[2]
+        if B * nblk == 0:
+            return None
+        buf = np.zeros(B * nblk * 8 + total * 8, dtype=np.uint64)
+        _check(self._lib.bgp_debug_ps_trace(self._h, dims, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size),
+               "bgp_debug_ps_trace")
+        return buf[: B * nblk * 8].reshape(B, nblk, 8), buf[B * nblk * 8:].reshape(total, 8)
 
     def set_streams(self, nstreams):
         _check(self._lib.bgp_set_streams(self._h, int(nstreams)), "bgp_set_streams")

@@ -240,6 +240,10 @@ int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
 int bgp_set_persist(bgp_ctx* ctx, int mode);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
 int bgp_set_timing(bgp_ctx* ctx, int enable);
+/* Debugging aid (BGP_PS_TRACE=1): in-kernel wall-clock stamps (100 MHz) of the last launch-free call.  dims = {matrices,
+ * block columns, tile tasks}; out (may be NULL to query dims) receives 8 stamps per (matrix, block column) of the chain
+ * role, then 8 per tile task; cap = capacity of out in 64-bit words.  Read by tools/persist_trace.py. */
+int bgp_debug_ps_trace(bgp_ctx* ctx, int* dims, unsigned long long* out, size_t cap);
 /* Debugging aid: working matrix (npad x npad doubles; L in the lower triangle after an LML call) and working right-hand
  * side (npad doubles, z = L^-1 y) of batch slot b as the last bgp_lml_batch left them; either pointer may be NULL. */
 int bgp_debug_workspace(bgp_ctx* ctx, int b, double* L, double* z);

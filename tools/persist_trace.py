@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """In-kernel timeline of ONE launch-free factorisation in its default form (the chain workgroup solves block (J+1, J) and
 updates block (J+1, J+1) itself): what a block column costs the chain -- pf_block, the wait for the tile workers'
-pre-updates, its own solve + update -- and what the tile tasks spend their time on.  usage: persist_trace_fat.py n d B"""
-import ctypes as C
+pre-updates, its own solve + update -- and what the tile tasks spend their time on.  usage: persist_trace.py n d B"""
 import os
 import sys
 
@@ -22,16 +21,10 @@ ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
 H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.05 * rng.randn(B, d + 2)
 for _ in range(4):
     ctx.lml(H)
-lib = _lib.load()
-lib.bgp_debug_ps_trace.restype = C.c_int
-lib.bgp_debug_ps_trace.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.c_size_t]
-dims = (C.c_int * 3)()
-lib.bgp_debug_ps_trace(ctx._h, dims, None, 0)
-Bt, nblk, total = dims[0], dims[1], dims[2]
-buf = np.zeros(Bt * nblk * 8 + total * 8, dtype=np.uint64)  # (total = owner slots)
-assert lib.bgp_debug_ps_trace(ctx._h, dims, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), buf.size) == 0
-ch = buf[: Bt * nblk * 8].reshape(Bt, nblk, 8).astype(np.int64)
-tl = buf[Bt * nblk * 8:].reshape(total, 8).astype(np.int64)
+tr = ctx.ps_trace()
+assert tr is not None, "no trace: was BGP_PS_TRACE=1 in place before the context was created?"
+ch, tl = tr[0].astype(np.int64), tr[1].astype(np.int64)
+Bt, nblk, total = ch.shape[0], ch.shape[1], tl.shape[0]
 t0 = ch[:, 0, 0].min()
 us = lambda v: (v - t0) / 100.0
 print(f"n={n} B={B} nblk={nblk} tile tasks={total}; times in us")
