@@ -72,7 +72,7 @@ SIGNATURES = {
     "bgp_comm_broadcast": (C.c_int, [_vp, _dp, C.c_size_t, C.c_int]),
     "bgp_comm_barrier": (C.c_int, [_vp]),
     "bgp_comm_nranks": (C.c_int, [_vp, _ip]),
-    "bgp_lml_batch_wait_allgather": (C.c_int, [_vp, _vp, C.c_int, _dp]),
+    "bgp_lml_batch_wait_allgather": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp, _ip]),
     "bgp_device_synchronize": (C.c_int, [C.c_int]),
     "bgp_set_streams": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing": (C.c_int, [_vp, _dp, _ip]),
@@ -80,7 +80,10 @@ SIGNATURES = {
     "bgp_set_persist": (C.c_int, [_vp, C.c_int]),
     "bgp_last_timing_columns": (C.c_int, [_vp, _dp, _ip]),
     "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
+    "bgp_debug_cov_factor": (C.c_int, [_vp, _ip, _dp]),
+    "bgp_persist_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "bgp_debug_ps_trace": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.c_size_t]),
+    "bgp_debug_pivot_root": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
     "bgp_bench_hbm_copy": (C.c_int, [C.c_int, C.c_longlong, C.c_int, _dp]),
     "bgp_mfma_f64_layout": (C.c_int, [C.c_int, _ip, _ip]),
@@ -393,6 +396,23 @@ class Context:
         _check(self._lib.bgp_debug_workspace(self._h, int(b), _p(L), _p(z)), "bgp_debug_workspace")
         return L, z
 
+    def debug_cov_factor(self):
+        """The (mpad, mpad) factor of the predictive covariance the last ``sample_y`` left (lower triangle); None without one."""
+        mp = C.c_int(0)
+        _check(self._lib.bgp_debug_cov_factor(self._h, C.byref(mp), C.cast(None, _dp)), "bgp_debug_cov_factor")
+        if mp.value == 0:
+            return None
+        L = np.empty((mp.value, mp.value))
+        _check(self._lib.bgp_debug_cov_factor(self._h, C.byref(mp), _p(L)), "bgp_debug_cov_factor")
+        return L
+
+    def persist_stats(self):
+        """Launch-free path bookkeeping (bgp_persist_stats): calls enqueued, time-outs, whether a time-out keeps the path off
+        and for how many eligible calls."""
+        v = (C.c_longlong * 4)()
+        _check(self._lib.bgp_persist_stats(self._h, v), "bgp_persist_stats")
+        return {"calls": int(v[0]), "timeouts": int(v[1]), "disabled": bool(v[2]), "cooldown_left": int(v[3])}
+
     def ps_trace(self):
         """In-kernel timeline of the last launch-free call (needs BGP_PS_TRACE=1 at context creation): (chain, tile) --
         wall-clock stamps (100 MHz), 8 per (matrix, block column) of the chain role and 8 per tile task; None without a
@@ -418,15 +438,20 @@ class Context:
         _check(self._lib.bgp_set_timing(self._h, int(bool(enable))), "bgp_set_timing")
         self._timing = bool(enable)
 
-    def lml_wait_allgather(self, comm, per_rank):
+    def lml_wait_allgather(self, comm, per_rank, local_error=0):
         """Collective form of ``lml_wait`` for the exact single-ensemble sharding: every rank has submitted its own rows
-        (possibly none) of the half-step's block; returns the (world, per_rank) log-likelihoods of all ranks, gathered
-        device to device over RCCL out of the contexts' resident result vectors (bgp_lml_batch_wait_allgather)."""
-        self._pending, self._pending_H = 0, None
+        (possibly none) of the half-step's block; returns ((world, per_rank) log-likelihoods of all ranks, (world,) status
+        words), gathered device to device over RCCL out of the contexts' resident result vectors
+        (bgp_lml_batch_wait_allgather).  ``local_error`` > 0: this rank's own work failed -- it still takes part (its peers
+        would block in the collective otherwise) and every rank finds the code in the status words."""
         out = np.empty((comm.world, int(per_rank)))
-        _check(self._lib.bgp_lml_batch_wait_allgather(self._h, comm._h, int(per_rank), _p(out)),
-               "bgp_lml_batch_wait_allgather")
-        return out
+        errs = np.zeros(comm.world, dtype=np.int32)
+        try:
+            rc = self._lib.bgp_lml_batch_wait_allgather(self._h, comm._h, int(per_rank), int(local_error), _p(out), _p(errs))
+        finally:
+            self._pending, self._pending_H = 0, None  # (the C call consumes the pending batch whatever its outcome)
+        _check(rc, "bgp_lml_batch_wait_allgather")
+        return out, errs
 
     def last_timing(self):
         ms = np.zeros(5)
@@ -519,6 +544,14 @@ def bench_hbm_copy(device=0, nbytes=1 << 30, iters=10):
     v = C.c_double(0.0)
     _check(load().bgp_bench_hbm_copy(device, nbytes, iters, C.byref(v)), "bgp_bench_hbm_copy")
     return v.value
+
+
+def pivot_root(x, device=0):
+    """(sqrt(x), 1 / sqrt(x)) as the diagonal-block factorisation forms its pivots (bgp_debug_pivot_root)."""
+    x = _c(x).ravel()
+    s, r = np.empty_like(x), np.empty_like(x)
+    _check(load().bgp_debug_pivot_root(int(device), x.size, _p(x), _p(s), _p(r)), "bgp_debug_pivot_root")
+    return s, r
 
 
 def mfma_f64_layout(device=0):

@@ -872,39 +872,65 @@ class _ShardedLogProb:
         rank, _lr, ws = distributed.world()
         B = Theta.shape[0]
         lo, hi = distributed.shard_rows(B, rank, ws)
+        # From here on every rank is committed to ONE collective in ``finish``.  Whatever fails locally in between -- the
+        # priors raising, a failed submit, a device error -- is carried in the token and reported THROUGH that collective
+        # (status word next to the values): a rank that raised here would leave its peers blocked in the all-gather.
         if gp.warp_inputs:  # per-walker warps: this rank's finished values are gathered from the host
-            return ("host", B, gp._log_prob_begin(Theta[lo:hi], priors, warp_priors) if hi > lo else None)
-        H = gp._canonical(Theta[lo:hi])
+            try:
+                return ("host", B, gp._log_prob_begin(Theta[lo:hi], priors, warp_priors) if hi > lo else None, None)
+            except Exception as exc:
+                return ("host", B, None, exc)
         # decided from what every rank sees alike (same block, same context settings): all ranks gather the same way
         can_async = not gp._ctx._timing and -(-B // ws) <= gp._ctx.max_batch
         native = distributed.backend() == "rccl" and can_async
-        submitted = gp._ctx.lml_submit(H) if (can_async and hi > lo) else False
+        submitted, lp, H, failure = False, None, None, None
         try:
+            H = gp._canonical(Theta[lo:hi])
+            submitted = gp._ctx.lml_submit(H) if (can_async and hi > lo) else False
             lp = _eval_priors(priors, Theta)  # all rows on every rank, while the device factorises this rank's
-        except BaseException:
-            if submitted:
-                gp._ctx.lml_wait()
-            raise
-        return ("dev", B, lp, H, submitted, native, hi > lo)
+        except Exception as exc:
+            failure = exc
+        return ("dev", B, lp, H, submitted, native, hi > lo, failure)
 
     def finish(self, token):
         gp = self._gp
         if token[0] == "single":
             return gp._log_prob_finish(token[1])
         if token[0] == "host":
-            _k, B, tok = token
-            local = gp._log_prob_finish(tok) if tok is not None else np.zeros(0)
-            return distributed.allgather_lml(None, B, local=local)
-        _k, B, lp, H, submitted, native, has_rows = token
+            _k, B, tok, failure = token
+            local = np.zeros(0)
+            if failure is None and tok is not None:
+                try:
+                    local = gp._log_prob_finish(tok)
+                except Exception as exc:
+                    failure = exc
+            return self._gather(None, B, local, failure)
+        _k, B, lp, H, submitted, native, has_rows, failure = token
         if native:
-            lml = distributed.allgather_lml(gp._ctx, B)
+            lml = self._gather(gp._ctx, B, None, failure)
         else:  # gloo group (CPU tests, ranks sharing one GPU) or a batch that could not go asynchronously
-            local = (gp._ctx.lml_wait() if submitted else gp._ctx.lml(H)) if has_rows else np.zeros(0)
-            lml = distributed.allgather_lml(None, B, local=local)
+            local = np.zeros(0)
+            try:
+                if submitted:
+                    local = gp._ctx.lml_wait()  # (also when the priors failed: the pending batch must be collected)
+                elif has_rows and failure is None:
+                    local = gp._ctx.lml(H)
+            except Exception as exc:
+                failure = failure or exc
+            lml = self._gather(None, B, local, failure)
         with np.errstate(invalid="ignore"):
             lp = lp + lml
         lp[~np.isfinite(lp)] = -np.inf
         return lp
+
+    @staticmethod
+    def _gather(ctx, B, local, failure):
+        try:
+            return distributed.allgather_lml(ctx, B, local=local, error=0 if failure is None else 1)
+        except distributed.ShardedEvaluationError as err:
+            if failure is not None:
+                raise err from failure
+            raise
 
 
 class _AsyncLogProb:

@@ -232,7 +232,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_NCRIT", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_NCRIT", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -301,7 +301,7 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->panels = 2;
     c->panels_auto = 1;
     const char* envp = getenv("BGP_PANELS");
-    if (envp && atoi(envp) >= 1 && atoi(envp) <= 8) {
+    if (envp && atoi(envp) >= 1 && atoi(envp) <= 64) {
       c->panels = atoi(envp);
       c->panels_auto = 0;
     }
@@ -408,16 +408,35 @@ static int lml_batch_impl(bgp_ctx* c, int B, const double* h, const double* warp
 
 static bool bgp_persist_auto(const bgp_ctx* c, int nb) { return bgp_persist_auto_rule(c->nblk, nb); }
 
+int bgp_ps_cooldown_calls() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("BGP_PS_COOLDOWN");
+    v = (e && atoi(e) > 0) ? atoi(e) : 256;
+  }
+  return v;
+}
+
+// Launch-free path bookkeeping of a context: out[0] = launch-free calls enqueued, out[1] = of which timed out (redone by
+// launches), out[2] = 1 while the path is switched off by a time-out, out[3] = eligible calls left before it is tried again
+// (0 with out[2] == 1: off for good after three time-outs, until bgp_set_persist(ctx, 1)).
+extern "C" int bgp_persist_stats(bgp_ctx* c, long long* out) {
+  if (!c || !out) return BGP_ERR_INVALID;
+  out[0] = c->ps_calls;
+  out[1] = c->ps_timeouts;
+  out[2] = c->ps_disabled;
+  out[3] = c->ps_cooldown;
+  return BGP_OK;
+}
+
 // A persistent call whose waits timed out (error word != 0 behind the synchronisation) is redone on the multi-launch
-// path, once and loudly; the context stays on that path afterwards.
+// path, loudly; bgp_ps_note_timeout decides how long the context stays there.
 static int ps_check(bgp_ctx* c) {
   if (!c->ps_inflight) return 0;
   c->ps_inflight = 0;
   if (!c->ps_herr || *c->ps_herr == 0) return 0;
   *c->ps_herr = 0;
-  c->ps_disabled = 1;
-  fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); the "
-                  "batch is redone on the multi-launch path, which this context keeps from now on\n");
+  bgp_ps_note_timeout(c, "the batch is redone");
   return 1;
 }
 
@@ -497,8 +516,9 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
     // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
     // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-    const bool use_ps = !fused_small && !fused_gram && !c->timing && !c->ps_disabled && bgp_persist_fits(c, nb) &&
-                        (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb)));
+    const bool use_ps = !fused_small && !fused_gram && !c->timing && bgp_persist_fits(c, nb) &&
+                        (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
+    if (use_ps) c->ps_calls++;
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     if (fused_small) {
       // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
@@ -740,6 +760,22 @@ extern "C" int bgp_debug_workspace(bgp_ctx* c, int b, double* Lout, double* zout
   return BGP_OK;
 }
 
+// The factor sample_y's last call left in the child workspace (mpad x mpad doubles, L in the lower triangle; the strict upper
+// triangle is whatever the covariance build left there).
+extern "C" int bgp_debug_cov_factor(bgp_ctx* c, int* mpad, double* Lout) {
+  BGP_REQUIRE_IDLE(c, "bgp_debug_cov_factor");
+  if (!c || !mpad) {
+    bgp_set_error("bgp_debug_cov_factor: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  *mpad = c->child ? c->child->npad : 0;
+  if (!Lout || !c->child) return BGP_OK;
+  BGP_HIP(hipSetDevice(c->device));
+  const size_t np = c->child->npad;
+  BGP_HIP(hipMemcpy(Lout, c->child->dK, np * np * sizeof(double), hipMemcpyDeviceToHost));
+  return BGP_OK;
+}
+
 extern "C" int bgp_device_synchronize(int device) {
   BGP_HIP(hipSetDevice(device));
   BGP_HIP(hipDeviceSynchronize());
@@ -787,7 +823,7 @@ extern "C" int bgp_set_persist(bgp_ctx* c, int mode) {
   } else {
     c->persist = mode;
   }
-  if (mode == 1) c->ps_disabled = 0;
+  if (mode == 1) c->ps_disabled = c->ps_cooldown = 0;
   return BGP_OK;
 }
 

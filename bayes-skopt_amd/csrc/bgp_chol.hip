@@ -70,6 +70,34 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   (void)pf_block<GEN, STAT, FORM>(b, Kbuf, Wbuf, yw, accb, lml, status, n, ld, mstride, ystride, nblk, k, gen);
 }
 
+// Debugging aid / accuracy test: the pivot root of the diagonal-block factorisation (pf_pivot_root) on n arguments.
+__global__ void pivot_root_kernel(const double* __restrict__ x, double* __restrict__ s, double* __restrict__ iv, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double a, b;
+  pf_pivot_root(x[i], a, b);
+  s[i] = a;
+  iv[i] = b;
+}
+extern "C" int bgp_debug_pivot_root(int device, int n, const double* x, double* sqrt_out, double* rsqrt_out) {
+  if (n <= 0 || !x || !sqrt_out || !rsqrt_out) {
+    bgp_set_error("bgp_debug_pivot_root: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(device));
+  double* d = nullptr;
+  BGP_HIP(hipMalloc(&d, (size_t)3 * n * sizeof(double)));
+  hipError_t e = hipMemcpy(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(pivot_root_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, d, d + n, d + 2 * (size_t)n, n);
+    e = hipMemcpy(sqrt_out, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  }
+  if (e == hipSuccess) e = hipMemcpy(rsqrt_out, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  BGP_HIP(e);
+  return BGP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Launch-free factorisation of SMALL batches (B <= 64 matrices, or one large matrix): ONE persistent kernel per batch
 // instead of ~3 dependent launches per block column (ps_kernel, bgp_syrk4.hip; the diagonal-block code is bgp_pf.h).

@@ -13,6 +13,8 @@
 #include "bgp_common.h"
 
 #include <dlfcn.h>
+
+#include <cstdlib>
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -27,6 +29,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                         // optional (bounded waits)
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
 };
 RcclApi g_rccl;
 
@@ -55,6 +59,8 @@ int load_rccl() {
   BGP_SYM(Broadcast, "ncclBroadcast")
   BGP_SYM(GetErrorString, "ncclGetErrorString")
 #undef BGP_SYM
+  g_rccl.CommAbort = reinterpret_cast<decltype(g_rccl.CommAbort)>(dlsym(h, "ncclCommAbort"));
+  g_rccl.CommGetAsyncError = reinterpret_cast<decltype(g_rccl.CommGetAsyncError)>(dlsym(h, "ncclCommGetAsyncError"));
   g_rccl.handle = h;
   return BGP_OK;
 }
@@ -69,7 +75,71 @@ struct bgp_comm {
   size_t cap_send = 0, cap_recv = 0;
   double* hrecv = nullptr;  // pinned landing buffer of the device-resident gathers
   size_t cap_hrecv = 0;
+  hipEvent_t ev_ctx = nullptr;  // the communicator's stream waits for a context's stream through this event
+  int aborted = 0;              // the communicator was aborted (a collective outlasted its bound / an asynchronous error)
 };
+
+// Every collective is waited for with a BOUND.  RCCL itself has no time-out: a rank that died (or returned before the
+// collective) leaves its peers in the kernel for ever.  The host polls the communicator's stream; an asynchronous error
+// reported by RCCL, or BGP_COMM_TIMEOUT_S seconds (default 300) without completion, aborts the communicator
+// (ncclCommAbort) and the call returns BGP_ERR_COMM: the process fails instead of hanging, and so do its peers.
+static double comm_timeout_s() {
+  static double v = 0.0;
+  if (v == 0.0) {
+    const char* e = getenv("BGP_COMM_TIMEOUT_S");
+    v = (e && atof(e) > 0.0) ? atof(e) : 300.0;
+  }
+  return v;
+}
+
+static int comm_sync(bgp_comm* c, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned it = 0;; it++) {
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e == hipSuccess) {
+      bgp_xfer().release(c->stream);
+      return BGP_OK;
+    }
+    (void)hipGetLastError();
+    if (e != hipErrorNotReady) {
+      bgp_set_error("%s: the communicator's stream failed: %s", what, hipGetErrorString(e));
+      bgp_xfer_drop_pending();
+      return BGP_ERR_HIP;
+    }
+    if ((it & 255) != 255) {
+      __builtin_ia32_pause();
+      continue;
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ncclResult_t ar = ncclSuccess;
+    const bool have = g_rccl.CommGetAsyncError && c->comm && g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess;
+    const bool bad = have && ar != ncclSuccess && ar != ncclInProgress;
+    if (bad || el > comm_timeout_s()) {
+      if (bad)
+        bgp_set_error("%s: RCCL reports an asynchronous error (%s); communicator aborted", what, g_rccl.GetErrorString(ar));
+      else
+        bgp_set_error("%s: the collective did not complete within %.0f s (BGP_COMM_TIMEOUT_S): a peer has died or left; "
+                      "communicator aborted", what, comm_timeout_s());
+      if (g_rccl.CommAbort && c->comm) {
+        (void)g_rccl.CommAbort(c->comm);
+        c->comm = nullptr;
+      }
+      c->aborted = 1;
+      bgp_xfer_drop_pending();
+      return BGP_ERR_COMM;
+    }
+    if (el > 0.2) usleep(200);  // a long wait: stop burning the core
+  }
+}
+
+#define BGP_COMM_LIVE(c, who)                                                                   \
+  do {                                                                                          \
+    if ((c)->aborted || !(c)->comm) {                                                           \
+      bgp_set_error(who ": the communicator was aborted by an earlier failed collective");      \
+      return BGP_ERR_COMM;                                                                      \
+    }                                                                                           \
+  } while (0)
+
 
 #define BGP_NCCL(call)                                                                          \
   do {                                                                                          \
@@ -142,6 +212,8 @@ extern "C" int bgp_comm_unique_id(void* id128) {
   return BGP_OK;
 }
 
+extern "C" void bgp_comm_destroy(bgp_comm* c);
+
 extern "C" int bgp_comm_init(int device, int rank, int world, const void* id128, bgp_comm** out) {
   if (!out || !id128 || world < 1 || rank < 0 || rank >= world) {
     bgp_set_error("bgp_comm_init: bad argument (rank %d of %d)", rank, world);
@@ -178,6 +250,16 @@ extern "C" int bgp_comm_init(int device, int rank, int world, const void* id128,
     delete c;
     return BGP_ERR_HIP;
   }
+  // the buffers of the per-half-step exchange exist before the first half-step: no allocation (that could fail on one rank
+  // only) between a submitted batch and its collective
+  if (hipEventCreateWithFlags(&c->ev_ctx, hipEventDisableTiming) != hipSuccess ||
+      comm_reserve(c, 4096 + 1, (size_t)(4096 + 1) * world) != BGP_OK ||
+      hipHostMalloc((void**)&c->hrecv, (size_t)(4096 + 1) * world * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+    bgp_set_error("bgp_comm_init: allocating the exchange buffers failed");
+    bgp_comm_destroy(c);
+    return BGP_ERR_HIP;
+  }
+  c->cap_hrecv = (size_t)(4096 + 1) * world;
   *out = c;
   return BGP_OK;
 }
@@ -185,7 +267,8 @@ extern "C" int bgp_comm_init(int device, int rank, int world, const void* id128,
 extern "C" void bgp_comm_destroy(bgp_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream && !c->aborted) (void)hipStreamSynchronize(c->stream);
+  if (c->ev_ctx) (void)hipEventDestroy(c->ev_ctx);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->dsend) (void)hipFree(c->dsend);
   if (c->drecv) (void)hipFree(c->drecv);
@@ -200,49 +283,107 @@ extern "C" int bgp_comm_nranks(bgp_comm* c, int* nranks) {
     bgp_set_error("bgp_comm_nranks: NULL argument");
     return BGP_ERR_INVALID;
   }
+  BGP_COMM_LIVE(c, "bgp_comm_nranks");
   BGP_NCCL(g_rccl.CommCount(c->comm, nranks));
   return BGP_OK;
 }
 
 // Exact single-ensemble sharding (SURVEY.md 8e option 1): every rank has submitted ITS rows of the half-step's proposal
-// block with bgp_lml_batch_submit (at most per_rank of them); this call replaces bgp_lml_batch_wait.  The communicator's
-// stream waits for the context's stream, RCCL all-gathers per_rank doubles straight out of every context's device-resident
-// log-likelihood vector, and ONE copy brings the world * per_rank values to the host (rank-major; the entries behind a
-// rank's own row count are padding).  No host staging on the send side, no second synchronisation.
-extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_rank, double* lml_all) {
-  if (!ctx || !c || !lml_all || per_rank <= 0) {
+// block with bgp_lml_batch_submit (at most per_rank of them); this call replaces bgp_lml_batch_wait.
+//
+// ONE host synchronisation per half-step: the communicator's stream waits for the context's stream through an event (no
+// host round trip), a pack kernel puts the rank's per_rank log-likelihoods and ONE status word side by side, RCCL
+// all-gathers the world * (per_rank + 1) doubles, one copy brings them to pinned host memory, and the host waits for that
+// (bounded: comm_sync).
+//
+// Every rank ENTERS the collective whatever happened locally -- RCCL has no time-out, a rank that returned early would
+// leave its peers in the kernel.  The status word carries the news instead:
+//   0               sound values;
+//   local_error     the caller's own failure between submit and wait (an exception in the prior evaluation, a failed
+//                   submit: any code > 0), or a failure of this function's local steps: the values are NaN;
+//   BGP_RANK_REDO   the rank's launch-free factorisation timed out (read on the device from the kernel's error word): it
+//                   redoes its batch by launches and EVERY rank, having seen the same word, goes round the gather again.
+// errors_out[r] = status word of rank r (0 = sound).  Returns BGP_OK when the collective itself completed -- the caller
+// looks at errors_out, the same on every rank, and every rank raises alike --, BGP_ERR_COMM when it did not (aborted).
+#define BGP_RANK_REDO 1000000
+__global__ void lml_pack_kernel(const double* __restrict__ dlml, int Bp, int per, const unsigned* __restrict__ ps_err,
+                                int local_error, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned pe = ps_err ? __hip_atomic_load(ps_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const int st = local_error ? local_error : (pe ? BGP_RANK_REDO : 0);
+  if (i < per) out[i] = (i < Bp && st == 0) ? dlml[i] : __builtin_nan("");
+  if (i == per) out[per] = (double)st;
+}
+
+extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_rank, int local_error, double* lml_all,
+                                            int* errors_out) {
+  if (!ctx || !c || !lml_all || !errors_out || per_rank <= 0 || local_error < 0) {
+    // (an argument error of this kind is the same on every rank: nobody enters the collective)
     bgp_set_error("bgp_lml_batch_wait_allgather: bad argument");
     return BGP_ERR_INVALID;
   }
-  if (per_rank > ctx->max_batch || ctx->pending_B > per_rank || ctx->device != c->device) {
-    bgp_set_error("bgp_lml_batch_wait_allgather: per_rank = %d must cover the pending batch (%d) and fit max_batch = %d, on "
-                  "the communicator's device", per_rank, ctx->pending_B, ctx->max_batch);
-    return BGP_ERR_INVALID;
-  }
-  BGP_HIP(hipSetDevice(c->device));
-  const size_t total = (size_t)per_rank * c->world;
-  int rc = comm_reserve(c, 0, total);
-  if (rc) return rc;
-  if (total > c->cap_hrecv) {
-    if (c->hrecv) (void)hipHostFree(c->hrecv);
-    c->hrecv = nullptr;
-    c->cap_hrecv = 0;
-    BGP_HIP(hipHostMalloc((void**)&c->hrecv, total * sizeof(double), hipHostMallocDefault));
-    c->cap_hrecv = total;
-  }
+  BGP_COMM_LIVE(c, "bgp_lml_batch_wait_allgather");
   const int Bp = ctx->pending_B;
-  ctx->pending_B = 0;  // (a rank without rows of its own has nothing pending: it contributes padding)
-  // the local batch must be complete and sound before its values leave the device: a launch-free factorisation that
-  // timed out is redone here (this wait is the host's only synchronisation with the context's stream per half-step)
-  BGP_HIP(bgp_stream_sync(ctx->stream));
-  if (Bp > 0) {
-    rc = bgp_lml_redo_if_abandoned(ctx, Bp);
-    if (rc) return rc;
+  ctx->pending_B = 0;  // the pending batch is consumed here whatever happens (a rank without rows has nothing pending)
+  if (per_rank > ctx->max_batch || Bp > per_rank || ctx->device != c->device) {
+    bgp_set_error("bgp_lml_batch_wait_allgather: per_rank = %d must cover the pending batch (%d) and fit max_batch = %d, on "
+                  "the communicator's device", per_rank, Bp, ctx->max_batch);
+    local_error = local_error ? local_error : BGP_ERR_INVALID;  // ... and is reported THROUGH the collective
   }
-  BGP_NCCL(g_rccl.AllGather(ctx->dlml, c->drecv, (size_t)per_rank, ncclFloat64, c->comm, c->stream));
-  BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(bgp_stream_sync(c->stream));
-  memcpy(lml_all, c->hrecv, total * sizeof(double));
+  const size_t slot = (size_t)per_rank + 1, total = slot * c->world;
+  int rc = BGP_OK;
+  if (hipSetDevice(c->device) != hipSuccess) local_error = local_error ? local_error : BGP_ERR_HIP;
+  if (slot > c->cap_send || total > c->cap_recv || total > c->cap_hrecv) {
+    // larger than the buffers of bgp_comm_init (per_rank > 4096): grown here, the same on every rank
+    rc = comm_reserve(c, slot, total);
+    if (!rc && total > c->cap_hrecv) {
+      if (c->hrecv) (void)hipHostFree(c->hrecv);
+      c->hrecv = nullptr;
+      c->cap_hrecv = 0;
+      if (hipHostMalloc((void**)&c->hrecv, total * sizeof(double), hipHostMallocDefault) == hipSuccess)
+        c->cap_hrecv = total;
+      else
+        rc = BGP_ERR_HIP;
+    }
+    if (rc) {  // without buffers this rank cannot take part: abort the communicator so that the peers fail too
+      if (g_rccl.CommAbort && c->comm) (void)g_rccl.CommAbort(c->comm);
+      c->comm = nullptr;
+      c->aborted = 1;
+      bgp_set_error("bgp_lml_batch_wait_allgather: growing the exchange buffers failed; communicator aborted");
+      return BGP_ERR_COMM;
+    }
+  }
+  for (int round = 0; round < 3; round++) {
+    // the context's work of this half-step -> the communicator's stream (device-side dependency, no host wait)
+    if (hipEventRecord(c->ev_ctx, ctx->stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_ctx, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(ctx->stream);  // (fall back to the host wait; the values are then certainly there)
+    }
+    const unsigned* pe = (round == 0 && ctx->ps_inflight && ctx->ps_flags) ? ctx->ps_flags + PS_ERROR : nullptr;
+    hipLaunchKernelGGL(lml_pack_kernel, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, c->stream, ctx->dlml, Bp,
+                       per_rank, pe, local_error, c->dsend);
+    BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, slot, ncclFloat64, c->comm, c->stream));
+    BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    rc = comm_sync(c, "bgp_lml_batch_wait_allgather");
+    if (rc) return rc;
+    // (the communicator's stream waited for the context's: that one is complete too -- release its staged transfers)
+    (void)bgp_stream_sync(ctx->stream);
+    bool redo = false;
+    for (int r = 0; r < c->world; r++) {
+      const double sw = c->hrecv[r * slot + per_rank];
+      errors_out[r] = (sw == sw && sw >= 0.0 && sw <= 2e9) ? (int)sw : BGP_ERR_COMM;
+      redo = redo || errors_out[r] == BGP_RANK_REDO;
+      memcpy(lml_all + (size_t)r * per_rank, c->hrecv + r * slot, (size_t)per_rank * sizeof(double));
+    }
+    // this rank's own launch-free call: note a time-out (and redo the batch by launches) or clear the in-flight mark
+    if (Bp > 0 && !local_error) {
+      const int rr = bgp_lml_redo_if_abandoned(ctx, Bp);
+      if (rr) local_error = rr;  // ... reported in the next round
+    }
+    if (!redo) return BGP_OK;
+    for (int r = 0; r < c->world; r++)
+      if (errors_out[r] == BGP_RANK_REDO) errors_out[r] = 0;  // (settled by the next round)
+  }
   return BGP_OK;
 }
 
@@ -252,14 +393,14 @@ extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count,
     return BGP_ERR_INVALID;
   }
   if (count == 0) return BGP_OK;
+  BGP_COMM_LIVE(c, "bgp_comm_allgather");
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count * c->world);
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, count, ncclFloat64, c->comm, c->stream));
   BGP_HIP(bgp_memcpy_async(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(bgp_stream_sync(c->stream));
-  return BGP_OK;
+  return comm_sync(c, "bgp_comm_allgather");
 }
 
 extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) {
@@ -268,14 +409,14 @@ extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) 
     return BGP_ERR_INVALID;
   }
   if (count == 0) return BGP_OK;
+  BGP_COMM_LIVE(c, "bgp_comm_allreduce_max");
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count);
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllReduce(c->dsend, c->drecv, count, ncclFloat64, ncclMax, c->comm, c->stream));
   BGP_HIP(bgp_memcpy_async(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(bgp_stream_sync(c->stream));
-  return BGP_OK;
+  return comm_sync(c, "bgp_comm_allreduce_max");
 }
 
 extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int root) {
@@ -284,14 +425,14 @@ extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int ro
     return BGP_ERR_INVALID;
   }
   if (count == 0) return BGP_OK;
+  BGP_COMM_LIVE(c, "bgp_comm_broadcast");
   BGP_HIP(hipSetDevice(c->device));
   int rc = comm_reserve(c, count, count);
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.Broadcast(c->dsend, c->drecv, count, ncclFloat64, root, c->comm, c->stream));
   BGP_HIP(bgp_memcpy_async(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  BGP_HIP(bgp_stream_sync(c->stream));
-  return BGP_OK;
+  return comm_sync(c, "bgp_comm_broadcast");
 }
 
 extern "C" int bgp_comm_barrier(bgp_comm* c) {

@@ -165,7 +165,10 @@ struct bgp_ctx {
   size_t cap_psflags = 0;
   unsigned* ps_herr = nullptr;  // pinned: error word of the last persistent call
   int ps_inflight = 0;          // a persistent call is on the stream (its error word is checked behind the sync)
-  int ps_disabled = 0;          // a persistent call timed out: multi-launch path from now on
+  int ps_disabled = 0;          // a persistent call timed out: multi-launch path (see bgp_ps_note_timeout)
+  int ps_cooldown = 0;          // eligible calls left on the multi-launch path before the launch-free one is tried again
+  long long ps_calls = 0;       // launch-free calls enqueued by this context (bgp_persist_stats)
+  long long ps_timeouts = 0;    // ... of which timed out and were redone by launches
   int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
   unsigned long long* ps_trace = nullptr;  // BGP_PS_TRACE=1: device buffer of in-kernel time stamps (bgp_debug_ps_trace)
   size_t cap_pstrace = 0;
@@ -261,6 +264,26 @@ static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B 
 // schedule's kernels are the better tile workers), and >= 100 unless there are at least 12 block columns.
 static inline bool bgp_persist_auto_rule(int nblk, int nb) {
   return nblk >= 6 && nb * nblk <= 400 && (nblk >= 12 || nb * nblk >= 100);
+}
+// A launch-free call timed out (a wait outlasted BGP_PS_TIMEOUT_MS: its workgroups were not co-resident -- another context,
+// process or RCCL kernel held CUs -- or the device was oversubscribed).  One transient event must not cost the context
+// the path for life: the next BGP_PS_COOLDOWN eligible calls go by launches, then the launch-free path is tried again;
+// after the third time-out it stays off (bgp_set_persist(ctx, 1) re-arms it).  bgp_persist_stats reports the counts.
+int bgp_ps_cooldown_calls();  // BGP_PS_COOLDOWN, default 256 (bgp_api.hip)
+static inline void bgp_ps_note_timeout(bgp_ctx* c, const char* what) {
+  c->ps_timeouts++;
+  c->ps_disabled = 1;
+  c->ps_cooldown = c->ps_timeouts >= 3 ? 0 : bgp_ps_cooldown_calls();
+  if (c->ps_timeouts <= 3)
+    fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); %s on the "
+                    "multi-launch path, which this context keeps %s (time-out %lld of this context; bgp_persist_stats)\n", what,
+            c->ps_cooldown ? "for its next eligible calls (BGP_PS_COOLDOWN, 256)" : "from now on", c->ps_timeouts);
+}
+// (call only when the batch is otherwise eligible: the cool-down counts eligible calls)
+static inline bool bgp_ps_allowed(bgp_ctx* c) {
+  if (!c->ps_disabled) return true;
+  if (c->ps_cooldown > 0 && --c->ps_cooldown == 0) c->ps_disabled = 0;
+  return false;
 }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);

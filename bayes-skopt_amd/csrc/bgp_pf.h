@@ -37,6 +37,26 @@ static __device__ __forceinline__ void micro_cols(double (&a)[16], double (&macc
   }
 }
 
+// The pivot's root and reciprocal root together, from the hardware seed v_rsq_f64 (relative error up to 1e-7):
+// one coupled Goldschmidt step (rounds 1-3 stopped here: sqrt within 36 ulp, 1/sqrt within 20 ulp of the correctly rounded
+// values over 1e7 arguments in [1e-12, 1e6] -- tools/pivot_sqrt_probe.hip) and one residual correction of each:
+//     dj  += (x - dj^2) * inv / 2          ->  sqrt:   <= 0.5 ulp (99.98 % correctly rounded, like LAPACK's dpotrf pivot)
+//     inv += inv * (1 - dj * inv)          ->  1/sqrt: <= 1.5 ulp
+// (tests/test_gpu_lml.py::test_pivot_root_accuracy asserts the bounds through bgp_debug_pivot_root).  Four more dependent
+// operations per pivot: 33 -> 40 ns per root on a dependent chain, < 1 us per 128 x 128 diagonal block.
+static __device__ __forceinline__ void pf_pivot_root(double x, double& dj, double& inv) {
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double g = x * y0, h = 0.5 * y0;
+  const double r = fma(-g, h, 0.5);
+  const double g1 = fma(g, r, g);
+  const double y1 = fma(y0, r, y0);
+  const double hy = 0.5 * y1;
+  const double d = fma(-g1, g1, x);
+  dj = fma(d, hy, g1);
+  const double e = fma(-dj, y1, 1.0);
+  inv = fma(y1, e, y1);
+}
+
 template <int J>
 static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr,
                                                       int& bad) {
@@ -44,14 +64,8 @@ static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&
     asm volatile("s_nop 1");  // a[J] was last written by the inline-asm updates above: DPP read hazard (2 wait states)
     const double djj = bc16<J>(a[J]);
     bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
-    // sqrt and 1/sqrt together from the hardware seed by one coupled (Goldschmidt) step: three dependent
-    // operations on the pivot chain instead of the library rsqrt's six
-    const double y0 = __builtin_amdgcn_rsq(djj);
-    const double g = djj * y0, h = 0.5 * y0;
-    const double r = fma(-g, h, 0.5);
-    const double dj = fma(g, r, g);        // sqrt(djj)
-    const double hh = fma(h, r, h);
-    const double inv = hh + hh;            // 1 / sqrt(djj)
+    double dj, inv;  // sqrt(djj), 1 / sqrt(djj)
+    pf_pivot_root(djj, dj, inv);
     a[J] = (lr == J) ? dj : a[J] * inv;
     const double naj = -a[J];
     const double mj = (((lr == J) ? 1.0 : 0.0) - macc[J]) * inv;  // M[J][lane]

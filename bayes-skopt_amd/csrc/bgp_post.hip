@@ -996,9 +996,10 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
       // the covariance's factorisation -- ONE matrix of 79 block columns at 10 000 candidates, the longest launch chain of
       // a tell -- on the launch-free path (12.6 -> 10.9 ms per call, same draws); should a wait time out, the covariance
       // is rebuilt and factorised by launches, and the context stays on them
-      const bool ps = !c->ps_disabled && bgp_persist_fits(w, 1) &&
-                      (c->persist == 1 || (c->persist == -1 && bgp_persist_auto_rule(w->nblk, 1)));
+      const bool ps = bgp_persist_fits(w, 1) && (c->persist == 1 || (c->persist == -1 && bgp_persist_auto_rule(w->nblk, 1))) &&
+                      bgp_ps_allowed(c);
       if (ps) {
+        c->ps_calls++;
         w->persist = 1;
         if ((rc = bgp_launch_cholesky_persist(w, 1))) break;
       } else if ((rc = bgp_launch_cholesky(w, 1, 0))) {
@@ -1008,9 +1009,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
       SY(bgp_stream_sync(c->stream));
       if (ps && w->ps_herr && *w->ps_herr != 0) {
         *w->ps_herr = 0;
-        c->ps_disabled = 1;
-        fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); the "
-                        "covariance is rebuilt and factorised on the multi-launch path, which this context keeps from now on\n");
+        bgp_ps_note_timeout(c, "the covariance is rebuilt and factorised");
         continue;
       }
       break;

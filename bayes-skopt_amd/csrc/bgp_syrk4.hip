@@ -252,6 +252,10 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
         s4_issue<T>(cur.XA, voff, (c + s + 1) * S4_KC, nb, w);
         if (!cur.diag) s4_issue<T>(cur.XB, voff, (c + s + 1) * S4_KC, nb + OPB, w);
       }
+#ifdef BGP_FAULT_INJECT  // tests/fault/ only (never in libbgp.so): a trailing update that drops its last 16-wide k-chunk on
+      // the tiles from matrix row 1536 on -- what tests/test_gpu_dense.py must turn red on
+      if ((BGP_FAULT_INJECT & 1) && NEGA == 1 && !ZEROC && cur.gi0 >= 1536 && c + s == nch - 1) continue;
+#endif
       s4_mma<NR, NC, CREL, VAR, NEGA>(pa, pb, s * STAGEB, acc);
       __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs of this chunk above the next wait + barrier
     }
@@ -813,7 +817,11 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
         __syncthreads();
         const int qq = sh_q;
         if (qq < 0) return;  // abandoned
-        s8_ring_run<PS_NST, 2, 4, 1>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, (qq - q) * 8, lds0, pa, pb, acc, w, 0);
+        int nch_run = (qq - q) * 8;
+#ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
+        if ((BGP_FAULT_INJECT & 2) && I >= 12 && qq == npan) nch_run -= 1;
+#endif
+        s8_ring_run<PS_NST, 2, 4, 1>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, nch_run, lds0, pa, pb, acc, w, 0);
         __syncthreads();  // (the ring and sh_q are free again)
         q = qq;
       }

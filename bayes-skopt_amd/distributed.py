@@ -36,9 +36,15 @@ import time
 import numpy as np
 
 __all__ = ["world", "init_process_group", "destroy_process_group", "gather_chains", "barrier", "max_over_ranks",
-           "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend", "group_info", "allgather_lml"]
+           "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend", "group_info", "allgather_lml",
+           "ShardedEvaluationError"]
 
-_state = {"backend": None, "comm": None, "rank": 0, "world": 1, "device": None}
+_state = {"backend": None, "comm": None, "rank": 0, "world": 1, "device": None, "job_prefix": None, "attempt": 0}
+
+
+class ShardedEvaluationError(RuntimeError):
+    """A rank's share of a sharded proposal block failed.  Raised on EVERY rank of the group from the same gathered status
+    words (the failing rank still took part in the collective), so that the whole job stops instead of hanging."""
 
 
 def world():
@@ -121,8 +127,11 @@ def _comm_dir():
 
 
 def _job_prefix(ws):
-    tag = "%s_%s_%s_ws%d" % (os.environ.get("MASTER_PORT", "29500"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                             _job_id(), ws)
+    """Names of this rendezvous' files: job (launcher pid + start time, port, run id), the launcher's restart count (a
+    worker restarted by torchrun --max-restarts keeps its parent) and this process's group-formation attempt (a second
+    init_process_group in one process): no two attempts share a name."""
+    tag = "%s_%s_%s_ws%d_r%s_a%d" % (os.environ.get("MASTER_PORT", "29500"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                    _job_id(), ws, os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), _state["attempt"])
     return os.path.join(_comm_dir(), "job_" + tag.replace("/", "_"))
 
 
@@ -156,38 +165,90 @@ def _cleanup_job_files(prefix):
             pass
 
 
+def _uid_digest(uid):
+    import hashlib
+
+    return hashlib.sha256(bytes(uid)).hexdigest()[:16].encode()
+
+
+_T_START = time.time()
+
+
+def _fresh_abort(prefix):
+    """An abort marker written during THIS process's lifetime (a leftover of an earlier attempt under a reused name is
+    older than this process and does not count)."""
+    try:
+        return os.stat(prefix + ".abort").st_mtime >= _T_START - 1.0
+    except OSError:
+        return False
+
+
 def _exchange_unique_id_files(rank, ws, timeout):
-    """Single node.  Phase 1: rank 0 writes <job>.uid (atomic rename), the others poll for it.  Phase 2: every rank
-    writes <job>.st.<rank> = b"ok" or b"fail: ..." and waits for all ws of them.  Returns the id when ALL ranks have
-    it; raises RuntimeError (on every rank alike) otherwise -- before anyone has entered ncclCommInitRank."""
+    """Single node, files in the per-user directory, a handshake that no leftover can satisfy:
+      1. every rank r > 0 writes <job>.hello.<r> = a nonce it has just drawn (and rewrites it should rank 0's initial
+         clean-up remove it);
+      2. rank 0 creates the id and answers every hello with <job>.ack.<r> = that nonce + the 128 id bytes; a rank only
+         accepts an ack that carries ITS nonce -- written by a live rank 0 of this attempt, whatever files an earlier,
+         killed attempt under the same name (a reused BGP_COMM_JOB) has left behind;
+      3. every rank writes <job>.st.<r> = b"ok:<digest of the id it holds>" or b"fail: ..." and waits for all ws of them;
+         a status only counts when it names the same id (the id is unique to the attempt).
+    Returns the id when ALL ranks hold it; raises RuntimeError (on every rank alike) otherwise -- before anyone has
+    entered ncclCommInitRank, so one rank timing out cannot leave the others blocked in the collective."""
     from . import _lib
 
     prefix = _job_prefix(ws)
+    _state["job_prefix"] = prefix
     deadline = time.monotonic() + timeout
     uid, err = None, None
+    acked = set()
+
+    def serve_acks():  # rank 0: answer the hellos seen so far
+        for r in range(1, ws):
+            if r in acked:
+                continue
+            nonce = _read_owned("%s.hello.%d" % (prefix, r))
+            if nonce is not None and len(nonce) == 32:
+                _write_private("%s.ack.%d" % (prefix, r), nonce + uid)
+                acked.add(r)
+
     try:
         if rank == 0:
-            _cleanup_job_files(prefix)  # (nothing of this job can exist yet; a pid + start-time collision is unheard of)
+            _cleanup_job_files(prefix)  # (leftovers of a reused name go; a hello removed here is rewritten by its rank)
             uid = _lib.comm_unique_id()
-            _write_private(prefix + ".uid", uid)
             import atexit
 
             atexit.register(_cleanup_job_files, prefix)
+            while len(acked) < ws - 1:
+                serve_acks()
+                if len(acked) == ws - 1:
+                    break
+                if _fresh_abort(prefix):
+                    raise RuntimeError("another rank gave the native group up")
+                if time.monotonic() > deadline:
+                    raise RuntimeError("no hello from rank(s) %s within %.0f s"
+                                       % (sorted(set(range(1, ws)) - acked), timeout))
+                time.sleep(0.01)
         else:
+            nonce = os.urandom(16).hex().encode()
+            hello = "%s.hello.%d" % (prefix, rank)
+            _write_private(hello, nonce)
             while uid is None:
-                buf = _read_owned(prefix + ".uid")
-                if buf is not None and len(buf) == _lib.COMM_ID_BYTES:
-                    uid = buf
-                elif _read_owned(prefix + ".abort") is not None:
+                buf = _read_owned("%s.ack.%d" % (prefix, rank))
+                if buf is not None and buf[:32] == nonce and len(buf) == 32 + _lib.COMM_ID_BYTES:
+                    uid = buf[32:]
+                elif _fresh_abort(prefix):
                     raise RuntimeError("another rank gave the native group up")
                 elif time.monotonic() > deadline:
-                    raise RuntimeError(f"no ncclUniqueId file {prefix}.uid from rank 0 within {timeout:.0f} s")
+                    raise RuntimeError(f"no ncclUniqueId from rank 0 ({prefix}.ack.{rank}) within {timeout:.0f} s")
                 else:
+                    if _read_owned(hello) != nonce:
+                        _write_private(hello, nonce)
                     time.sleep(0.01)
     except Exception as exc:  # reported to the others below, then raised
         err = exc
-    _write_private("%s.st.%d" % (prefix, rank), b"ok" if err is None else ("fail: %r" % (err,)).encode())
-    # phase 2: the verdict of every rank
+    mine = b"ok:" + _uid_digest(uid) if err is None else ("fail: %r" % (err,)).encode()
+    _write_private("%s.st.%d" % (prefix, rank), mine)
+    # the verdict of every rank
     bad = None if err is None else "rank %d: %r" % (rank, err)
     pending = set(range(ws))
     while pending and bad is None:
@@ -195,11 +256,15 @@ def _exchange_unique_id_files(rank, ws, timeout):
             buf = _read_owned("%s.st.%d" % (prefix, r))
             if buf is None:
                 continue
-            pending.discard(r)
-            if buf != b"ok":
+            if buf.startswith(b"ok:"):
+                if buf == mine:
+                    pending.discard(r)
+                # (another digest: a leftover of an earlier attempt -- wait for this attempt's status)
+            elif buf.startswith(b"fail:") and os.stat("%s.st.%d" % (prefix, r)).st_mtime >= _T_START - 1.0:
+                pending.discard(r)
                 bad = "rank %d: %s" % (r, buf.decode(errors="replace"))
         if pending and bad is None:
-            if _read_owned(prefix + ".abort") is not None:
+            if _fresh_abort(prefix):
                 bad = "another rank gave the native group up"
             elif time.monotonic() > deadline + 5.0:
                 bad = "no status from rank(s) %s within %.0f s" % (sorted(pending), timeout)
@@ -271,6 +336,8 @@ def init_process_group(backend=None, device=None):
         return rank, local_rank, ws
     from . import _lib
 
+    _state["attempt"] += 1  # (every rank of a job forms its groups in the same order: the counters agree)
+
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     name = backend or os.environ.get("BGP_DIST_BACKEND")
@@ -317,7 +384,9 @@ def destroy_process_group():
         dist = _torch_dist()
         if dist.is_initialized():
             dist.destroy_process_group()
-    _state.update(backend=None, comm=None, rank=0, world=1, device=None)
+    if _state["job_prefix"] and _state["rank"] == 0:
+        _cleanup_job_files(_state["job_prefix"])  # (not left to atexit, which a SIGTERM skips)
+    _state.update(backend=None, comm=None, rank=0, world=1, device=None, job_prefix=None)
 
 
 def group_info(device=None):
@@ -394,18 +463,33 @@ def _assemble(parts, B, ws):
     return full
 
 
-def allgather_lml(ctx, B, local=None):
+def _raise_if_any_rank_failed(errs):
+    bad = [(r, int(e)) for r, e in enumerate(errs) if int(e) != 0]
+    if bad:
+        raise ShardedEvaluationError("rank(s) %s failed in their share of a sharded log-probability block (codes %s); every "
+                                     "rank stops" % ([r for r, _e in bad], [e for _r, e in bad]))
+
+
+def allgather_lml(ctx, B, local=None, error=0):
     """The B log-likelihoods of a sharded proposal block on every rank.  Native group: ``ctx`` holds this rank's
     submitted rows (``Context.lml_submit``) and the values travel device to device (bgp_lml_batch_wait_allgather);
-    gloo (CPU tests, ranks sharing a GPU): ``local`` = this rank's values, already collected on the host."""
+    gloo (CPU tests, ranks sharing a GPU): ``local`` = this rank's values, already collected on the host.
+    ``error`` != 0: this rank's own share failed.  It STILL takes part -- a rank that stayed away would leave its peers in
+    the collective for ever -- and sends the code in a status word next to its values; every rank then raises
+    ``ShardedEvaluationError`` from the same gathered words."""
     ws = _state["world"]
     per = -(-B // ws)
     if _state["backend"] == "rccl" and local is None:
-        return _assemble(ctx.lml_wait_allgather(_state["comm"], per), B, ws)
-    buf = np.zeros(per)
-    if local is not None and len(local):
-        buf[: len(local)] = local
-    return _assemble(_allgather(buf), B, ws)
+        vals, errs = ctx.lml_wait_allgather(_state["comm"], per, local_error=int(error))
+    else:
+        buf = np.full(per + 1, np.nan)
+        if local is not None and len(local) and not error:
+            buf[: len(local)] = local
+        buf[per] = float(error)
+        g = _allgather(buf)
+        vals, errs = g[:, :per], g[:, per]
+    _raise_if_any_rank_failed(errs)
+    return _assemble(vals, B, ws)
 
 
 def shard_log_prob(fn):
@@ -422,8 +506,20 @@ def shard_log_prob(fn):
         ws, rank = _state["world"], _state["rank"]
         B = Theta.shape[0]
         lo, hi = shard_rows(B, rank, ws)
-        local = fn(Theta[lo:hi], *args, **kwargs) if hi > lo else np.zeros(0)
-        return allgather_lml(None, B, local=np.asarray(local, dtype=np.float64))
+        local, failure = np.zeros(0), None
+        try:
+            if hi > lo:
+                local = np.asarray(fn(Theta[lo:hi], *args, **kwargs), dtype=np.float64)
+                if local.shape != (hi - lo,):
+                    raise ValueError("log-probability returned shape %r for %d rows" % (local.shape, hi - lo))
+        except Exception as exc:  # the peers are (about to be) in the collective: take part, say so, then raise
+            failure = exc
+        try:
+            return allgather_lml(None, B, local=local, error=0 if failure is None else 1)
+        except ShardedEvaluationError as err:
+            if failure is not None:
+                raise err from failure
+            raise
 
     return wrapped
 

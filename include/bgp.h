@@ -39,6 +39,7 @@ extern "C" {
 #define BGP_ERR_NODEVICE 3 /* no usable gfx950 device            */
 #define BGP_ERR_STATE 4    /* call order (e.g. predict before posterior) */
 #define BGP_ERR_NOTPD 5    /* bgp_sample_y: covariance (+jitter) not positive definite */
+#define BGP_ERR_COMM 6     /* a collective did not complete (peer lost, asynchronous RCCL error): communicator aborted */
 
 enum { BGP_FORM_PRODUCT = 0, BGP_FORM_SUM = 1 };
 enum { BGP_RBF = 0, BGP_MATERN12 = 1, BGP_MATERN32 = 2, BGP_MATERN52 = 3 };
@@ -216,8 +217,11 @@ int bgp_sample_y_batch(bgp_ctx* ctx, int B, const int* pidx, const double* h_ker
  * n = 2048 x 128 matrices on MI355X, results bit-identical), one group below that (every group's dependent
  * chain is as long as the whole batch's, nothing to gain).  This call, or the environment variable
  * BGP_STREAMS read at context creation, forces a fixed group count.  Other environment switches read at
- * context creation: BGP_PANELS (block columns per trailing update; default 4 from n = 1536, else 2), and the experimental
- * BGP_TWO_PANEL=0, BGP_SYRK2=1, BGP_LEFT_LOOKING=1, BGP_KBUILD1=1, BGP_SMALL_SPLIT=1, BGP_FUSED_GRAM=1. */
+ * context creation: BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
+ * (see bgp_set_persist) and the A/B switches BGP_KBUILD1=1 (unpipelined Gram build), BGP_SMALL_SPLIT=1 (n <= 128 through
+ * the two-launch path), BGP_FUSED_GRAM=1 (Gram tiles generated inside the first trailing update); process-wide:
+ * BGP_PANEL_WIDTH, BGP_ROWQUAD_T, BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_NCRIT, BGP_PS_TRACE
+ * (DESIGN.md sections 6 and 10).  A BGP_* variable the library does not read is reported once on stderr. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */
@@ -238,6 +242,12 @@ int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
  * 128, matrices x block columns <= 400).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
  * sklearn/_gpr.py:587. */
 int bgp_set_persist(bgp_ctx* ctx, int mode);
+/* Bookkeeping of that path: out[0] = launch-free calls enqueued by this context, out[1] = of which timed out (a wait
+ * outlasted BGP_PS_TIMEOUT_MS, 500 ms: the workgroups were not co-resident; the batch was redone by launches, same
+ * results), out[2] = 1 while a time-out keeps the path switched off, out[3] = eligible calls left before it is tried again
+ * (BGP_PS_COOLDOWN, 256; after the third time-out the path stays off until bgp_set_persist(ctx, 1)).  A context that shares
+ * its device with other contexts, processes or collectives should call bgp_set_persist(ctx, 0). */
+int bgp_persist_stats(bgp_ctx* ctx, long long* out4);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
 int bgp_set_timing(bgp_ctx* ctx, int enable);
 /* Debugging aid (BGP_PS_TRACE=1): in-kernel wall-clock stamps (100 MHz) of the last launch-free call.  dims = {matrices,
@@ -247,6 +257,12 @@ int bgp_debug_ps_trace(bgp_ctx* ctx, int* dims, unsigned long long* out, size_t 
 /* Debugging aid: working matrix (npad x npad doubles; L in the lower triangle after an LML call) and working right-hand
  * side (npad doubles, z = L^-1 y) of batch slot b as the last bgp_lml_batch left them; either pointer may be NULL. */
 int bgp_debug_workspace(bgp_ctx* ctx, int b, double* L, double* z);
+/* Debugging aid: the Cholesky factor of the predictive covariance as the last bgp_sample_y left it (*mpad = its padded
+ * edge, a multiple of 128, 0 when there is none; L: mpad x mpad doubles, lower triangle; may be NULL to query mpad). */
+int bgp_debug_cov_factor(bgp_ctx* ctx, int* mpad, double* L);
+/* Debugging aid / accuracy test: sqrt(x[i]) and 1 / sqrt(x[i]) as the diagonal-block factorisation forms its pivots
+ * (hardware seed + coupled Goldschmidt step + one residual correction each; LAPACK dpotrf's sqrt via sklearn/_gpr.py:587). */
+int bgp_debug_pivot_root(int device, int n, const double* x, double* sqrt_out, double* rsqrt_out);
 /* fp64 MFMA micro-benchmark: TFLOP/s of back-to-back v_mfma_f64_16x16x4_f64 on the whole chip. */
 int bgp_bench_mfma_f64(int device, int iters, double* tflops);
 /* HBM copy micro-benchmark: GB/s (read+write) of a streaming double2 copy of `bytes` bytes. */
@@ -278,10 +294,19 @@ int bgp_comm_barrier(bgp_comm* comm);
 /* ranks RCCL counts in the communicator (ncclCommCount) */
 int bgp_comm_nranks(bgp_comm* comm, int* nranks);
 /* Exact single-ensemble sharding of bask/bayesgpr.py:490-530 (ONE n_walkers ensemble, one RNG): every rank has
- * submitted its own rows of a half-step's proposal block with bgp_lml_batch_submit; this replaces bgp_lml_batch_wait
- * and returns the log-likelihoods of ALL ranks (world * per_rank doubles, rank-major, gathered device to device out of
- * every context's resident result vector -- no host staging on the send side). */
-int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, double* lml_all);
+ * submitted its own rows of a half-step's proposal block with bgp_lml_batch_submit (possibly none); this replaces
+ * bgp_lml_batch_wait and returns the log-likelihoods of ALL ranks (world * per_rank doubles, rank-major, gathered device to
+ * device out of every context's resident result vector: the communicator's stream waits for the context's stream through
+ * an event, ONE host synchronisation per half-step).
+ * Every rank must ENTER this call once it has been agreed on (RCCL has no time-out): a rank whose own work failed between
+ * submit and wait passes local_error > 0 instead of returning early; its values travel as NaN and errors_out[r] (world
+ * ints, identical on every rank) carries the code, so that all ranks raise alike.  A rank whose launch-free factorisation
+ * timed out redoes its batch by launches and all ranks repeat the gather (decided from the same gathered status word).
+ * The pending batch is consumed whatever the outcome.  Returns BGP_OK when the collective completed (inspect errors_out),
+ * BGP_ERR_COMM when it did not within BGP_COMM_TIMEOUT_S seconds (default 300) or RCCL reported an asynchronous error:
+ * the communicator is aborted (ncclCommAbort) and every later collective on it answers BGP_ERR_COMM. */
+int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, int local_error, double* lml_all,
+                                 int* errors_out);
 
 #ifdef __cplusplus
 }

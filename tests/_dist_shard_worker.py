@@ -1,6 +1,7 @@
 """Worker for the exact single-ensemble sharding test (SURVEY.md 8(e) option 1): every rank drives the
 same sampler RNG, evaluates only its rows of each proposal block and all-gathers the log-probabilities.
-argv: out_dir mode   (mode "toy": CPU toy target; mode "gpu": the device LML, ranks share GPU 0)."""
+argv: out_dir mode [W]  (mode "toy": CPU toy target with W walkers (default 14); "fail": the same, rank 3's share raises in
+its 6th call -- every rank must stop with ShardedEvaluationError; mode "gpu": the device LML, ranks share GPU 0)."""
 import json
 import os
 import sys
@@ -18,19 +19,29 @@ def main():
     out_dir, mode = sys.argv[1], sys.argv[2]
     rank, local_rank, ws = distributed.init_process_group(backend="gloo")
     calls = []
-    if mode == "toy":
-        p, W, steps = 3, 14, 25   # W/2 = 7 rows per half-step: uneven split 3/4 over two ranks
+    if mode in ("toy", "fail"):
+        import time
+
+        p, W, steps = 3, (int(sys.argv[3]) if len(sys.argv) > 3 else 14), 25   # default W/2 = 7 rows per half-step: 3/4 over two ranks
         mu = np.array([1.0, -2.0, 0.5])
 
         def log_prob(Xb):
             calls.append(len(Xb))
+            if mode == "fail" and rank == 3 and len(calls) == 6:
+                json.dump({"t": time.time()}, open(os.path.join(out_dir, "raised.json"), "w"))
+                raise FloatingPointError("rank 3's share of the block blew up")
             lp = -0.5 * ((Xb - mu) ** 2).sum(axis=1)
             lp[Xb[:, 0] > 1.5] = -np.inf  # hard wall: -inf must survive the gather
             return lp
 
         sampler = bask.sampler.EnsembleSampler(W, p, distributed.shard_log_prob(log_prob))
         sampler.random_state = np.random.RandomState(5).get_state()
-        sampler.run_mcmc(mu + 1e-2 * np.random.RandomState(4).randn(W, p), steps)
+        try:
+            sampler.run_mcmc(mu + 1e-2 * np.random.RandomState(4).randn(W, p), steps)
+        except distributed.ShardedEvaluationError as exc:
+            json.dump({"t": time.time(), "msg": str(exc), "cause": repr(exc.__cause__), "calls": len(calls)},
+                      open(os.path.join(out_dir, f"stopped{rank}.json"), "w"))
+            raise
         chain = sampler.get_chain(flat=True)
         lp = sampler.get_log_prob(flat=True)
     else:

@@ -364,6 +364,114 @@ def gen_sizes_posterior(out):
     np.savez_compressed(os.path.join(out, "posterior_sizes.npz"), **rec)
 
 
+
+def zero_offdiag_blocks(K, nb=128):
+    """K with every off-diagonal nb x nb block zeroed: what a blocked factorisation whose panel solves and trailing updates
+    do nothing at all would see."""
+    Z = np.zeros_like(K)
+    for i in range(0, K.shape[0], nb):
+        Z[i:i + nb, i:i + nb] = K[i:i + nb, i:i + nb]
+    return Z
+
+
+def lml_of(K, y):
+    L = cholesky(K, lower=True)
+    a = cho_solve((L, True), y)
+    return -0.5 * y.dot(a) - np.log(np.diag(L)).sum() - 0.5 * len(y) * np.log(2.0 * np.pi)
+
+
+def gen_dense(out):
+    """DENSE, ill-conditioned matrices at the sizes where the blocked paths switch on (P = 4 panel groups from 12 block
+    columns, the 16-32-block-column index ranges of the trailing update / panel solve / launch-free tile tasks): n = 2048
+    (d = 2) and n = 4096 (d = 3), length scales 0.3 .. 1.0, noise 1e-4 .. 1e-2 -> cond(K) 1e4 .. 1e7, median off-diagonal
+    entry O(0.1) of the diagonal.  (The B / C / D cases above use the 8(d) inputs with l ~ 0.3 in d = 8 / 16 / 32: cond(K)
+    = 130 / 5.7 / 1.06 -- nearly diagonal; a factorisation with a broken trailing update passes them at 1e-6.)
+    Every case ASSERTS its own sensitivity: the log-likelihood with all off-diagonal 128-blocks of K zeroed must differ by
+    more than 1e-2 relative, so a nearly diagonal case cannot be committed here again.
+    Stored: seeds + scalars only (X, y, Xq regenerated by synth() / RandomState): log-likelihoods of three hyper-parameter
+    vectors (sklearn/_gpr.py:579-613 reached from bask/bayesgpr.py:374), alpha head, posterior mean / std / noise-free std at
+    64 query points for the middle one (skopt predict formula with the explicit inverse, bask/bayesgpr.py:200-217,622-635),
+    and a batch with mixed outcomes: a coinciding pair of points whose second member lies beyond block column 12 and carries
+    a NEGATIVE per-point diagonal term (Optimizer.tell always passes a vector alpha): with enough noise the matrix
+    factorises, otherwise LAPACK's dpotrf fails exactly at that pivot (-inf, sklearn/_gpr.py:586-589)."""
+    rec = {}
+    for tag, n, d, bad in (("N2", 2048, 2, 1700), ("N4", 4096, 3, 3000)):
+        X, y = synth(n, d, seed=7)
+        ells = (0.3, 0.6, 1.0)
+        sig2 = (1e-2, 1e-3, 1e-4)
+        TH = np.array([np.concatenate([[np.log(1.0 + 0.2 * i)], np.log(ells[i] * (1.0 + 0.1 * np.arange(d))), [np.log(sig2[i])]])
+                       for i in range(3)])
+        g = sk_gpr(make_kernel("matern52", "product", d), X, y, 1e-10)
+        lmls, conds, meds, sens = [], [], [], []
+        for th in TH:
+            K = g.kernel_.clone_with_theta(th)(X)
+            K[np.diag_indices_from(K)] += 1e-10
+            lml = g.log_marginal_likelihood(th)
+            assert abs(lml_of(K, y) - lml) <= 1e-9 * abs(lml)
+            ev = np.linalg.eigvalsh(K)
+            off = np.abs(K[np.triu_indices(n, 1)])
+            lz = lml_of(zero_offdiag_blocks(K), y)
+            lmls.append(lml)
+            conds.append(ev[-1] / ev[0])
+            meds.append(np.median(off) / K[0, 0])
+            sens.append(abs(lz - lml) / abs(lml))
+            print(tag, "theta", np.round(th, 3), "lml %.6f cond %.2e median offdiag/diag %.3f sensitivity %.3f"
+                  % (lml, conds[-1], meds[-1], sens[-1]))
+            assert sens[-1] > 1e-2, "nearly diagonal case: the blocked machinery would not be tested"
+            assert meds[-1] > 0.02
+        rec[tag + "_nd_seed"] = np.array([n, d, 7])
+        rec[tag + "_theta"] = TH
+        rec[tag + "_lml"] = np.array(lmls)
+        rec[tag + "_cond"] = np.array(conds)
+        rec[tag + "_sensitivity"] = np.array(sens)
+        # posterior at the middle vector
+        th = TH[1]
+        m = 64
+        Xq = np.random.RandomState(500 + n).uniform(size=(m, d))
+        gp = sk_gpr(make_kernel("matern52", "product", d).clone_with_theta(th), X, y, 1e-10)
+        L_inv = solve_triangular(gp.L_.T, np.eye(n))
+        K_inv = L_inv.dot(L_inv.T)
+        mean, std = skopt_predict(gp, K_inv, Xq)
+        m2, s2 = gp.predict(Xq, return_std=True)
+        assert np.allclose(mean, m2, rtol=1e-7, atol=1e-9)
+        gp.kernel_.set_params(k2=sk.WhiteKernel(noise_level=0.0))
+        mean0, std0 = skopt_predict(gp, K_inv, Xq)
+        rec[tag + "_m_qseed"] = np.array([m, 500 + n])
+        rec[tag + "_alpha_head"] = gp.alpha_[:16]
+        rec[tag + "_alpha_tail"] = gp.alpha_[-16:]
+        rec[tag + "_mean"], rec[tag + "_std"], rec[tag + "_std0"] = mean, std, std0
+        # how well the reference's own arithmetic knows these numbers: explicit-inverse formula vs sklearn's solve
+        rec[tag + "_var_selfdiff"] = np.array(np.abs(std ** 2 - s2 ** 2).max())
+        print(tag, "mean[:3]", mean[:3], "std[:3]", std[:3], "std0[:3]", std0[:3], "var self-diff %.2e" % rec[tag + "_var_selfdiff"])
+        # a batch with MIXED outcomes: point `bad` (block column bad // 128 >= 12) is a copy of point 5 and carries a negative
+        # diagonal term -3e-3.  Its pivot lies in [s2 - 3e-3, 2 s2 - 3e-3 + 1e-10] (s2 = the vector's noise): the vector
+        # with s2 = 1e-2 factorises, the two others fail exactly there (LinAlgError -> -inf, sklearn/_gpr.py:586-589)
+        X2 = X.copy()
+        X2[bad] = X2[5]
+        avec = np.full(n, 1e-10)
+        avec[bad] = -3e-3
+        gb = sk_gpr(make_kernel("matern52", "product", d), X[:8], y[:8], 1e-10)  # (a fit with this alpha could raise)
+        gb.X_train_, gb.y_train_, gb.alpha = X2, y, avec
+        with np.errstate(all="ignore"):
+            vals = np.array([gb.log_marginal_likelihood(t) for t in TH])
+        assert np.isfinite(vals[0]) and vals[1] == -np.inf and vals[2] == -np.inf, vals
+        infos = [0]
+        for t in TH[1:]:
+            K = g.kernel_.clone_with_theta(t)(X2)
+            K[np.diag_indices_from(K)] += avec
+            try:
+                cholesky(K, lower=True)
+                raise AssertionError("expected LinAlgError")
+            except np.linalg.LinAlgError as e:
+                infos.append(int(str(e).split("-th")[0]))
+        assert infos[1] == bad + 1 and infos[2] == bad + 1 and bad // 128 >= 12, (infos, bad)
+        rec[tag + "_bad_index_value"] = np.array([bad, -3e-3])
+        rec[tag + "_bad_lml"] = vals
+        rec[tag + "_bad_info"] = np.array(infos)
+        print(tag, "mixed case:", vals, "dpotrf info", infos, "(block column %d)" % (bad // 128))
+    np.savez_compressed(os.path.join(out, "dense_sizes.npz"), **rec)
+
+
 def gen_sample_y(out):
     """a8: the call the reference makes for function draws -- sklearn's GaussianProcessRegressor.sample_y
     (sklearn/_gpr.py:522-526: numpy's legacy multivariate_normal, i.e. an SVD of the predictive covariance), reached from
@@ -396,4 +504,5 @@ if __name__ == "__main__":
     gen_reference_tier1(HERE)
     gen_sizes_posterior(HERE)
     gen_sample_y(HERE)
+    gen_dense(HERE)
     print("done")

@@ -235,3 +235,129 @@ def test_bench_self_spawn_reports_a_failing_rank():
         assert json.loads(res.stdout.splitlines()[-1])["n_gpus"] == 2
     else:
         assert "needs an MI355X" in res.stderr and not res.stdout.strip()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# world size 8 -- the target configuration -- over gloo, and the collective's error path
+# ---------------------------------------------------------------------------------------------------------
+def _spawn_ranks(ws, worker, args, tmp_path, timeout=300):
+    """ws plain processes with a launcher's environment (no torchrun agent: every rank's exit code is its own)."""
+    port = _free_port()
+    procs = []
+    for r in range(ws):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(ws), LOCAL_WORLD_SIZE=str(ws), OMP_NUM_THREADS="1", BGP_DIST_BACKEND="gloo",
+                   BGP_COMM_DIR=str(tmp_path / "rdv"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)] + list(args), env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    return outs
+
+
+def _toy_reference(W, steps=25):
+    import bayes_skopt_amd as bask
+
+    mu = np.array([1.0, -2.0, 0.5])
+
+    def log_prob(Xb):
+        lp = -0.5 * ((Xb - mu) ** 2).sum(axis=1)
+        lp[Xb[:, 0] > 1.5] = -np.inf
+        return lp
+
+    sampler = bask.sampler.EnsembleSampler(W, 3, log_prob)
+    sampler.random_state = np.random.RandomState(5).get_state()
+    sampler.run_mcmc(mu + 1e-2 * np.random.RandomState(4).randn(W, 3), steps)
+    return sampler.get_chain(flat=True)
+
+
+@pytest.mark.parametrize("W", [256, 100])
+def test_eight_rank_exact_ensemble_sharding_equals_single_process(tmp_path, W):
+    """ws = 8, the north star's configuration: W = 256 walkers -> 128 proposals per half-step -> 16 rows per rank (config C's
+    shard); W = 100 -> 50 rows -> an UNEVEN split (6 / 7 rows, padded to per = 7 in the exchange).  Every rank's chain is
+    the single-process chain, bit for bit."""
+    outs = _spawn_ranks(8, "_dist_shard_worker.py", [str(tmp_path), "toy", str(W)], tmp_path)
+    for rc, _o, e in outs:
+        assert rc == 0, e[-2000:]
+    ref = _toy_reference(W)
+    import bayes_skopt_amd as bask
+
+    for k in range(8):
+        np.testing.assert_array_equal(np.load(tmp_path / f"chain{k}.npy"), ref)
+        r = json.load(open(tmp_path / f"shard{k}.json"))
+        lo, hi = bask.distributed.shard_rows(W // 2, k, 8)
+        assert r["ws"] == 8 and set(r["calls"][1:]) == {hi - lo} and len(r["calls"]) == 1 + 2 * 25
+    if W == 256:
+        assert all(json.load(open(tmp_path / f"shard{k}.json"))["calls"][1] == 16 for k in range(8))
+    else:
+        assert sorted(json.load(open(tmp_path / f"shard{k}.json"))["calls"][1] for k in range(8)) == [6] * 6 + [7] * 2
+
+
+def test_a_rank_that_fails_inside_the_sharded_evaluation_stops_every_rank(tmp_path):
+    """Rank 3 of 8 raises inside its share of a half-step.  It must still take part in the all-gather (its peers would
+    block for ever otherwise -- RCCL has no time-out) and report through the status word: every rank raises
+    ShardedEvaluationError naming rank 3 and exits non-zero, within seconds of the failure; rank 3's error carries the
+    original exception as its cause."""
+    import time
+
+    outs = _spawn_ranks(8, "_dist_shard_worker.py", [str(tmp_path), "fail", "64"], tmp_path, timeout=240)
+    t_raised = json.load(open(tmp_path / "raised.json"))["t"]
+    for k, (rc, _o, e) in enumerate(outs):
+        assert rc != 0, k
+        assert "ShardedEvaluationError" in e, e[-1500:]
+        st = json.load(open(tmp_path / f"stopped{k}.json"))
+        assert "[3]" in st["msg"]
+        assert st["t"] - t_raised < 30.0
+        assert st["calls"] == 6  # nobody went on to another half-step
+        assert ("FloatingPointError" in st["cause"]) == (k == 3)
+    assert time.time() - t_raised < 120.0
+
+
+def test_bench_rendezvous_at_world_size_eight():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--rendezvous-only"], env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == [float(r) for r in range(8)] and len(d["rank_devices"]) == 8
+
+
+def test_rendezvous_ignores_a_consistent_set_of_stale_files(tmp_path):
+    """A killed earlier attempt under the SAME job name (a reused BGP_COMM_JOB) has left a complete, self-consistent set of
+    rendezvous files behind -- id, acks, "ok" statuses of every rank.  A rank of the new attempt that starts before rank 0
+    must not pick any of it up: an ack only counts with the nonce this rank has just drawn, a status only with the digest
+    of the id this attempt's rank 0 created."""
+    code = (
+        "import os, sys, time; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib, distributed;"
+        "_lib.comm_unique_id = lambda: bytes([7]) * 128;"
+        "distributed._state['attempt'] = 1;"
+        "r = int(os.environ['RANK']); time.sleep(float(os.environ['DELAY']));"
+        "uid = distributed._exchange_unique_id(r, 3, timeout=60.0);"
+        "open(os.path.join(%r, 'got%%d.bin' %% r), 'wb').write(uid); time.sleep(2.0 if r == 0 else 0.0)"
+    ) % (ROOT, str(tmp_path))
+    port = _free_port()
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="3", BGP_COMM_JOB="nightly",
+                BGP_COMM_DIR=str(tmp_path / "rdv"))
+    # the leftovers, written with the library's own naming (same job name, same attempt number)
+    pre = ("import os, sys; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import distributed;"
+           "distributed._state['attempt'] = 1; p = distributed._job_prefix(3); old = bytes([9]) * 128;"
+           "dg = distributed._uid_digest(old);"
+           "[distributed._write_private(p + '.ack.%%d' %% r, b'0' * 32 + old) for r in (1, 2)];"
+           "[distributed._write_private(p + '.hello.%%d' %% r, b'0' * 32) for r in (1, 2)];"
+           "[distributed._write_private(p + '.st.%%d' %% r, b'ok:' + dg) for r in (0, 1, 2)];"
+           "distributed._write_private(p + '.uid', old)") % ROOT
+    assert subprocess.run([sys.executable, "-c", pre], env=base, timeout=120).returncode == 0
+    old = time_old = None
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(base, RANK=str(r), DELAY=("3.0" if r == 0 else "0.0")))
+             for r in (1, 2, 0)]  # ranks 1 and 2 are up (and polling) three seconds before rank 0 cleans up
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    for r in range(3):
+        assert open(tmp_path / f"got{r}.bin", "rb").read() == bytes([7]) * 128

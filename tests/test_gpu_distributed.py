@@ -124,9 +124,9 @@ gs2 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_stat
                     shard_ensemble=True)
 from bayes_skopt_amd import _lib
 real = _lib.Context.lml_wait_allgather
-def counted(self, comm, per_rank):
+def counted(self, comm, per_rank, local_error=0):
     calls.append(per_rank)
-    return real(self, comm, per_rank)
+    return real(self, comm, per_rank, local_error)
 _lib.Context.lml_wait_allgather = counted
 gs2.fit(X, y, **kw)
 distributed.destroy_process_group()
@@ -146,3 +146,79 @@ def test_device_resident_lml_gather_through_rccl():
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["same"] and d["torch"] is False
     assert d["calls"] == 1 + 2 * 7 and d["per_rank"] == [10, 20]  # initial ensemble (20 rows) + 2 half-steps x 7 steps
+
+
+_ERRPATH_WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import bayes_skopt_amd as bask
+from bayes_skopt_amd import _lib, distributed
+rank, local_rank, ws = distributed.init_process_group()
+comm = distributed._state["comm"]
+rng = np.random.RandomState(0)
+n, d = 1100, 4
+X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+ctx = _lib.Context(X, y, 1e-10, max_batch=16)
+H = np.concatenate([[0.0], np.full(d, np.log(0.4)), [np.log(0.02)]]) + 0.1 * rng.randn(12, d + 2)
+ctx.set_persist(0)
+ref = ctx.lml(H)
+out = {}
+# 1. sound batch, launch schedule and launch-free: values == the synchronous call, status words 0
+for mode in (0, 1):
+    ctx.set_persist(mode)
+    assert ctx.lml_submit(H)
+    vals, errs = ctx.lml_wait_allgather(comm, 16)
+    out["sound%%d" %% mode] = [bool(np.array_equal(vals[0, :12], ref)), errs.tolist(), bool(np.all(np.isnan(vals[0, 12:])))]
+# 2. this rank reports a failure of its own: it still takes part, the values are NaN, the word carries the code, and the
+#    pending batch is consumed (the context is usable at once)
+assert ctx.lml_submit(H)
+vals, errs = ctx.lml_wait_allgather(comm, 16, local_error=7)
+out["err"] = [errs.tolist(), bool(np.all(np.isnan(vals)))]
+out["after_err"] = bool(np.array_equal(ctx.lml(H), ref))
+# 3. nothing submitted (a rank without rows): padding only
+vals, errs = ctx.lml_wait_allgather(comm, 16)
+out["empty"] = [errs.tolist(), bool(np.all(np.isnan(vals)))]
+# 4. per_rank too small for the pending batch: reported THROUGH the collective, not by returning before it
+assert ctx.lml_submit(H)
+vals, errs = ctx.lml_wait_allgather(comm, 8)
+out["small"] = errs.tolist()
+out["after_small"] = bool(np.array_equal(ctx.lml(H), ref))
+# 5. the sharded log-probability: a failure in the priors reaches every rank as ShardedEvaluationError (cause attached)
+gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=3, device=0, normalize_y=True,
+                   shard_ensemble=True)
+def bad_prior(x):
+    raise FloatingPointError("prior blew up")
+try:
+    gp.fit(X[:200], y[:200], n_desired_samples=20, n_burnin=1, n_walkers_per_thread=10, progress=False,
+           priors=[bad_prior] * (d + 2))
+    out["fit"] = "no error"
+except distributed.ShardedEvaluationError as exc:
+    out["fit"] = [str(exc), repr(exc.__cause__)]
+ctx.close()
+distributed.destroy_process_group()
+print(json.dumps(out))
+"""
+
+
+def test_collective_error_path_through_rccl():
+    """bgp_lml_batch_wait_allgather never returns before the collective: a local failure travels as a status word next to
+    NaN values, the pending batch is consumed whatever happens, and a timed-out launch-free factorisation is redone by
+    launches with a second gather round (one-rank RCCL group: the box has one GPU)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), BGP_DIST_FORCE="1",
+               BGP_DIST_BACKEND="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    res = subprocess.run([sys.executable, "-c", _ERRPATH_WORKER % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["sound0"] == [True, [0], True] and d["sound1"] == [True, [0], True]
+    assert d["err"] == [[7], True] and d["after_err"]
+    assert d["empty"] == [[0], True]
+    assert d["small"] == [1] and d["after_small"]  # BGP_ERR_INVALID
+    assert "[0]" in d["fit"][0] and "FloatingPointError" in d["fit"][1]
+    # the same with every launch-free wait timing out: the rank's word says "redo", it redoes its batch by launches and the
+    # gather goes round again -- same values, one warning
+    res = subprocess.run([sys.executable, "-c", _ERRPATH_WORKER % ROOT], env=dict(env, BGP_PS_TIMEOUT_TICKS="200"),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["sound1"] == [True, [0], True] and res.stderr.count("timed out") >= 1
