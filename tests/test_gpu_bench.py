@@ -59,8 +59,14 @@ def test_bench_single_gpu_line():
     assert set(sh) == {"128", "64", "32", "16"} and sh["16"] < sh["32"] < sh["64"] < sh["128"]
     assert set(d["shard_projection"]["evals_per_s"]) == {"1", "2", "4", "8"}
     lf = d["launch_free"]
-    assert set(lf) == {"n4096_B1", "n2048_B16", "n1024_B32"} and all(v["bit_identical"] for v in lf.values())
-    assert all(0 < v["launch_free_ms"] < 3 * v["launches_ms"] for v in lf.values())
+    shapes = {k: v for k, v in lf.items() if k.startswith("n")}
+    assert set(shapes) == {"n4096_B1", "n2048_B16", "n1024_B32"} and all(v["bit_identical"] for v in shapes.values())
+    assert all(0 < v["launch_free_ms"] < 3 * v["launches_ms"] for v in shapes.values())
+    assert lf["timeouts"] == 0 and all(v["calls"] >= 18 and 0 < v["launch_free_frac"] < 1 for v in shapes.values())
+    assert "fresh child process" in lf["measured_in"]
+    e2e = d["end_to_end"]  # the whole hot path against the same peak: below the trailing update's own fraction
+    assert 0.2 < e2e["frac"] < r["frac"] and abs(e2e["tflops"] - e2e["flops_per_eval"] * d["value"] / 1e12) < 1e-9
+    assert d["launch_free_calls_in_timed_path"]["timeouts"] == 0
     cb = d["config_B"]
     assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9
     ce = d["config_E"]
@@ -84,6 +90,7 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
     assert d["dist_backend"] == "gloo" and d["rank_devices"] == [0, 0] and d["rccl_nranks"] is None
     assert d["weak_chains_evals_per_s"] > 0 and d["gathered_chain_rows"] == 2 * 256
+    assert 0 < d["collective_ms_per_half_step"] < 50.0
 
 
 @pytest.mark.parametrize("shard", ["chains", "ensemble"])
