@@ -271,13 +271,13 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   return bgp_launch_cholesky_slice(ctx, 0, B, ctx->stream, augmented);
 }
 
-int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
-  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr);
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, int first_np) {
+  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr, first_np);
 }
 
 // gen != nullptr (LML path only): the matrices hold block column 0 only (bgp_launch_kbuild_col0); the trailing updates
 // of the FIRST group of block columns -- the first launches to touch any other tile -- generate the Gram entries.
-int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen) {
+int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen, int first_np) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -300,9 +300,12 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     // with the LDS-DMA kernels, whose look-ahead column launches are cheap enough), 2 below (P = 2, 3, 4 are equal
     // within noise at n = 1024); BGP_PANELS fixes it.
     const int P = ctx->panels_auto ? (nblk >= 12 ? 4 : 2) : ctx->panels;
+    // first_np > 0: the FIRST panel group holds first_np block columns only (walker groups on different streams are staggered
+    // by half a panel group, so that one group's latency- / memory-bound column phase meets the other's bulk update;
+    // regrouping only: same operations per element in the same order, same bits)
     int k = 0;
     while (k < nblk) {
-      const int np = std::min(P, nblk - k);
+      const int np = std::min((k == 0 && first_np > 0) ? std::min(first_np, P) : P, nblk - k);
       for (int j = 0; j < np; j++) {
         bgp_tbegin(ctx, 1, st);
         hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus,

@@ -190,7 +190,7 @@ gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_
 def bad_prior(x):
     raise FloatingPointError("prior blew up")
 try:
-    gp.fit(X[:200], y[:200], n_desired_samples=20, n_burnin=1, n_walkers_per_thread=10, progress=False,
+    gp.fit(X[:200], y[:200], n_desired_samples=40, n_burnin=1, n_walkers_per_thread=20, progress=False,
            priors=[bad_prior] * (d + 2))
     out["fit"] = "no error"
 except distributed.ShardedEvaluationError as exc:
