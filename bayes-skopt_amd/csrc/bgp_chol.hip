@@ -193,7 +193,20 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
   a.total = bgp_ps_total_tasks(B, nblk);
-  const int tile_wgs = std::min(a.total, ncu - B);
+  {
+    // chain pairs (bgp_pf.h): two workgroups per matrix alternate over the block columns, the idle one preparing the next
+    // diagonal block UNDER the other's factorisation; needs 2 * Bpad CUs and at least as many (and 32) left for the tile role.
+    // BGP_PS_PAIR = 0 / 1 fixes it.
+    static int want = -2;
+    if (want == -2) {
+      const char* e = getenv("BGP_PS_PAIR");
+      want = e ? (atoi(e) != 0 ? 1 : 0) : 0;
+    }
+    a.Bpad = 8 * ((B + 7) / 8);
+    a.pair = (want == 1 && nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B)) ? 1 : 0;
+    a.nchain = a.pair ? 2 * a.Bpad : B;
+  }
+  const int tile_wgs = std::min(a.total, ncu - a.nchain);
   {
     // critical pool of the tile role: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
     // workgroups of their own, one per task of a column.  Measured: with up to ~10 block columns the chain waits less
@@ -205,6 +218,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       ncf = e ? atoi(e) : -1;
     }
     a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min(3 * B, tile_wgs / 2) : 0);
+    if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
   }
   a.spin_limit = limit;
   a.trace = nullptr;
@@ -230,7 +244,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       c->ps_trace_total = a.total;
     }
   }
-  bgp_launch_ps(c->stream, a, B + tile_wgs);
+  bgp_launch_ps(c->stream, a, a.nchain + tile_wgs);
   BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(hipGetLastError());
   return BGP_OK;

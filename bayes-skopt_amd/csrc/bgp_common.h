@@ -235,6 +235,8 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 //   diagrdy[b * nblk + I]         1 when the diagonal block (I, I) carries the panels 0 .. I-2 (the chain applies panel I-1)
 //   xready[(b * nblk + I) * nblk + J]   1 when the panel block X_IJ is final, I > J
 //   subrdy[b * nblk + I]          1 when block (I, I-1) carries the panels 0 .. I-2 (the chain solves it)
+//   wrow[b * nblk + J]            pair mode: number of 16-row blocks of W_JJ = L_JJ^-1 that are complete in memory (0 .. 7; the
+//                                 eighth goes out with wready[J])
 #define PS_TICKET 0
 #define PS_ERROR 1
 #define PS_HDR 32
@@ -250,10 +252,13 @@ struct PsArgs {
   size_t mstride;
   int total;          // tasks of the tile kernel (0: two block columns, the chain does everything)
   int ncrit;          // workgroups of the tile kernel's critical pool (0: one list)
+  int pair;           // 1: TWO chain workgroups per matrix that alternate over the block columns (bgp_pf.h, ps_chain_role)
+  int Bpad;           // pair mode: chain workgroup p of matrix b is block p * Bpad + b (Bpad = B rounded up to 8: same XCD)
+  int nchain;         // chain workgroups at the head of the grid (B, or 2 * Bpad)
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
 };
-static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (3 + nblk); }
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (4 + nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
 // DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
 //   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11

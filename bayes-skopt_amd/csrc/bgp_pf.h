@@ -278,8 +278,11 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
                                                double* __restrict__ yw, double* __restrict__ accb,
                                                double* __restrict__ lml, int* __restrict__ status, int n, int ld,
                                                size_t mstride, int ystride, int nblk, int k, const PfGen& gen,
-                                               bool inlds = false) {
+                                               bool inlds = false, unsigned* wrow = nullptr) {
   // inlds (chain kernel, k > 0): the block and its right-hand side are in LDS already (pf_chain_next left them there)
+  // wrow (chain pairs): the 16-row blocks of W go out to the partner workgroup AS THEY ARE FORMED -- row block p is complete
+  // in memory at the end of step p + 1; the otherwise idle wave 4 releases it and raises *wrow to the number of complete
+  // row blocks (1 .. 7; the eighth and z go out with the caller's wready flag) while the other waves run the next step
   const PfLds lds = pf_lds();
   double* const s = lds.s;
   double* const Minv = lds.Minv;
@@ -453,11 +456,16 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       }
       // last step: rows <= 5 of W are complete -> the terms K <= 5 of row 7 (one block per update wave)
       if (sb == 7) w7 = pf_wsum(w7, s, Minv, nullptr, 7, u6, u6, 6, lane);  // block J = u6 (W row 6 went 5 - u6)
+      if (wrow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's W blocks have left the wave
     }
     __syncthreads();
     PF_T(2 + sb * 3);
     failed = fail_lds;
     if (failed) break;  // uniform across the workgroup
+    if (wrow && w == 4 && lane == 0 && sb >= 1) {  // row blocks 0 .. sb-1 of W are complete
+      ps_release();
+      ps_st(wrow, (unsigned)sb);
+    }
   }
   if (failed) {
     if (tid == 0) {
@@ -732,18 +740,274 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   return 0;
 }
 
-// The chain role of the launch-free factorisation: workgroup b of ps_kernel walks the block columns of matrix b.
-static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b) {
+// ---- chain PAIRS (PsArgs::pair) ----------------------------------------------------------------------------------------
+// With ONE chain workgroup per matrix a block column costs 55 us: 25 us of pf_block and then, one after the other on the
+// same CU, the solve of block (J+1, J) and the last update of block (J+1, J+1) (pf_chain_next: 29 us, 17 of them MFMA issue).
+// Nothing in those two steps needs the WHOLE of W_JJ at once: column block sb of X = A W^T only reads row block sb of W, which
+// pf_block completes at the end of its step sb + 1, and the rank-16 term of the diagonal update with that column block of X
+// can follow at once.  So a SECOND workgroup -- the one that will factorise column J + 1 -- does both under the first one's
+// pf_block(J), row block by row block as pf_block publishes them (wrow), accumulates D_{J+1,J+1} in registers and drops it
+// into ITS OWN LDS tile: when pf_block(J) ends only the last row block's share is left (a few us), and the tile is where the
+// next factorisation needs it.  The two workgroups swap roles every column.  Per element the operations and their order are
+// those of pf_chain_next (accumulators start from the block as the tile workers left it, k ascending): the same bits.
+// Staging in the (free) tile region: W's lower row blocks PACKED -- row block q is 16 rows of 16 (q + 1) + 2 doubles (== 2 mod
+// 16: conflict-free B-operand reads) at PH_WOFF(q) -- and two 128 x 16 column blocks of X.
+#define PH_WLDQ(q) (16 * ((q) + 1) + 2)
+#define PH_WOFF(q) (128 * (q) * ((q) + 1) + 32 * (q))
+#define PH_XLD 18   // leading dimension of a staged 128 x 16 column block of X
+static_assert(PH_WOFF(8) + 2 * 128 * PH_XLD <= 128 * PF_LD, "the helper's staging buffers live in the (free) tile region");
+
+// `have` = row blocks of W_JJ known to be in memory (and acquired), `staged` = row blocks already in LDS.  Everything that is
+// out is staged in ONE burst (one L2 round trip for many row blocks: a helper that starts late finds most of W waiting).
+template <int SB, int NT>
+static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int J, int* ok_lds, int have, int staged,
+                                                    const double (&af)[32], double* __restrict__ Xg, int ld, d4 (&dt)[5],
+                                                    const int (&tio)[5], const int (&tjo)[5], double* __restrict__ Wl,
+                                                    double* __restrict__ Xl, int tid, int w, int lane, unsigned long long* tr) {
+  if constexpr (SB < 8) {
+    const int lr = lane & 15, lk = lane >> 4;
+    unsigned* const flags = a.flags;
+    if (SB == 7 && tr && tid == 0) tr[J * 8 + 5] = wall_clock64();  // everything but the last row block is done
+    if (have <= SB) {  // row block SB not known to be out yet: wait for it (one lane), then ONE acquire for everything published
+      if (tid == 0) {
+        unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
+        unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
+        unsigned* const err = flags + PS_ERROR;
+        const bool ok = (SB < 7) ? ps_wait_ge(wrow + J, (unsigned)(SB + 1), err, a.spin_limit)
+                                 : ps_wait_ge(wready + J, 1u, err, a.spin_limit);
+        int cnt = (SB < 7) ? (int)ps_ld(wrow + J) : 8;
+        if (cnt > 7) cnt = (ps_ld(wready + J) >= 1u) ? 8 : 7;
+        ps_acquire();
+        if (__hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) cnt = -2;  // the matrix has failed
+        *ok_lds = ok ? cnt : -1;
+      }
+      __syncthreads();
+      have = *ok_lds;
+      __syncthreads();
+      if (have < 0) return have;
+    }
+    if (SB == 7 && tr && tid == 0) tr[J * 8 + 7] = wall_clock64();  // the last row block and z are out
+    // (the step's global addresses are formed HERE, from an opaque copy of the step number: formed at the top of the helper and
+    // kept in scalar registers for all eight steps they made the kernel spill scalars to scratch)
+    int sbo = SB;
+    asm volatile("" : "+s"(sbo));
+    const double* const Wg = a.W + ((size_t)b * a.nblk + J) * (128 * 128) + (size_t)(16 * 128) * (sbo - SB);
+    const int sr = tid >> 5, sc0 = tid & 31;  // staging: thread -> (row, first column) of a 16-row block
+    if (staged <= SB) {  // row block SB of W (16 rows x 16 (SB + 1) columns, lower blocks only) -> LDS, latency in the open
+      const double* const src = Wg + (size_t)(16 * SB + sr) * 128;
+      double* const dst = Wl + PH_WOFF(SB) + sr * PH_WLDQ(SB);
+      double v[(16 * (SB + 1) + 31) / 32];
+#pragma unroll
+      for (int i = 0; i < (16 * (SB + 1) + 31) / 32; i++) v[i] = (sc0 + 32 * i < 16 * (SB + 1)) ? src[sc0 + 32 * i] : 0.0;
+#pragma unroll
+      for (int i = 0; i < (16 * (SB + 1) + 31) / 32; i++)
+        if (sc0 + 32 * i < 16 * (SB + 1)) dst[sc0 + 32 * i] = v[i];
+      staged = SB + 1;
+      __syncthreads();
+    }
+    // the NEXT row block, if it is out already: its loads fly under this step's MFMAs
+    constexpr int NPRE = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
+    double vpre[NPRE];
+    const bool pre = SB < 7 && have > SB + 1 && staged == SB + 1;
+    if (pre) {
+      const double* const src = Wg + (size_t)(16 * (SB + 1) + sr) * 128;
+#pragma unroll
+      for (int i = 0; i < NPRE; i++) vpre[i] = (sc0 + 32 * i < 16 * (SB + 2)) ? src[sc0 + 32 * i] : 0.0;
+    }
+    // column block SB of X = A W^T for this wave's 16 rows: k ascending, as pf_chain_next
+    // (operand reads two 16-wide chunks deep, fenced: left to itself the compiler hoists every LDS read of the step above the
+    // first MFMA -- 64 more live registers, and the kernel spilled)
+    d4 xs = (d4){0.0, 0.0, 0.0, 0.0};
+    {
+      const double* const wq = Wl + PH_WOFF(SB) + lr * PH_WLDQ(SB) + lk;
+      double bq[2][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) bq[0][kk] = wq[4 * kk];
+#pragma unroll
+      for (int g = 0; g <= SB; g++) {
+        if (g < SB) {
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) bq[(g + 1) & 1][kk] = wq[16 * (g + 1) + 4 * kk];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) xs = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * g + kk], bq[g & 1][kk], xs, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ... out at once, in place (this wave's rows of A are in its registers), and into LDS for the update below.  (The 64
+    // registers a resident X would take made the kernel spill: the right-hand side re-reads these stores at the end.)
+    double* const Xs = Xl + (SB & 1) * (128 * PH_XLD);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      Xg[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr)] = xs[r];
+      Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
+    }
+    __syncthreads();
+    // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15
+    {
+      double ua[2][NT], ub[2][NT];
+      const double* const xl = Xs + lr * PH_XLD + lk;  // (tio / tjo: wave-uniform row offsets of the tile's two row blocks)
+#pragma unroll
+      for (int u = 0; u < NT; u++) {
+        ua[0][u] = xl[tio[u]];
+        ub[0][u] = xl[tjo[u]];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        if (kk < 3) {
+#pragma unroll
+          for (int u = 0; u < NT; u++) {
+            ua[(kk + 1) & 1][u] = xl[tio[u] + 4 * (kk + 1)];
+            ub[(kk + 1) & 1][u] = xl[tjo[u] + 4 * (kk + 1)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NT; u++) dt[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(ua[kk & 1][u], ub[kk & 1][u], dt[u], 0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (pre) {
+      double* const dst = Wl + PH_WOFF(SB + 1) + sr * PH_WLDQ(SB + 1);
+#pragma unroll
+      for (int i = 0; i < NPRE; i++)
+        if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vpre[i];
+      staged = SB + 2;
+      __syncthreads();
+    }
+    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr);
+  } else {
+    return have;
+  }
+}
+
+// Returns 0 (block (J+1, J+1) and its right-hand side are in this workgroup's LDS), -1 when a wait was abandoned, -2 when the
+// matrix has failed.
+static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr) {
+  const PfLds lds = pf_lds();
+  double* const s = lds.s;
+  double* const ylds = lds.ylds;
+  double* const Wl = s;
+  double* const Xl = s + PH_WOFF(8);
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int I = J + 1, ld = a.ld, nblk = a.nblk;
+  unsigned* const flags = a.flags;
+  unsigned* const err = flags + PS_ERROR;
+  double* const Mb = a.K + (size_t)b * a.mstride;
+  double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
+  const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
+  if (J > 0) {  // the tile workers' pre-updates of the two blocks (panels 0 .. J-1)
+    if (tid == 0) {
+      const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
+      const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
+      const bool ok = ps_wait_ge(subrdy + I, 1u, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      ps_acquire();
+      *ok_lds = ok ? 1 : 0;
+    }
+    __syncthreads();
+    const int ok = *ok_lds;
+    __syncthreads();
+    if (!ok) return -1;
+  }
+  if (tr && tid == 0) tr[J * 8 + 2] = wall_clock64();
+  double af[32];
+  {
+    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
+#pragma unroll
+    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+  }
+  d4 dt[5];
+  int tio[5], tjo[5], tco[5];  // wave-uniform: row offsets of the tile's row blocks in a staged X column block; tile origin in the LDS tile
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    const int t = w + 8 * u;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    tio[u] = ti * 16 * PH_XLD;
+    tjo[u] = tj * 16 * PH_XLD;
+    tco[u] = ti * 16 * PF_LD + tj * 16;
+    if (t < 36) {
+      const double* const dp = Db + (unsigned)((ti * 16 + lk) * ld + tj * 16 + lr);
+#pragma unroll
+      for (int r = 0; r < 4; r++) dt[u][r] = dp[(unsigned)(4 * r * ld)];
+    } else {
+      dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+  }
+  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr)
+                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr);
+  if (have < 0) return have;
+  if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
+  // ---- z_J is out (the last wait was for wready[J]): the right-hand side, as pf_chain_next -- X read back from this wave's
+  // own stores (drained first)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const double* const zg = a.yw + (size_t)b * a.ystride + J * 128;
+    double zc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) zc[j] = zg[16 * j + lr];
+    double yv[4];
+    {
+      const double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
+#pragma unroll
+      for (int r = 0; r < 4; r++) yv[r] = yi[16 * w + lk + 4 * r];
+    }
+    double xv[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) xv[r][j] = Ab[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * j + lr)];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * w + lk + 4 * r;
+      double part = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) part = __builtin_fma(xv[r][j], zc[j], part);
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      part += __shfl_xor(part, 8);
+      if (lr == 0) ylds[row] = yv[r] - part;
+    }
+  }
+  ps_publish_barrier();  // X has reached memory; nobody reads the staging buffers any more
+  if (tid == 0) ps_signal_add(flags + PS_HDR + (size_t)2 * a.B * nblk + ((size_t)b * nblk + I) * nblk + J);  // xready[I][J]
+  if (tr && tid == 0) tr[J * 8 + 6] = wall_clock64();
+#pragma unroll
+  for (int u = 0; u < 5; u++) {
+    if (w + 8 * u < 36) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) s[tco[u] + (lk + 4 * r) * PF_LD + lr] = dt[u][r];
+    }
+  }
+  __syncthreads();
+  if (tr && tid == 0) tr[J * 8 + 3] = wall_clock64();
+  return 0;
+}
+
+// The chain role of the launch-free factorisation: workgroup b of ps_kernel walks the block columns of matrix b (p = 0), or
+// -- chain pairs -- workgroups (b, 0) and (b, 1) take the even and the odd block columns and prepare each other's next block.
+template <int PAIR>
+static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int p) {
   const int tid = threadIdx.x;
   __shared__ int ps_ok;
   unsigned* const flags = a.flags;
   unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
+  unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
   unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
   for (int J = 0; J < a.nblk; J++) {
+    if (PAIR && (J & 1) != p) {  // the partner factorises column J: prepare block (J+1, J+1) under it
+      if (J + 1 < a.nblk && pf_pair_helper(a, b, J, &ps_ok, tr) < 0) return;
+      continue;
+    }
     if (tr && tid == 0) tr[J * 8 + 0] = wall_clock64();
-    // (J > 0: the block and its right-hand side are in LDS, pf_chain_next left them there)
+    // (J > 0: the block and its right-hand side are in LDS, pf_chain_next / pf_pair_helper left them there)
     const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
-                                         a.nblk, J, PfGen(), J > 0);
+                                         a.nblk, J, PfGen(), J > 0, PAIR ? wrow + J : nullptr);
     if (tr && tid == 0) tr[J * 8 + 1] = wall_clock64();
     ps_publish_barrier();
     if (tid == 0) {
@@ -751,12 +1015,15 @@ static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b) {
       // a failed matrix (status set above) releases every later column at once -- and the panel blocks this workgroup owes
       // the tile tasks: they see the status and only pass their own flags on
       for (int j = J; j < (failed ? a.nblk : J + 1); j++) ps_st(wready + j, 1u);
-      if (failed)
+      if (failed) {
         for (int j = J; j + 1 < a.nblk; j++)
           ps_st(flags + PS_HDR + (size_t)2 * a.B * a.nblk + ((size_t)b * a.nblk + j + 1) * a.nblk + j, 1u);
+        if (PAIR)
+          for (int j = J; j < a.nblk; j++) ps_st(wrow + j, 8u);
+      }
     }
     if (failed) return;
-    if (J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr) < 0) return;  // (abandoned: the host redoes the batch)
+    if (!PAIR && J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr) < 0) return;  // (abandoned: the host redoes the batch)
   }
 }
 

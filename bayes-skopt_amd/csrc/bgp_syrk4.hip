@@ -988,15 +988,24 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
 // The launch-free factorisation: workgroups 0 .. B-1 are the chain (one per matrix, bgp_pf.h), the others the tile workers.
 // One LDS array serves both roles (157 KB: one workgroup per CU); workgroups are placed in index order, so the chain is
 // resident before any tile worker starts to spin.
+template <int PAIR>
 __global__ void __launch_bounds__(512, 1) ps_kernel(PsArgs a) {
-  if ((int)blockIdx.x < a.B)
-    ps_chain_role(a, (int)blockIdx.x);
-  else
-    ps_tile_role(a, (int)blockIdx.x - a.B);
+  const int id = (int)blockIdx.x;
+  if (id >= a.nchain) {
+    ps_tile_role(a, id - a.nchain);
+  } else if (!PAIR) {
+    ps_chain_role<0>(a, id, 0);
+  } else {
+    const int p = id >= a.Bpad ? 1 : 0, b = id - p * a.Bpad;
+    if (b < a.B) ps_chain_role<1>(a, b, p);  // (the padding slots of a pair group exit at once: their CUs go to tile workers)
+  }
 }
 
 void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg) {
-  hipLaunchKernelGGL(ps_kernel, dim3(nwg), dim3(512), 0, st, a);
+  if (a.pair)
+    hipLaunchKernelGGL(ps_kernel<1>, dim3(nwg), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL(ps_kernel<0>, dim3(nwg), dim3(512), 0, st, a);
 }
 int bgp_ps_total_tasks(int B, int nblk) { return B * ps_tasks_per_matrix(nblk); }
 

@@ -57,13 +57,17 @@ def _run(env, shapes=SHAPES):
     return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
 
 
-@pytest.mark.parametrize("ncrit", ["auto", "0", "24"])
+@pytest.mark.parametrize("ncrit", ["auto", "0", "24", "pair"])
 def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit):
     """ncrit = workgroups of the tile kernel's critical pool (automatic: one per critical task of a column up to ten block
-    columns, none beyond; 0: one ticket list; 24: fewer than the critical tasks of a column -- they queue)."""
+    columns, none beyond; 0: one ticket list; 24: fewer than the critical tasks of a column -- they queue); "pair": chain
+    PAIRS (BGP_PS_PAIR=1: two chain workgroups per matrix alternate over the block columns, the idle one preparing the next
+    diagonal block under the other's factorisation from the rows of W as they are published)."""
     ref, _ = _run({"BGP_PERSIST": "0"})
     env = {"BGP_PERSIST": "1"}
-    if ncrit != "auto":
+    if ncrit == "pair":
+        env["BGP_PS_PAIR"] = "1"
+    elif ncrit != "auto":
         env["BGP_PS_NCRIT"] = ncrit
     got, err = _run(env)
     assert "timed out" not in err, err[-1500:]

@@ -47,8 +47,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
     a = run({"BGP_PERSIST": "0"}, shapes, 30)
-    b = run({"BGP_PERSIST": "1", "BGP_PS_TIMEOUT_MS": os.environ.get("BGP_PS_TIMEOUT_MS", "500")}, shapes, 30)
+    b = run({"BGP_PERSIST": "1", "BGP_PS_PAIR": "0", "BGP_PS_TIMEOUT_MS": os.environ.get("BGP_PS_TIMEOUT_MS", "500")}, shapes, 30)
+    c = run({"BGP_PERSIST": "1", "BGP_PS_PAIR": "1", "BGP_PS_TIMEOUT_MS": os.environ.get("BGP_PS_TIMEOUT_MS", "500")}, shapes, 30)
     for k in a:
         same = a[k]["lml"] == b[k]["lml"] and a[k]["status"] == b[k]["status"]
-        print(f"{k:>14s}: launches {a[k]['ms']:.3f} ms   persistent {b[k]['ms']:.3f} ms   x{a[k]['ms'] / b[k]['ms']:.2f}   "
-              f"bit-identical {same}   stable {b[k]['stable']}   failed matrices {sum(1 for s in b[k]['status'] if s)}", flush=True)
+        samec = a[k]["lml"] == c[k]["lml"] and a[k]["status"] == c[k]["status"]
+        print(f"{k:>14s}: launches {a[k]['ms']:.3f} ms   launch-free {b[k]['ms']:.3f} ms (x{a[k]['ms'] / b[k]['ms']:.2f})   chain pairs "
+              f"{c[k]['ms']:.3f} ms (x{a[k]['ms'] / c[k]['ms']:.2f})   bit-identical {same} / {samec}   stable {b[k]['stable']} / "
+              f"{c[k]['stable']}   failed matrices {sum(1 for s in b[k]['status'] if s)}", flush=True)
