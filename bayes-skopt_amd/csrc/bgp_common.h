@@ -102,6 +102,7 @@ struct bgp_ctx {
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
   int panels_auto = 1;   // no BGP_PANELS in the environment: chosen per problem size (bgp_chol.hip)
+  int lookahead = 0;     // env BGP_LOOKAHEAD=1: trailing updates travel with the next group's panel solves (syrk4f_kernel)
   int stagger = 0;       // env BGP_STAGGER=s: walker group g starts with a first panel group of (g * s) % P columns (0: as P)
   int nstreams = 1;
   int streams_auto = 1;  // choose the group count per call from the batch size (see bgp_ctx_create)

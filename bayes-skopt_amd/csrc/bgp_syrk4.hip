@@ -505,17 +505,15 @@ __global__ void __launch_bounds__(256, 3)
 // the two passes run through ONE two-stage ring.  Nothing is written before the last chunk has landed (in place).  Per
 // element the k order of trsm4_kernel: the same bits.
 template <int VAR>
-__global__ void __launch_bounds__(256, 4)
-    trsm5_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
-                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B,
-                 int augmented = 0) {
+static __device__ __forceinline__ void trsm5_body(unsigned lds0, int bid, double* __restrict__ Kbuf,
+                                                  const double* __restrict__ Wbuf, double* __restrict__ yw,
+                                                  const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk,
+                                                  int k, int B, int augmented) {
   constexpr unsigned OPB = 64 * S4_ROWB, STAGEB = 2 * OPB;
   const int nrb = augmented ? nblk : nblk - k - 1;
   int b, t;
-  bgp_map_block(blockIdx.x, 2 * nrb, B, b, t);
+  bgp_map_block(bid, 2 * nrb, B, b, t);
   if (b >= B || status[b] != 0) return;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ib = augmented ? bgp_rowblk(t >> 1, k, nblk - k - 1, nblk) : k + 1 + (t >> 1), half = t & 1;
@@ -575,6 +573,87 @@ __global__ void __launch_bounds__(256, 4)
     part += __shfl_xor(part, 8);
     if ((lane & 15) == 0) yi[row] -= part;
   }
+}
+
+template <int VAR>
+__global__ void __launch_bounds__(256, 4)
+    trsm5_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
+                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B,
+                 int augmented = 0) {
+  __shared__ __attribute__((aligned(1024))) char smem[4 * 64 * S4_ROWB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  trsm5_body<VAR>(lds0, (int)blockIdx.x, Kbuf, Wbuf, yw, status, ld, mstride, ystride, nblk, k, B, augmented);
+}
+
+// Look-ahead by FUSION (LML path, BGP_LOOKAHEAD): ONE launch holds the panel solve of block column c (trsm5's two-pass body:
+// the footprint of an update tile, 256 threads / 32 KB) AND a piece of the previous panel group's trailing update that the
+// solve does not touch (a later block column, or everything from the next group on).  The solve is bound by HBM (the panel
+// is read and written once), the update by the fp64 MFMA pipe: side by side on the same CUs the solve's 1.1 ms per half-step
+// of config C disappear under the update.  (Two streams do not get there: the other walker group's potrf_kernel -- one 157 KB
+// workgroup per CU -- finds no empty CU while an update launch runs, and the groups fall into lockstep: tools/rocprof_overlap.py.)
+// Grid: groups of 8 consecutive blocks (one per XCD, so that a matrix stays on its XCD in both roles); every qg-th group is
+// a solve group until the nTg solve groups are used up.  Regrouping only: per element the operations of the plain schedule
+// in the same order -- the same bits.
+struct S4Fuse {
+  const double* W;   // inverses of the diagonal blocks
+  double* yw;        // working right-hand sides
+  int ystride, ktr;  // panel index of the solve
+  int nTg, qg;       // solve groups (of 8 workgroups), one every qg groups
+};
+
+template <int VAR>
+__global__ void __launch_bounds__(256, 4)
+    syrk4f_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp, int K,
+                  int jstart, int colmode, int B, int total, int pw, S4Fuse f) {
+  constexpr int T = 64;
+  constexpr unsigned STAGEB = 2 * T * S4_ROWB;
+  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int g = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;
+  const int gq = g / f.qg;
+  if (gq < f.nTg && g == gq * f.qg) {
+    trsm5_body<VAR>(lds0, 8 * gq + x, Kbuf, f.W, f.yw, status, ld, mstride, f.ystride, nblk, f.ktr, B, 0);
+    return;
+  }
+  const int gs = g - (gq + 1 < f.nTg ? gq + 1 : f.nTg);  // update groups in front of this one
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int nt128 = nblk - jstart;
+  const S4Tile cur = s4_decode<T>(8 * gs + x, total, s4_ntile<T>(nt128, colmode), Kbuf, status, ld, mstride, kp, jstart, colmode,
+                                  nt128, B, pw);
+  if (cur.q >= total) return;
+  unsigned voff[T / 32];
+  s4_src<T>(voff, ld, w, lane);
+  if (!cur.diag) {
+    s4_tile<T, 2, 2, -64, VAR>(nullptr, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane, S4Gen());
+  } else if (w < 2) {
+    s4_tile<T, 2, 2, 0, VAR>(nullptr, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane, S4Gen());
+  } else {
+    s4_tile<T, 1, 2, -64, VAR>(nullptr, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane, S4Gen());
+  }
+}
+
+// the update (kp, K, jstart, colmode) of bgp_launch_syrk4 with the panel solve of block column ktr in the same launch
+void bgp_launch_syrk4_trsm(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+                           int K, int jstart, int colmode, int B, const double* dW, double* dyw, int ystride, int ktr) {
+  const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
+  static int pw = 0;
+  if (!pw) {
+    const char* e = getenv("BGP_PANEL_WIDTH");
+    pw = (e && atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : S4_PW;
+  }
+  S4Fuse f;
+  f.W = dW;
+  f.yw = dyw;
+  f.ystride = ystride;
+  f.ktr = ktr;
+  const int nT = B8 * 2 * (nblk - ktr - 1);
+  f.nTg = nT / 8;
+  const int nSg = total / 8;
+  f.qg = std::max(1, (f.nTg + nSg) / std::max(1, f.nTg));  // one solve group every qg groups: spread over the whole launch
+  // (with qg groups per solve group the solve groups end at group (nTg - 1) qg < nTg + nSg: every update group has a slot)
+  hipLaunchKernelGGL(syrk4f_kernel<0>, dim3(8 * (f.nTg + nSg)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
+                     colmode, B, total, pw, f);
 }
 
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
