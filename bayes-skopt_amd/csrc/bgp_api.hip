@@ -231,8 +231,8 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_LOOKAHEAD", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_NCRIT", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STAGGER", "BGP_STREAMS", "BGP_TRSM", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
+                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_NCRIT", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -305,10 +305,6 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
       c->panels = atoi(envp);
       c->panels_auto = 0;
     }
-    const char* envla = getenv("BGP_LOOKAHEAD");
-    c->lookahead = (envla && atoi(envla) != 0) ? 1 : 0;
-    const char* envsg = getenv("BGP_STAGGER");
-    c->stagger = envsg ? atoi(envsg) : 0;
     (void)hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     for (int g = 0; g < ns; g++) {
       (void)hipStreamCreate(&c->gstream[g]);
@@ -583,7 +579,7 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         } else {
           rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
           if (rc) return rc;
-          rc = bgp_launch_cholesky_slice(c, o, gb, st, 0, c->stagger > 0 ? (g * c->stagger) % 16 : 0);
+          rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
         }
         if (rc) return rc;
         BGP_HIP(hipEventRecord(c->ev_done[g], st));

@@ -255,8 +255,6 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
                       int K, int jstart, int colmode, int B, const S4Gen* gen);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k, int augmented);
-void bgp_launch_syrk4_trsm(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
-                           int K, int jstart, int colmode, int B, const double* dW, double* dyw, int ystride, int ktr);
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
@@ -287,13 +285,13 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   return bgp_launch_cholesky_slice(ctx, 0, B, ctx->stream, augmented);
 }
 
-int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, int first_np) {
-  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr, first_np);
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
+  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr);
 }
 
 // gen != nullptr (LML path only): the matrices hold block column 0 only (bgp_launch_kbuild_col0); the trailing updates
 // of the FIRST group of block columns -- the first launches to touch any other tile -- generate the Gram entries.
-int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen, int first_np) {
+int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -316,42 +314,9 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     // with the LDS-DMA kernels, whose look-ahead column launches are cheap enough), 2 below (P = 2, 3, 4 are equal
     // within noise at n = 1024); BGP_PANELS fixes it.
     const int P = ctx->panels_auto ? (nblk >= 12 ? 4 : 2) : ctx->panels;
-    // first_np > 0: the FIRST panel group holds first_np block columns only (walker groups on different streams are staggered
-    // by half a panel group, so that one group's latency- / memory-bound column phase meets the other's bulk update;
-    // regrouping only: same operations per element in the same order, same bits)
-    if (ctx->lookahead && !gen && !ctx->timing) {
-      // Look-ahead by fusion (syrk4f_kernel): the trailing update of a panel group is not one launch behind the group but
-      // travels with the NEXT group's panel solves -- block column by block column as that group needs them, the rest with its
-      // last solve:   R[col k] | potrf(k) | trsm(k) + R[col k+1] | col k+1 | potrf(k+1) | trsm(k+1) + R[col k+2] | ... |
-      // trsm(k+np-1) + R[cols >= k+np].  Per element the updates still arrive in ascending k.  (Per-launch timing keeps the
-      // plain schedule: its categories are kernels, not fused launches.)
-      int k = 0, pk = -1, pK = 0;  // pending update: panels pk .. pk + pK/128 - 1, not yet applied to the columns >= k
-      while (k < nblk) {
-        const int np = std::min((k == 0 && first_np > 0) ? std::min(first_np, P) : P, nblk - k);
-        if (pk >= 0) bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, pk, pK, k, 1, B, nullptr);
-        for (int j = 0; j < np; j++) {
-          const int c = k + j;
-          hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus,
-                             ctx->n, ld, mstride, ystride, nblk, c, PfGen());
-          if (c + 1 >= nblk) break;
-          if (pk >= 0 && j + 1 < np)
-            bgp_launch_syrk4_trsm(st, B8, dK, dstatus, ld, mstride, nblk, pk, pK, c + 1, 1, B, dW, dyw, ystride, c);
-          else if (pk >= 0 && k + np < nblk)
-            bgp_launch_syrk4_trsm(st, B8, dK, dstatus, ld, mstride, nblk, pk, pK, k + np, 0, B, dW, dyw, ystride, c);
-          else
-            bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, c, 0);
-          if (j + 1 < np) bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), c + 1, 1, B, nullptr);
-        }
-        pk = (k + np < nblk) ? k : -1;
-        pK = 128 * np;
-        k += np;
-      }
-      BGP_HIP(hipGetLastError());
-      return BGP_OK;
-    }
     int k = 0;
     while (k < nblk) {
-      const int np = std::min((k == 0 && first_np > 0) ? std::min(first_np, P) : P, nblk - k);
+      const int np = std::min(P, nblk - k);
       for (int j = 0; j < np; j++) {
         bgp_tbegin(ctx, 1, st);
         hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus,

@@ -102,8 +102,6 @@ struct bgp_ctx {
   // latency-bound potrf / small trsm launches of one group overlap the MFMA-bound syrk of another
   int panels = 2;        // right-looking LML path: block columns per trailing update (K = 128 * panels; env BGP_PANELS)
   int panels_auto = 1;   // no BGP_PANELS in the environment: chosen per problem size (bgp_chol.hip)
-  int lookahead = 0;     // env BGP_LOOKAHEAD=1: trailing updates travel with the next group's panel solves (syrk4f_kernel)
-  int stagger = 0;       // env BGP_STAGGER=s: walker group g starts with a first panel group of (g * s) % P columns (0: as P)
   int nstreams = 1;
   int streams_auto = 1;  // choose the group count per call from the batch size (see bgp_ctx_create)
   hipStream_t gstream[BGP_MAX_STREAMS] = {nullptr};
@@ -319,7 +317,7 @@ int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int u
 // scaled inputs + block column 0 of the Gram matrices only; fills `gen` for the trailing updates that generate the rest
 int bgp_launch_kbuild_col0(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha, const double* dXb, size_t xstride,
                            S4Gen* gen);
-int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen, int first_np = 0);
+int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen);
 // same for the slice [off, off+B) of the current batch on an explicit stream
 int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
                             int use_alpha);
@@ -341,4 +339,4 @@ int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* 
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
 // n <= 128: K-build + factorisation + LML of the slice [off, off+B) in ONE launch (bgp_chol.hip, potrf_kernel<1,..>)
 int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st);
-int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, int first_np = 0);
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);

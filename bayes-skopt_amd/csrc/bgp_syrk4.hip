@@ -496,183 +496,12 @@ __global__ void __launch_bounds__(256, 3)
   }
 }
 
-// The same panel solve in 32 KB of LDS instead of 48: the footprint of syrk4_kernel<64>, so that panel-solve workgroups of
-// one walker group fit into the LDS holes that finishing trailing-update workgroups of the OTHER walker group leave on a CU
-// (a 48 KB workgroup never fits into a 32 KB hole: with two streams the memory-bound solve then waits for the tail of the
-// MFMA-bound update instead of running under it).  Two passes over the output columns: pass 0 forms X[:, 0:64] from the W
-// rows 0 .. 63 (k < 64 only: W is lower triangular), pass 1 X[:, 64:128] from the W rows 64 .. 127 (all k); the A rows
-// are staged once per pass, a stage holds 64 A rows + 64 W rows of one 16-wide k-chunk (16 KB), and the twelve chunks of
-// the two passes run through ONE two-stage ring.  Nothing is written before the last chunk has landed (in place).  Per
-// element the k order of trsm4_kernel: the same bits.
-template <int VAR>
-static __device__ __forceinline__ void trsm5_body(unsigned lds0, int bid, double* __restrict__ Kbuf,
-                                                  const double* __restrict__ Wbuf, double* __restrict__ yw,
-                                                  const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk,
-                                                  int k, int B, int augmented) {
-  constexpr unsigned OPB = 64 * S4_ROWB, STAGEB = 2 * OPB;
-  const int nrb = augmented ? nblk : nblk - k - 1;
-  int b, t;
-  bgp_map_block(bid, 2 * nrb, B, b, t);
-  if (b >= B || status[b] != 0) return;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ib = augmented ? bgp_rowblk(t >> 1, k, nblk - k - 1, nblk) : k + 1 + (t >> 1), half = t & 1;
-  double* A = Kbuf + (size_t)b * mstride + (size_t)(ib * 128 + half * 64) * ld + k * 128;
-  const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  unsigned voffA[2], voffW[2];
-  s4_src<64>(voffA, ld, w, lane);
-  s4_src<64>(voffW, 128, w, lane);
-  const int r0 = w * 16;
-  unsigned pa[4], pb[4];
-  s4_frag_addr(pa, lds0, r0, lane);
-  s4_frag_addr(pb, lds0 + OPB, 0, lane);
-  d4 acc0[1][4], acc1[1][4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) acc0[0][j] = acc1[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
-  // virtual chunk v = 0 .. 11: pass 0 chunks 0 .. 3, then pass 1 chunks 0 .. 7
-#define T5_ISSUE(v, base)                                                                                     \
-  do {                                                                                                        \
-    const int c__ = (v) < 4 ? (v) : (v) - 4, p__ = (v) < 4 ? 0 : 1;                                           \
-    s4_issue<64>(A, voffA, c__ * S4_KC, (base), w);                                                           \
-    s4_issue_from<64>(W + p__ * 64 * 128, voffW, c__ * S4_KC, (base) + OPB, w, p__ ? 16 * (c__ - 4) : 16 * c__); \
-  } while (0)
-  if (!(VAR & 1)) T5_ISSUE(0, lds0);
-  for (int v = 0; v < 12; v += 2) {
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-      S4_WAIT_VM0();
-      __builtin_amdgcn_s_barrier();
-      if (!(VAR & 1) && v + s + 1 < 12) T5_ISSUE(v + s + 1, lds0 + (unsigned)((s ^ 1) * STAGEB));
-      const int vv = v + s;
-      if (vv < 4)
-        s4_mma<1, 4, -64, VAR, 0>(pa, pb, s * STAGEB, acc0, vv);
-      else
-        s4_mma<1, 4, -64, VAR, 0>(pa, pb, s * STAGEB, acc1, vv > 8 ? vv - 8 : 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-#undef T5_ISSUE
-  const double* zk = yw + (size_t)b * ystride + k * 128;
-  double zc[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-  double* yi = yw + (size_t)b * ystride + ib * 128 + half * 64;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = GK_ROWB(r0, 0, lane, r);
-    double part = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const double x = j < 4 ? acc0[0][j][r] : acc1[0][j - 4][r];
-      if (!(VAR & 8)) A[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
-      part += x * zc[j];
-    }
-    part += __shfl_xor(part, 1);
-    part += __shfl_xor(part, 2);
-    part += __shfl_xor(part, 4);
-    part += __shfl_xor(part, 8);
-    if ((lane & 15) == 0) yi[row] -= part;
-  }
-}
-
-template <int VAR>
-__global__ void __launch_bounds__(256, 4)
-    trsm5_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
-                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B,
-                 int augmented = 0) {
-  __shared__ __attribute__((aligned(1024))) char smem[4 * 64 * S4_ROWB];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  trsm5_body<VAR>(lds0, (int)blockIdx.x, Kbuf, Wbuf, yw, status, ld, mstride, ystride, nblk, k, B, augmented);
-}
-
-// Look-ahead by FUSION (LML path, BGP_LOOKAHEAD): ONE launch holds the panel solve of block column c (trsm5's two-pass body:
-// the footprint of an update tile, 256 threads / 32 KB) AND a piece of the previous panel group's trailing update that the
-// solve does not touch (a later block column, or everything from the next group on).  The solve is bound by HBM (the panel
-// is read and written once), the update by the fp64 MFMA pipe: side by side on the same CUs the solve's 1.1 ms per half-step
-// of config C disappear under the update.  (Two streams do not get there: the other walker group's potrf_kernel -- one 157 KB
-// workgroup per CU -- finds no empty CU while an update launch runs, and the groups fall into lockstep: tools/rocprof_overlap.py.)
-// Grid: groups of 8 consecutive blocks (one per XCD, so that a matrix stays on its XCD in both roles); every qg-th group is
-// a solve group until the nTg solve groups are used up.  Regrouping only: per element the operations of the plain schedule
-// in the same order -- the same bits.
-struct S4Fuse {
-  const double* W;   // inverses of the diagonal blocks
-  double* yw;        // working right-hand sides
-  int ystride, ktr;  // panel index of the solve
-  int nTg, qg;       // solve groups (of 8 workgroups), one every qg groups
-};
-
-template <int VAR>
-__global__ void __launch_bounds__(256, 4)
-    syrk4f_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp, int K,
-                  int jstart, int colmode, int B, int total, int pw, S4Fuse f) {
-  constexpr int T = 64;
-  constexpr unsigned STAGEB = 2 * T * S4_ROWB;
-  __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int g = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;
-  const int gq = g / f.qg;
-  if (gq < f.nTg && g == gq * f.qg) {
-    trsm5_body<VAR>(lds0, 8 * gq + x, Kbuf, f.W, f.yw, status, ld, mstride, f.ystride, nblk, f.ktr, B, 0);
-    return;
-  }
-  const int gs = g - (gq + 1 < f.nTg ? gq + 1 : f.nTg);  // update groups in front of this one
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
-  const int nt128 = nblk - jstart;
-  const S4Tile cur = s4_decode<T>(8 * gs + x, total, s4_ntile<T>(nt128, colmode), Kbuf, status, ld, mstride, kp, jstart, colmode,
-                                  nt128, B, pw);
-  if (cur.q >= total) return;
-  unsigned voff[T / 32];
-  s4_src<T>(voff, ld, w, lane);
-  if (!cur.diag) {
-    s4_tile<T, 2, 2, -64, VAR>(nullptr, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane, S4Gen());
-  } else if (w < 2) {
-    s4_tile<T, 2, 2, 0, VAR>(nullptr, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane, S4Gen());
-  } else {
-    s4_tile<T, 1, 2, -64, VAR>(nullptr, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane, S4Gen());
-  }
-}
-
-// the update (kp, K, jstart, colmode) of bgp_launch_syrk4 with the panel solve of block column ktr in the same launch
-void bgp_launch_syrk4_trsm(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
-                           int K, int jstart, int colmode, int B, const double* dW, double* dyw, int ystride, int ktr) {
-  const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
-  static int pw = 0;
-  if (!pw) {
-    const char* e = getenv("BGP_PANEL_WIDTH");
-    pw = (e && atoi(e) >= 1 && atoi(e) <= 64) ? atoi(e) : S4_PW;
-  }
-  S4Fuse f;
-  f.W = dW;
-  f.yw = dyw;
-  f.ystride = ystride;
-  f.ktr = ktr;
-  const int nT = B8 * 2 * (nblk - ktr - 1);
-  f.nTg = nT / 8;
-  const int nSg = total / 8;
-  f.qg = std::max(1, (f.nTg + nSg) / std::max(1, f.nTg));  // one solve group every qg groups: spread over the whole launch
-  // (with qg groups per solve group the solve groups end at group (nTg - 1) qg < nTg + nSg: every update group has a slot)
-  hipLaunchKernelGGL(syrk4f_kernel<0>, dim3(8 * (f.nTg + nSg)), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
-                     colmode, B, total, pw, f);
-}
-
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k, int augmented) {
   const int B8 = 8 * ((B + 7) / 8);
   const int nrb = augmented ? nblk : nblk - k - 1;
-  static int kind = 0;
-  if (!kind) {
-    // 4 (default): trsm4_kernel (48 KB of LDS, one pass); 5: trsm5_kernel (32 KB, two passes) -- measured 4 % slower per step
-    // at config C, alone and under the other walker group's update alike
-    const char* e = getenv("BGP_TRSM");
-    kind = (e && atoi(e) == 5) ? 5 : 4;
-  }
-  if (kind == 4)
-    hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * nrb), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk,
-                       k, B, augmented);
-  else
-    hipLaunchKernelGGL(trsm5_kernel<0>, dim3(B8 * 2 * nrb), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk,
-                       k, B, augmented);
+  hipLaunchKernelGGL(trsm4_kernel<0>, dim3(B8 * 2 * nrb), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk,
+                     k, B, augmented);
 }
 
 // ------------------------------------------------------------------------------------------
