@@ -17,12 +17,14 @@ void bgp_set_error(const char* fmt, ...) {
 
 extern "C" const char* bgp_last_error(void) { return g_err.c_str(); }
 
-BgpXfer& bgp_xfer() {
-  static thread_local BgpXfer x;
-  return x;
-}
+#include <mutex>
+static BgpXfer g_xfer;
+static std::mutex g_xfer_mutex;
 
-void bgp_xfer_drop_pending() { bgp_xfer().pending.clear(); }
+void bgp_xfer_drop_pending() {
+  std::lock_guard<std::mutex> lock(g_xfer_mutex);
+  g_xfer.pending.clear();
+}
 
 char* BgpXfer::take(size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
@@ -57,28 +59,51 @@ void BgpXfer::release(hipStream_t st) {
   pending.resize(keep);
   busy.erase(std::remove(busy.begin(), busy.end(), st), busy.end());
   if (pending.empty() && busy.empty()) {  // nothing staged is in flight any more: the arena starts over
-    if (blocks.size() > 1) {              // (several blocks: one of the total size next time)
-      size_t total = 0;
-      for (Block& b : blocks) {
-        total += b.cap;
-        (void)hipHostFree(b.p);
-      }
+    size_t total = 0;
+    for (Block& b : blocks) total += b.cap;
+    if (blocks.size() > 1 || total > BGP_XFER_KEEP) {  // several blocks: one of the total size next time, capped
+      for (Block& b : blocks) (void)hipHostFree(b.p);
       blocks.clear();
-      Block nb;
-      nb.cap = total;
-      nb.off = 0;
-      nb.p = nullptr;
-      if (hipHostMalloc((void**)&nb.p, nb.cap, hipHostMallocDefault) == hipSuccess) blocks.push_back(nb);
-      else (void)hipGetLastError();
+      if (total <= BGP_XFER_KEEP) {
+        Block nb;
+        nb.cap = total;
+        nb.off = 0;
+        nb.p = nullptr;
+        if (hipHostMalloc((void**)&nb.p, nb.cap, hipHostMallocDefault) == hipSuccess) blocks.push_back(nb);
+        else (void)hipGetLastError();
+      }
     }
     for (Block& b : blocks) b.off = 0;
   }
 }
 
+void bgp_xfer_release(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_xfer_mutex);
+  g_xfer.release(st);
+}
+
+// the last context of the process is gone: give the pinned arena back (bgp_ctx_destroy)
+static int g_live_contexts = 0;
+static void xfer_free_all() {
+  std::lock_guard<std::mutex> lock(g_xfer_mutex);
+  if (!g_xfer.pending.empty() || !g_xfer.busy.empty()) return;
+  for (BgpXfer::Block& b : g_xfer.blocks) (void)hipHostFree(b.p);
+  g_xfer.blocks.clear();
+}
+
 hipError_t bgp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
                               hipMemcpyKind kind, hipStream_t st) {
   if (width == 0 || height == 0) return hipSuccess;
-  BgpXfer& x = bgp_xfer();
+  if ((kind == hipMemcpyHostToDevice || kind == hipMemcpyDeviceToHost) && width * height > BGP_XFER_DIRECT) {
+    // large: synchronously, straight between the caller's buffer and the device, behind everything the stream holds
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    bgp_xfer_release(st);
+    if (height == 1 || (dpitch == width && spitch == width)) return hipMemcpy(dst, src, width * height, kind);
+    return hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
+  }
+  std::lock_guard<std::mutex> lock(g_xfer_mutex);
+  BgpXfer& x = g_xfer;
   if (kind == hipMemcpyHostToDevice) {
     char* stage = x.take(width * height);
     if (!stage) return hipErrorOutOfMemory;
@@ -270,6 +295,10 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
   }
   BGP_HIP(hipSetDevice(device));
   bgp_ctx* c = new bgp_ctx();
+  {
+    std::lock_guard<std::mutex> lock(g_xfer_mutex);
+    g_live_contexts++;
+  }
   c->device = device;
   c->d = d;
   c->ks = *ks;
@@ -278,6 +307,8 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
   if (hipStreamCreate(&c->stream) != hipSuccess) {
     bgp_set_error("hipStreamCreate failed");
     delete c;
+    std::lock_guard<std::mutex> lock(g_xfer_mutex);
+    g_live_contexts--;
     return BGP_ERR_HIP;
   }
   {
@@ -381,6 +412,12 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+  bool last;
+  {
+    std::lock_guard<std::mutex> lock(g_xfer_mutex);
+    last = --g_live_contexts == 0;
+  }
+  if (last) xfer_free_all();
 }
 
 int bgp_ensure_scratch(bgp_ctx* c, size_t doubles) {

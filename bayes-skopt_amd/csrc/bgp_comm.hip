@@ -97,7 +97,7 @@ static int comm_sync(bgp_comm* c, const char* what) {
   for (unsigned it = 0;; it++) {
     const hipError_t e = hipStreamQuery(c->stream);
     if (e == hipSuccess) {
-      bgp_xfer().release(c->stream);
+      bgp_xfer_release(c->stream);
       return BGP_OK;
     }
     (void)hipGetLastError();

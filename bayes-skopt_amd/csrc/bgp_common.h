@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bgp.h"
@@ -61,7 +62,14 @@ struct BgpXfer {
   char* take(size_t bytes);
   void release(hipStream_t st);   // the stream has been synchronised: unpack its downloads, forget its uploads
 };
-BgpXfer& bgp_xfer();
+// ONE arena per process behind a mutex (bgp_api.hip): the bookkeeping is keyed by STREAM, so whichever thread synchronises a
+// stream unpacks that stream's downloads -- a thread-local arena left them behind when another thread than the enqueuing one
+// waited.  Transfers above BGP_XFER_DIRECT bytes (predictive covariances, whole kernel matrices, debugging downloads) do not
+// go through it: they are copied synchronously, straight between the caller's buffer and the device (nothing asynchronous
+// is left behind either way), and an idle arena above BGP_XFER_KEEP bytes is given back.
+#define BGP_XFER_DIRECT ((size_t)8 << 20)
+#define BGP_XFER_KEEP ((size_t)64 << 20)
+void bgp_xfer_release(hipStream_t st);
 hipError_t bgp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
                               hipMemcpyKind kind, hipStream_t st);
 static inline hipError_t bgp_memcpy_async(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
@@ -72,23 +80,38 @@ static inline hipError_t bgp_memcpy_async(void* dst, const void* src, size_t byt
 // the thread, and for the 0.5-1 ms device calls of the small-batch regime (config E: 26 calls of 50 proposals at
 // n ~ 1000 per tell) the wake-up was measured BISTABLE on MI355X -- the same tell took 25 ms or 52 ms of MCMC, +1 ms per
 // call, run to run and tell to tell.  Polling hipStreamQuery from the calling thread (which has nothing else to do)
-// removes that; after 200 ms of polling the core is handed back to the blocking wait.  BGP_WAIT=block selects the
-// runtime's wait from the start (A/B measurements, oversubscribed hosts).
+// removes that.  The first 2 ms are a tight poll (the calls this exists for last 0.1-2 ms); a longer call (n = 4096 batches,
+// the 10 112^2 covariance of sample_y) is polled every ~20 us with the core handed back in between, and after 200 ms the
+// runtime's blocking wait takes over.  BGP_WAIT=block selects the runtime's wait from the start (A/B measurements,
+// oversubscribed hosts).
 int bgp_wait_spins();
+static inline void bgp_cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
 static inline hipError_t bgp_stream_sync(hipStream_t st) {
   hipError_t e = hipErrorNotReady;
   if (bgp_wait_spins()) {
     const auto t0 = std::chrono::steady_clock::now();
+    bool slow = false;
     for (unsigned it = 0;; it++) {
       e = hipStreamQuery(st);
       if (e != hipErrorNotReady) break;
       (void)hipGetLastError();  // (hipErrorNotReady is recorded as the thread's last error)
-      if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
-      __builtin_ia32_pause();
+      if (slow) {
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+      } else {
+        if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) slow = true;
+        bgp_cpu_relax();
+      }
     }
   }
   if (e == hipErrorNotReady) e = hipStreamSynchronize(st);
-  if (e == hipSuccess) bgp_xfer().release(st);
+  if (e == hipSuccess) bgp_xfer_release(st);
   return e;
 }
 

@@ -1031,7 +1031,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
   } while (0);
   (void)hipStreamSynchronize(c->stream);
   if (rc) bgp_xfer_drop_pending();  // (a failed call unpacks nothing into the caller's buffers later)
-  bgp_xfer().release(c->stream);
+  bgp_xfer_release(c->stream);
   return rc;
 }
 

@@ -1,7 +1,9 @@
-"""Launch-free factorisation of small batches (BGP_PERSIST=1: ps_chain_kernel + ps_tile_kernel on complementary CU-masked
-streams, csrc/bgp_chol.hip / bgp_syrk4.hip): the same arithmetic in the same order as the multi-launch schedule, so the
-log-likelihoods, the failure statuses and a whole MCMC chain must be BIT-identical to it; every in-kernel wait is bounded
-and a timeout falls back to the multi-launch path with the right answer."""
+"""Launch-free factorisation of small batches (bgp_set_persist / BGP_PERSIST; csrc/bgp_syrk4.hip::ps_kernel): ONE persistent
+kernel per batch -- chain workgroups (one per matrix, or a pair per matrix with BGP_PS_PAIR=1; csrc/bgp_pf.h) first in the grid,
+ticket-ordered left-looking tile workers behind them, one LDS array for both roles, device-scope flags between them.  The same
+arithmetic in the same order as the multi-launch schedule, so the log-likelihoods, the failure statuses, the factors and a
+whole MCMC chain must be BIT-identical to it; every in-kernel wait is bounded, a time-out falls back to the multi-launch
+path with the right answer, and the context tries the launch-free path again after a cool-down (three time-outs switch it off)."""
 import json
 import os
 import subprocess
@@ -238,3 +240,40 @@ def test_the_automatic_choice_takes_the_launch_free_path_where_it_measured_faste
     assert res.returncode == 0, res.stderr[-2000:]
     got = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert got == {"1024_32": True, "1024_4": False, "512_32": False, "1536_2": True, "1024_64": False, "768_32": True}, got
+
+
+def test_time_out_policy_cool_down_then_off_for_good():
+    """One transient time-out must not cost a context the path for life (and three must): with every wait timing out and a
+    cool-down of 2 eligible calls the context goes launch-free, by launches twice, launch-free again, ... and after the third
+    time-out stays on the launches; bgp_persist_stats counts; bgp_set_persist(ctx, 1) re-arms.  Results are right throughout."""
+    code = r"""
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import bayes_skopt_amd
+from bayes_skopt_amd import _lib
+rng = np.random.RandomState(1)
+n, d, B = 1024, 4, 8
+X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1))
+ctx = _lib.Context(X, y, 1e-10, max_batch=B)
+H = np.concatenate([[0.0], np.full(d, np.log(0.4)), [np.log(0.02)]]) + 0.1 * rng.randn(B, d + 2)
+ctx.set_persist(0); ref = ctx.lml(H)
+ctx.set_persist(1)
+log = []
+for i in range(12):
+    ok = bool(np.array_equal(ctx.lml(H), ref))
+    s = ctx.persist_stats(); log.append([ok, s["calls"], s["timeouts"], s["disabled"], s["cooldown_left"]])
+ctx.set_persist(1)
+ok = bool(np.array_equal(ctx.lml(H), ref)); s = ctx.persist_stats(); log.append([ok, s["calls"], s["timeouts"], s["disabled"], s["cooldown_left"]])
+print("RESULT " + json.dumps(log))
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BGP_PS_TIMEOUT_TICKS="200", BGP_PS_COOLDOWN="2"),
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    log = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert all(r[0] for r in log)
+    # call 1: launch-free, times out (1), two calls by launches, call 4 launch-free again (2), two by launches, call 7 (3): off
+    assert [r[1:3] for r in log[:12]] == [[1, 1], [1, 1], [1, 1], [2, 2], [2, 2], [2, 2], [3, 3]] + [[3, 3]] * 5
+    assert log[6][3] is True and log[6][4] == 0 and log[11][3] is True
+    assert log[12][1:3] == [4, 4]  # re-armed by bgp_set_persist(ctx, 1): tried (and timed out) once more
+    assert res.stderr.count("timed out") == 3  # said so three times, then quietly
