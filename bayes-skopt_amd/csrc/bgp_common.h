@@ -301,7 +301,7 @@ int bgp_ps_cooldown_calls();  // BGP_PS_COOLDOWN, default 256 (bgp_api.hip)
 static inline void bgp_ps_note_timeout(bgp_ctx* c, const char* what) {
   c->ps_timeouts++;
   c->ps_disabled = 1;
-  c->ps_cooldown = c->ps_timeouts >= 3 ? 0 : bgp_ps_cooldown_calls();
+  c->ps_cooldown = c->ps_timeouts >= 3 ? 0 : bgp_ps_cooldown_calls() + 1;  // (+ 1: the redo of this very batch counts one)
   if (c->ps_timeouts <= 3)
     fprintf(stderr, "libbgp: warning: the launch-free factorisation timed out (a wait outlasted BGP_PS_TIMEOUT_MS); %s on the "
                     "multi-launch path, which this context keeps %s (time-out %lld of this context; bgp_persist_stats)\n", what,
