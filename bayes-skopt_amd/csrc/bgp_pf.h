@@ -840,11 +840,12 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       Xg[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr)] = xs[r];
-      Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
+      if constexpr (NT > 0) Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
     }
-    __syncthreads();
-    // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15
-    {
+    // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15   (NT == 0: the streamed
+    // panel solve of a tile task -- no diagonal block)
+    if constexpr (NT > 0) {
+      __syncthreads();
       double ua[2][NT], ub[2][NT];
       const double* const xl = Xs + lr * PH_XLD + lk;  // (tio / tjo: wave-uniform row offsets of the tile's two row blocks)
 #pragma unroll
@@ -986,6 +987,60 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
   }
   __syncthreads();
   if (tr && tid == 0) tr[J * 8 + 3] = wall_clock64();
+  return 0;
+}
+
+// The same streamed solve for a TILE task (chain pairs only): S(J+2, J), the block both pre-updates of column J+2 wait for, does
+// not wait for the whole of W_JJ either -- its workgroup has applied the panels 0 .. J-1 and stored the block, re-reads its own
+// rows as A fragments and follows pf_block(J) row block by row block; X_{J+2,J} is out a few us after W_JJ's last row block
+// instead of a whole 12 us solve later (the head of the tile side's critical hand-over).  Right-hand side and flag as the
+// ring solve of ps_tile_role.  Returns 0, -1 (abandoned) or -2 (the matrix has failed: the caller only passes its flag on).
+static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J, int I, int* ok_lds) {
+  double* const Wl = reinterpret_cast<double*>(pf_lds_raw());
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));
+  const int tid = tid_, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lk = lane >> 4;
+  const int ld = a.ld;
+  double* const Ab = a.K + (size_t)b * a.mstride + (size_t)I * 128 * ld + (size_t)J * 128;
+  double af[32];
+  {
+    const double* const ap = Ab + (unsigned)((16 * w + lr) * ld + lk);
+#pragma unroll
+    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+  }
+  d4 dt[5];
+  const int tz[5] = {0, 0, 0, 0, 0};
+  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr);
+  if (have < 0) return have;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    const double* const zg = a.yw + (size_t)b * a.ystride + J * 128;
+    double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
+    double zc[8], yv[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++) zc[j] = zg[16 * j + lr];
+#pragma unroll
+    for (int r = 0; r < 4; r++) yv[r] = yi[16 * w + lk + 4 * r];
+    double xv[4][8];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) xv[r][j] = Ab[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * j + lr)];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int row = 16 * w + lk + 4 * r;
+      double part = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) part = __builtin_fma(xv[r][j], zc[j], part);
+      part += __shfl_xor(part, 1);
+      part += __shfl_xor(part, 2);
+      part += __shfl_xor(part, 4);
+      part += __shfl_xor(part, 8);
+      if (lr == 0) yi[row] = yv[r] - part;
+    }
+  }
   return 0;
 }
 

@@ -642,6 +642,7 @@ static __device__ __forceinline__ void s8_ring_run_diag(const double* XA, const 
 
 #define PS_NST 4
 // wg = this workgroup's index among the tile workgroups of the launch
+template <int PAIR>
 static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   constexpr unsigned AOPB = 128 * S4_ROWB, STAGEB = 256 * S4_ROWB;
   static_assert(PS_NST * STAGEB <= PF_LDS_BYTES, "the operand ring lives in the chain role's LDS array");
@@ -837,6 +838,17 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     }
     // ---- 2. panel solve against W_JJ: waves stacked along the rows, 16 rows x 128 columns each
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
+    if (PAIR && I == J + 2) {  // chain pairs: the critical solve of the column follows pf_block(J) row block by row block
+      __syncthreads();  // every wave's part of the block is in memory (the solve re-reads it as A fragments)
+      const int r = dead ? -2 : pf_stream_S(a, b, J, I, &sh_q);
+      if (r == -1) return;
+      if (tr) tr[5] = wall_clock64();
+      ps_publish_barrier();
+      if (tid == 0) ps_signal_add(xrI + J);
+      if (tr) tr[6] = wall_clock64();
+      __syncthreads();
+      continue;
+    }
     if (tid == 0) {
       const bool ok = ps_wait_ge(wready + J, 1u, err, a.spin_limit);
       ps_acquire();
@@ -900,7 +912,7 @@ template <int PAIR>
 __global__ void __launch_bounds__(512, 1) ps_kernel(PsArgs a) {
   const int id = (int)blockIdx.x;
   if (id >= a.nchain) {
-    ps_tile_role(a, id - a.nchain);
+    ps_tile_role<PAIR>(a, id - a.nchain);
   } else if (!PAIR) {
     ps_chain_role<0>(a, id, 0);
   } else {
