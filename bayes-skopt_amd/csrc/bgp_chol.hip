@@ -205,6 +205,14 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     a.Bpad = 8 * ((B + 7) / 8);
     a.pair = (want == 1 && nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B)) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
+    {
+      static int ns = -1;
+      if (ns < 0) {
+        const char* e = getenv("BGP_PS_STREAM");
+        ns = e ? atoi(e) : 2;
+      }
+      a.ncrit_stream = ns;
+    }
   }
   const int tile_wgs = std::min(a.total, ncu - a.nchain);
   {
