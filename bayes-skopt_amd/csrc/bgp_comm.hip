@@ -107,7 +107,7 @@ static int comm_sync(bgp_comm* c, const char* what) {
       return BGP_ERR_HIP;
     }
     if ((it & 255) != 255) {
-      __builtin_ia32_pause();
+      bgp_cpu_relax();
       continue;
     }
     const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -362,8 +362,19 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
     const unsigned* pe = (round == 0 && ctx->ps_inflight && ctx->ps_flags) ? ctx->ps_flags + PS_ERROR : nullptr;
     hipLaunchKernelGGL(lml_pack_kernel, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, c->stream, ctx->dlml, Bp,
                        per_rank, pe, local_error, c->dsend);
-    BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, slot, ncclFloat64, c->comm, c->stream));
-    BGP_HIP(hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // (a failure to ENQUEUE the collective leaves the peers in it: abort the communicator so that they fail at once too)
+    const ncclResult_t nr = g_rccl.AllGather(c->dsend, c->drecv, slot, ncclFloat64, c->comm, c->stream);
+    hipError_t he = hipSuccess;
+    if (nr == ncclSuccess) he = hipMemcpyAsync(c->hrecv, c->drecv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (nr != ncclSuccess || he != hipSuccess) {
+      bgp_set_error("bgp_lml_batch_wait_allgather: enqueueing the exchange failed (%s); communicator aborted",
+                    nr != ncclSuccess ? g_rccl.GetErrorString(nr) : hipGetErrorString(he));
+      (void)hipGetLastError();
+      if (g_rccl.CommAbort && c->comm) (void)g_rccl.CommAbort(c->comm);
+      c->comm = nullptr;
+      c->aborted = 1;
+      return BGP_ERR_COMM;
+    }
     rc = comm_sync(c, "bgp_lml_batch_wait_allgather");
     if (rc) return rc;
     // (the communicator's stream waited for the context's: that one is complete too -- release its staged transfers)
