@@ -263,3 +263,66 @@ def test_unknown_switch_is_reported():
                        text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
     assert "BGP_SYRK4 is not one this library reads" in r.stderr and "BGP_PANELS" not in r.stderr
+
+
+def test_allocation_failure_is_an_error_and_the_library_stays_usable(lib, O):
+    """A workspace the device cannot hold (4 000 matrices of 4096^2 doubles = 537 GB of 288) is a BgpError naming the
+    allocation -- no crash, no sticky HIP error: the next context works."""
+    rng = np.random.RandomState(0)
+    n, d = 4096, 3
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1))
+    H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.05 * rng.randn(8, d + 2)
+    with pytest.raises(lib.BgpError) as err:
+        lib.Context(X, y, 1e-10, max_batch=4000)  # (the workspace is allocated with the context)
+    assert "hipMalloc" in str(err.value) and "out of memory" in str(err.value)
+    X2, y2 = X[:300], y[:300]
+    ctx = lib.Context(X2, y2, 1e-10, max_batch=4)
+    np.testing.assert_allclose(ctx.lml(H[:4]), O.lml_batch(X2, y2, np.full(300, 1e-10), H[:4]), rtol=RTOL)
+    ctx.close()
+
+
+def test_two_contexts_from_two_threads_and_a_wait_on_another_thread(lib, O):
+    """The pinned transfer arena is process-wide and keyed by stream: contexts driven from different threads at the same
+    time, and a batch submitted on one thread and collected on another, give the right answers (every caller-buffer
+    transfer -- chunked LML calls beyond max_batch, predict -- goes through the arena)."""
+    import threading
+
+    rng = np.random.RandomState(1)
+    jobs = []
+    for k, (n, d) in enumerate(((700, 3), (520, 5))):
+        X = rng.uniform(size=(n, d))
+        y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+        H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.1 * rng.randn(20, d + 2)
+        jobs.append((X, y, H, O.lml_batch(X, y, np.full(n, 1e-10), H)))
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            X, y, H, _ref = jobs[k]
+            ctx = lib.Context(X, y, 1e-10, max_batch=8)  # 20 proposals in chunks of 8: the arena path
+            vals = [ctx.lml(H) for _ in range(15)]
+            ctx.posterior(H[:1])
+            mean, var = ctx.predict(H[:1], X[:64])
+            out[k] = (vals, mean, var)
+            ctx.close()
+        except Exception as exc:  # pragma: no cover
+            errs.append(exc)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for k in (0, 1):
+        for v in out[k][0]:
+            np.testing.assert_allclose(v, jobs[k][3], rtol=RTOL)
+    # submit here, wait there
+    X, y, H, ref = jobs[0]
+    ctx = lib.Context(X, y, 1e-10, max_batch=32)
+    got = {}
+    assert ctx.lml_submit(H)
+    t = threading.Thread(target=lambda: got.setdefault("v", ctx.lml_wait()))
+    t.start()
+    t.join()
+    np.testing.assert_allclose(got["v"], ref, rtol=RTOL)
+    ctx.close()
