@@ -121,7 +121,7 @@ extern "C" int bgp_debug_pivot_root(int device, int n, const double* x, double* 
 // the batch on the multi-launch path.  Arithmetic, operand order and summation order are those of the multi-launch path:
 // the log-likelihoods are bit-identical (tests/test_gpu_persist.py).
 // ------------------------------------------------------------------------------------------
-int bgp_ps_total_tasks(int B, int nblk);
+int bgp_ps_total_tasks(int B, int nblk, int np);
 void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg);
 
 // BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
@@ -192,7 +192,16 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.B = B;
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
-  a.total = bgp_ps_total_tasks(B, nblk);
+  {
+    // P(I) -- the pre-update of block (I, I-1) that the chain waits for -- in 1, 2 or 4 column slices with a workgroup each
+    // (BGP_PS_PSPLIT; default 1, chain pairs 2: their cycle runs THROUGH this task)
+    static int psp = -1;
+    if (psp < 0) {
+      const char* e = getenv("BGP_PS_PSPLIT");
+      psp = (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) ? atoi(e) : 0;
+    }
+    a.psplit = psp;  // (0: decided below, once pair mode is known)
+  }
   {
     // chain pairs (bgp_pf.h): two workgroups per matrix alternate over the block columns, the idle one preparing the next
     // diagonal block UNDER the other's factorisation; needs 2 * Bpad CUs and at least as many (and 32) left for the tile role.
@@ -205,6 +214,8 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     a.Bpad = 8 * ((B + 7) / 8);
     a.pair = (want == 1 && nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B)) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
+    if (a.psplit == 0) a.psplit = a.pair ? 2 : 1;
+    a.total = bgp_ps_total_tasks(B, nblk, a.psplit);
     {
       static int ns = -1;
       if (ns < 0) {
@@ -225,7 +236,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       const char* e = getenv("BGP_PS_NCRIT");
       ncf = e ? atoi(e) : -1;
     }
-    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min(3 * B, tile_wgs / 2) : 0);
+    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 2) * B, tile_wgs / 2) : 0);
     if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
   }
   a.spin_limit = limit;

@@ -277,6 +277,7 @@ struct PsArgs {
   int pair;           // 1: TWO chain workgroups per matrix that alternate over the block columns (bgp_pf.h, ps_chain_role)
   int Bpad;           // pair mode: chain workgroup p of matrix b is block p * Bpad + b (Bpad = B rounded up to 8: same XCD)
   int nchain;         // chain workgroups at the head of the grid (B, or 2 * Bpad)
+  int psplit;         // column slices a pre-update task P(I) is dealt out in (1, 2 or 4): subrdy[I] counts to psplit
   int ncrit_stream;   // pair mode: panel solves S(I, J) with I <= J + ncrit_stream follow pf_block(J) row block by row block
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task

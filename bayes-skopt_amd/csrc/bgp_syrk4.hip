@@ -526,9 +526,11 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
 // ascending, A-negate): bit-identical factors.
 // ------------------------------------------------------------------------------------------
-static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk) { return nblk > 2 ? 3 * (nblk - 2) : 0; }
+// critical tasks per block column and matrix: S(J+2, J), the np parts of P(J+2) (np = PsArgs::psplit column slices of the block),
+// Dg(J+2)
+static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) { return nblk > 2 ? (np + 2) * (nblk - 2) : 0; }
 static __host__ __device__ __forceinline__ int ps_bulk_per_matrix(int nblk) { return nblk > 3 ? (nblk - 3) * (nblk - 2) / 2 : 0; }
-static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk) { return ps_crit_per_matrix(nblk) + ps_bulk_per_matrix(nblk); }
+static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk, int np) { return ps_crit_per_matrix(nblk, np) + ps_bulk_per_matrix(nblk); }
 
 // vmcnt(N) with a compile-time N
 template <int N>
@@ -641,6 +643,55 @@ static __device__ __forceinline__ void s8_ring_run_diag(const double* XA, const 
 }
 
 #define PS_NST 4
+// Left-looking update of a 128 x (16 NC x 2) slice of a block with the panels 0 .. npan-1 as far as they are final (it waits on
+// xready only when it has caught up with the factorisation): C -= X_I,p X_J,p^T, waves as 4 x 2, each 32 rows x 16 NC columns.
+// XB = the rows of block row Jc that belong to the slice's columns (the ring stages 128 rows from there: the rows behind a
+// narrower slice are staged and not read).  Returns 0, or -1 when a wait was abandoned.
+template <int NC>
+static __device__ __forceinline__ int ps_ll_update(const PsArgs& a, const double* XA, const double* XB, double* C, int npan,
+                                                   unsigned* xrI, unsigned* xrJ, unsigned* err, int* sh_q, unsigned lds0,
+                                                   const unsigned (&voffX)[2], int ld, int w, int lane, int tid, int I,
+                                                   unsigned long long* tr) {
+  constexpr unsigned AOPB = 128 * S4_ROWB;
+  const int wr = w >> 1, wc = w & 1;
+  unsigned pa[4], pb[4];
+  d4 acc[2][NC];
+  s4_frag_addr(pa, lds0, wr * 32, lane);
+  s4_frag_addr(pb, lds0 + AOPB, wc * 16 * NC, lane);
+  gk_load_c<2, NC, -64>(C, (size_t)ld, acc, wr * 32, wc * 16 * NC, lane);
+  int q = 0;
+  while (q < npan) {
+    if (tid == 0) {
+      int qq = q;
+      bool ok = true;
+#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
+      while (qq < npan && PS_READY(qq)) qq++;
+      if (qq == q) {  // caught up with the factorisation: wait for the next panel
+        ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
+        qq = q + 1;
+        while (ok && qq < npan && PS_READY(qq)) qq++;
+      }
+#undef PS_READY
+      ps_acquire();
+      *sh_q = ok ? qq : -1;
+      if (tr && q == 0) tr[1] = wall_clock64();
+      if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
+    }
+    __syncthreads();
+    const int qq = *sh_q;
+    if (qq < 0) return -1;  // abandoned
+    int nch_run = (qq - q) * 8;
+#ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
+    if ((BGP_FAULT_INJECT & 2) && I >= 12 && qq == npan) nch_run -= 1;
+#endif
+    s8_ring_run<PS_NST, 2, NC, 1>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, nch_run, lds0, pa, pb, acc, w, 0);
+    __syncthreads();  // (the ring and sh_q are free again)
+    q = qq;
+  }
+  gk_store_c<2, NC, -64>(C, (size_t)ld, acc, wr * 32, wc * 16 * NC, lane);
+  return 0;
+}
+
 // wg = this workgroup's index among the tile workgroups of the launch
 template <int PAIR>
 static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
@@ -649,7 +700,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   __shared__ int sh_t, sh_q;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)pf_lds_raw();
   const int tid = threadIdx.x, lane0 = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wr = w >> 1, wc = w & 1;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nblk = a.nblk, B = a.B, ld = a.ld;
   unsigned* const flags = a.flags;
   unsigned* const err = flags + PS_ERROR;
@@ -666,7 +717,8 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   for (;;) {
     const int x = (xcc + list) & 7;
     const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
-    const int per_matrix = !pools ? ps_tasks_per_matrix(nblk) : (pool == 0 ? ps_crit_per_matrix(nblk) : ps_bulk_per_matrix(nblk));
+    const int NP = a.psplit, NK = NP + 2;  // parts of a P task; critical tasks per column and matrix
+    const int per_matrix = !pools ? ps_tasks_per_matrix(nblk, NP) : (pool == 0 ? ps_crit_per_matrix(nblk, NP) : ps_bulk_per_matrix(nblk));
     if (tid == 0) {
       int tt = -1;
       if (Bx > 0 && per_matrix > 0) {
@@ -687,16 +739,16 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       continue;
     }
     // (trace slot: unique per (pool, list, ticket) while B % 8 == 0)
-    const int tglobal = (pools && pool == 1 ? B * ps_crit_per_matrix(nblk) : 0) + (int)(((long long)t * 8 + x) % ((long long)B * per_matrix));
-    // ---- ticket -> (column J, matrix b, kind, block row I).  kind 0: S(I, J); 1: P(I); 2: Dg(I)
-    int J = 0, kind = 0, I;
-    if (pools && pool == 0) {  // three critical tasks per column and matrix
-      J = t / (3 * Bx);
-      t -= J * 3 * Bx;
-      kind = t / Bx;
+    const int tglobal = (pools && pool == 1 ? B * ps_crit_per_matrix(nblk, NP) : 0) + (int)(((long long)t * 8 + x) % ((long long)B * per_matrix));
+    // ---- ticket -> (column J, matrix b, kind, block row I).  kind 0: S(I, J); 1: P(I), part `part` of NP; 2: Dg(I)
+    int J = 0, kq = 0, I;
+    if (pools && pool == 0) {  // NK critical tasks per column and matrix
+      J = t / (NK * Bx);
+      t -= J * NK * Bx;
+      kq = t / Bx;
       I = J + 2;
     } else {
-      const int head = pools ? 0 : 3;  // (one list: the critical tasks lead their column)
+      const int head = pools ? 0 : NK;  // (one list: the critical tasks lead their column)
       for (;;) {
         const int c = (head + nblk - J - 3) * Bx;
         if (t < c) break;
@@ -704,9 +756,10 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
         J++;
       }
       const int q0 = t / Bx;
-      kind = q0 < head ? q0 : 0;
+      kq = q0 < head ? q0 : 0;
       I = q0 < head ? J + 2 : J + 3 + (q0 - head);
     }
+    const int kind = kq == 0 ? 0 : (kq <= NP ? 1 : 2), part = kq - 1;
     const int b = x + 8 * (t % Bx);
     const bool presub = kind == 1, diag = kind == 2;
     const int Jc = J + kind;               // block column of the task's block
@@ -789,44 +842,19 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
         }
       }
     } else if (npan > 0 && !dead) {
-      // ---- 1. left-looking update with the panels 0 .. npan-1: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles)
+      // ---- 1. left-looking update with the panels 0 .. npan-1: waves as 4 x 2, each 32 rows x 64 columns (2 x 4 MFMA tiles);
+      // a P task split NP ways owns 128 / NP columns of its block (each wave 32 rows x 32 or 16 columns)
       const double* const XA = M + (size_t)I * 128 * ld;
-      const double* const XB = M + (size_t)Jc * 128 * ld;
-      unsigned pa[4], pb[4];
-      d4 acc[2][4];
-      s4_frag_addr(pa, lds0, wr * 32, lane);
-      s4_frag_addr(pb, lds0 + AOPB, wc * 64, lane);
-      gk_load_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
-      int q = 0;
-      while (q < npan) {
-        if (tid == 0) {
-          int qq = q;
-          bool ok = true;
-#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
-          while (qq < npan && PS_READY(qq)) qq++;
-          if (qq == q) {  // caught up with the factorisation: wait for the next panel
-            ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
-            qq = q + 1;
-            while (ok && qq < npan && PS_READY(qq)) qq++;
-          }
-#undef PS_READY
-          ps_acquire();
-          sh_q = ok ? qq : -1;
-          if (tr && q == 0) tr[1] = wall_clock64();
-          if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
-        }
-        __syncthreads();
-        const int qq = sh_q;
-        if (qq < 0) return;  // abandoned
-        int nch_run = (qq - q) * 8;
-#ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
-        if ((BGP_FAULT_INJECT & 2) && I >= 12 && qq == npan) nch_run -= 1;
-#endif
-        s8_ring_run<PS_NST, 2, 4, 1>(XA + (size_t)q * 128, voffX, XB + (size_t)q * 128, voffX, nch_run, lds0, pa, pb, acc, w, 0);
-        __syncthreads();  // (the ring and sh_q are free again)
-        q = qq;
-      }
-      gk_store_c<2, 4, -64>(C, (size_t)ld, acc, wr * 32, wc * 64, lane);
+      int rc;
+      if (presub && NP == 2)
+        rc = ps_ll_update<2>(a, XA, M + ((size_t)Jc * 128 + 64 * part) * ld, C + 64 * part, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w,
+                             lane, tid, I, tr);
+      else if (presub && NP == 4)
+        rc = ps_ll_update<1>(a, XA, M + ((size_t)Jc * 128 + 32 * part) * ld, C + 32 * part, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w,
+                             lane, tid, I, tr);
+      else
+        rc = ps_ll_update<4>(a, XA, M + (size_t)Jc * 128 * ld, C, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane, tid, I, tr);
+      if (rc < 0) return;  // abandoned
     }
     if (tr) tr[3] = wall_clock64();
     if (diag || presub) {
@@ -927,7 +955,7 @@ void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg) {
   else
     hipLaunchKernelGGL(ps_kernel<0>, dim3(nwg), dim3(512), 0, st, a);
 }
-int bgp_ps_total_tasks(int B, int nblk) { return B * ps_tasks_per_matrix(nblk); }
+int bgp_ps_total_tasks(int B, int nblk, int np) { return B * ps_tasks_per_matrix(nblk, np); }
 
 // ------------------------------------------------------------------------------------------
 // General NT product on the same ring for the posterior consumers (sample_y, predictive covariances):
