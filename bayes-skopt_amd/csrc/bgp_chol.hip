@@ -194,7 +194,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.mstride = (size_t)ld * ld;
   {
     // P(I) -- the pre-update of block (I, I-1) that the chain waits for -- in 1, 2 or 4 column slices with a workgroup each
-    // (BGP_PS_PSPLIT; default 1, chain pairs 2: their cycle runs THROUGH this task)
+    // (BGP_PS_PSPLIT; default 1, chain pairs 4: their cycle runs THROUGH this task)
     static int psp = -1;
     if (psp < 0) {
       const char* e = getenv("BGP_PS_PSPLIT");
@@ -209,12 +209,17 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     static int want = -2;
     if (want == -2) {
       const char* e = getenv("BGP_PS_PAIR");
-      want = e ? (atoi(e) != 0 ? 1 : 0) : 0;
+      want = e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }
     a.Bpad = 8 * ((B + 7) / 8);
-    a.pair = (want == 1 && nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B)) ? 1 : 0;
+    // automatic: where the chain is the bound and the pairs measured faster (tools/persist_probe.py, MI355X, P in 4 slices):
+    // one matrix of 12 .. 48 block columns (n = 1536: 0.656 -> 0.609 ms, 2048: 0.859 -> 0.805, 3072: 1.331 -> 1.248,
+    // 4096: 1.751 -> 1.640), two of up to 24 (2048: 0.869 -> 0.810, 3072: 1.389 -> 1.358); not 4096 x 2 (2.186 / 2.185), not from
+    // four matrices on (the tile side is the bound and loses the pairs' CUs), not the 10 112^2 covariance (9.8 -> 10.6 ms)
+    const bool fits = nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B);
+    a.pair = (fits && (want == 1 || (want == -1 && nblk >= 12 && B * nblk <= 48))) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
-    if (a.psplit == 0) a.psplit = a.pair ? 2 : 1;
+    if (a.psplit == 0) a.psplit = a.pair ? 4 : 1;
     a.total = bgp_ps_total_tasks(B, nblk, a.psplit);
     {
       static int ns = -1;

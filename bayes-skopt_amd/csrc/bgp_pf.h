@@ -757,13 +757,16 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
 #define PH_XLD 18   // leading dimension of a staged 128 x 16 column block of X
 static_assert(PH_WOFF(8) + 2 * 128 * PH_XLD <= 128 * PF_LD, "the helper's staging buffers live in the (free) tile region");
 
-// `have` = row blocks of W_JJ known to be in memory (and acquired), `staged` = row blocks already in LDS.  Everything that is
-// out is staged in ONE burst (one L2 round trip for many row blocks: a helper that starts late finds most of W waiting).
+// `have` = row blocks of W_JJ known to be in memory (and acquired), `staged` = row blocks already in LDS, `vin` / `pin` = row block
+// SB + 1 in registers (loaded during the previous step's update), stored to LDS in front of this step's ONE barrier.  Per
+// step: solve (row block SB from LDS) -> X out and into LDS, row block SB + 1 into LDS -> barrier -> loads of row block SB + 2
+// issued -> rank-16 update.  A row block that is not there yet is waited for, acquired and staged in the open.
 template <int SB, int NT>
 static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int J, int* ok_lds, int have, int staged,
                                                     const double (&af)[32], double* __restrict__ Xg, int ld, d4 (&dt)[5],
                                                     const int (&tio)[5], const int (&tjo)[5], double* __restrict__ Wl,
-                                                    double* __restrict__ Xl, int tid, int w, int lane, unsigned long long* tr) {
+                                                    double* __restrict__ Xl, int tid, int w, int lane, unsigned long long* tr,
+                                                    const double (&vin)[4], bool pin, int* peek_lds) {
   if constexpr (SB < 8) {
     const int lr = lane & 15, lk = lane >> 4;
     unsigned* const flags = a.flags;
@@ -787,6 +790,21 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       if (have < 0) return have;
     }
     if (SB == 7 && tr && tid == 0) tr[J * 8 + 7] = wall_clock64();  // the last row block and z are out
+    // Wave 7 (four tiles instead of five in the update) LOOKS for row blocks that have come out since, without waiting, and
+    // acquires them: the other waves learn the count behind this step's barrier and issue the loads of the block after next
+    // under the update -- a helper that has caught up with pf_block otherwise pays a blocking poll, an acquire and an exposed
+    // load per step (6-7 us against the 3.1 us of a pf_block step: it fell 14 us behind over the last five row blocks).
+    if (SB < 6 && w == 7 && lane == 0) {
+      int cnt = have;
+      if (have < 7) {
+        const unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
+        cnt = (int)ps_ld(wrow + J);
+        if (cnt > 7) cnt = 7;
+        if (cnt > have) ps_acquire();
+        else cnt = have;
+      }
+      *peek_lds = cnt;
+    }
     // (the step's global addresses are formed HERE, from an opaque copy of the step number: formed at the top of the helper and
     // kept in scalar registers for all eight steps they made the kernel spill scalars to scratch)
     int sbo = SB;
@@ -803,16 +821,8 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       for (int i = 0; i < (16 * (SB + 1) + 31) / 32; i++)
         if (sc0 + 32 * i < 16 * (SB + 1)) dst[sc0 + 32 * i] = v[i];
       staged = SB + 1;
+      pin = false;  // (whatever was on its way belongs to a row block that is staged now)
       __syncthreads();
-    }
-    // the NEXT row block, if it is out already: its loads fly under this step's MFMAs
-    constexpr int NPRE = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
-    double vpre[NPRE];
-    const bool pre = SB < 7 && have > SB + 1 && staged == SB + 1;
-    if (pre) {
-      const double* const src = Wg + (size_t)(16 * (SB + 1) + sr) * 128;
-#pragma unroll
-      for (int i = 0; i < NPRE; i++) vpre[i] = (sc0 + 32 * i < 16 * (SB + 2)) ? src[sc0 + 32 * i] : 0.0;
     }
     // column block SB of X = A W^T for this wave's 16 rows: k ascending, as pf_chain_next
     // (operand reads two 16-wide chunks deep, fenced: left to itself the compiler hoists every LDS read of the step above the
@@ -842,10 +852,29 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       Xg[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr)] = xs[r];
       if constexpr (NT > 0) Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
     }
+    // the next row block, if it came in under the previous step: into LDS in front of the step's barrier
+    constexpr int NNX = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
+    if (SB < 7 && pin && staged == SB + 1) {
+      double* const dst = Wl + PH_WOFF(SB + 1) + sr * PH_WLDQ(SB + 1);
+#pragma unroll
+      for (int i = 0; i < NNX; i++)
+        if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vin[i];
+      staged = SB + 2;
+    }
+    __syncthreads();
+    if (SB < 6) have = *peek_lds;  // (>= the old value; a failed matrix shows at the next blocking wait)
+    // the row block after that, if it is out: its loads fly under the update and the next solve
+    double vout[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool pout = SB < 6 && have > SB + 2 && staged == SB + 2;
+    if (pout) {
+      constexpr int NN2 = (SB < 6) ? (16 * (SB + 3) + 31) / 32 : 1;
+      const double* const src = Wg + (size_t)(16 * (SB + 2) + sr) * 128;
+#pragma unroll
+      for (int i = 0; i < NN2; i++) vout[i] = (sc0 + 32 * i < 16 * (SB + 3)) ? src[sc0 + 32 * i] : 0.0;
+    }
     // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15   (NT == 0: the streamed
     // panel solve of a tile task -- no diagonal block)
     if constexpr (NT > 0) {
-      __syncthreads();
       double ua[2][NT], ub[2][NT];
       const double* const xl = Xs + lr * PH_XLD + lk;  // (tio / tjo: wave-uniform row offsets of the tile's two row blocks)
 #pragma unroll
@@ -867,15 +896,8 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (pre) {
-      double* const dst = Wl + PH_WOFF(SB + 1) + sr * PH_WLDQ(SB + 1);
-#pragma unroll
-      for (int i = 0; i < NPRE; i++)
-        if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vpre[i];
-      staged = SB + 2;
-      __syncthreads();
-    }
-    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr);
+    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vout, pout,
+                                     peek_lds);
   } else {
     return have;
   }
@@ -883,7 +905,7 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
 
 // Returns 0 (block (J+1, J+1) and its right-hand side are in this workgroup's LDS), -1 when a wait was abandoned, -2 when the
 // matrix has failed.
-static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr) {
+static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int J, int* ok_lds, int* peek_lds, unsigned long long* tr) {
   const PfLds lds = pf_lds();
   double* const s = lds.s;
   double* const ylds = lds.ylds;
@@ -939,8 +961,9 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
       dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
     }
   }
-  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr)
-                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr);
+  const double vz[4] = {0.0, 0.0, 0.0, 0.0};
+  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vz, false, peek_lds)
+                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vz, false, peek_lds);
   if (have < 0) return have;
   if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
   // ---- z_J is out (the last wait was for wready[J]): the right-hand side, as pf_chain_next -- X read back from this wave's
@@ -995,7 +1018,7 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
 // rows as A fragments and follows pf_block(J) row block by row block; X_{J+2,J} is out a few us after W_JJ's last row block
 // instead of a whole 12 us solve later (the head of the tile side's critical hand-over).  Right-hand side and flag as the
 // ring solve of ps_tile_role.  Returns 0, -1 (abandoned) or -2 (the matrix has failed: the caller only passes its flag on).
-static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J, int I, int* ok_lds) {
+static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J, int I, int* ok_lds, int* peek_lds) {
   double* const Wl = reinterpret_cast<double*>(pf_lds_raw());
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));
@@ -1012,7 +1035,8 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
   }
   d4 dt[5];
   const int tz[5] = {0, 0, 0, 0, 0};
-  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr);
+  const double vz[4] = {0.0, 0.0, 0.0, 0.0};
+  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, vz, false, peek_lds);
   if (have < 0) return have;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
@@ -1049,14 +1073,14 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
 template <int PAIR>
 static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int p) {
   const int tid = threadIdx.x;
-  __shared__ int ps_ok;
+  __shared__ int ps_ok, ps_peek;
   unsigned* const flags = a.flags;
   unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
   unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
   unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
   for (int J = 0; J < a.nblk; J++) {
     if (PAIR && (J & 1) != p) {  // the partner factorises column J: prepare block (J+1, J+1) under it
-      if (J + 1 < a.nblk && pf_pair_helper(a, b, J, &ps_ok, tr) < 0) return;
+      if (J + 1 < a.nblk && pf_pair_helper(a, b, J, &ps_ok, &ps_peek, tr) < 0) return;
       continue;
     }
     if (tr && tid == 0) tr[J * 8 + 0] = wall_clock64();

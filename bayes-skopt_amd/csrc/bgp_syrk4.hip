@@ -868,7 +868,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
     if (PAIR && I <= J + a.ncrit_stream) {  // chain pairs: the critical solve of the column follows pf_block(J) row block by row block
       __syncthreads();  // every wave's part of the block is in memory (the solve re-reads it as A fragments)
-      const int r = dead ? -2 : pf_stream_S(a, b, J, I, &sh_q);
+      const int r = dead ? -2 : pf_stream_S(a, b, J, I, &sh_q, &sh_t);
       if (r == -1) return;
       if (tr) tr[5] = wall_clock64();
       ps_publish_barrier();
