@@ -757,16 +757,22 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
 #define PH_XLD 18   // leading dimension of a staged 128 x 16 column block of X
 static_assert(PH_WOFF(8) + 2 * 128 * PH_XLD <= 128 * PF_LD, "the helper's staging buffers live in the (free) tile region");
 
-// `have` = row blocks of W_JJ known to be in memory (and acquired), `staged` = row blocks already in LDS, `vin` / `pin` = row block
-// SB + 1 in registers (loaded during the previous step's update), stored to LDS in front of this step's ONE barrier.  Per
-// step: solve (row block SB from LDS) -> X out and into LDS, row block SB + 1 into LDS -> barrier -> loads of row block SB + 2
-// issued -> rank-16 update.  A row block that is not there yet is waited for, acquired and staged in the open.
+// barrier for LDS traffic only: global loads / stores of the wave stay in flight across it
+static __device__ __forceinline__ void pf_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// `have` = row blocks of W_JJ known to be in memory (and acquired), `staged` = row blocks already in LDS.  Per step: wave 7 looks
+// (without waiting) for row blocks published since; solve (row block SB from LDS) -> X out and into LDS -> barrier -> loads of row
+// block SB + 1 issued if it is out -> rank-16 update -> row block SB + 1 into LDS -> barrier.  A row block that is not there when
+// its step begins is waited for, acquired and staged in the open.
 template <int SB, int NT>
 static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int J, int* ok_lds, int have, int staged,
                                                     const double (&af)[32], double* __restrict__ Xg, int ld, d4 (&dt)[5],
                                                     const int (&tio)[5], const int (&tjo)[5], double* __restrict__ Wl,
                                                     double* __restrict__ Xl, int tid, int w, int lane, unsigned long long* tr,
-                                                    const double (&vin)[4], bool pin, int* peek_lds) {
+                                                    int* peek_lds) {
   if constexpr (SB < 8) {
     const int lr = lane & 15, lk = lane >> 4;
     unsigned* const flags = a.flags;
@@ -794,12 +800,12 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
     // acquires them: the other waves learn the count behind this step's barrier and issue the loads of the block after next
     // under the update -- a helper that has caught up with pf_block otherwise pays a blocking poll, an acquire and an exposed
     // load per step (6-7 us against the 3.1 us of a pf_block step: it fell 14 us behind over the last five row blocks).
-    if (SB < 6 && w == 7 && lane == 0) {
+    if (SB < 7 && w == 7 && lane == 0) {
       int cnt = have;
-      if (have < 7) {
+      if (have < 8) {
         const unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
         cnt = (int)ps_ld(wrow + J);
-        if (cnt > 7) cnt = 7;
+        if (cnt >= 7) cnt = (ps_ld(flags + PS_HDR + (size_t)b * a.nblk + J) >= 1u) ? 8 : 7;  // (the eighth goes out with wready)
         if (cnt > have) ps_acquire();
         else cnt = have;
       }
@@ -821,7 +827,6 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       for (int i = 0; i < (16 * (SB + 1) + 31) / 32; i++)
         if (sc0 + 32 * i < 16 * (SB + 1)) dst[sc0 + 32 * i] = v[i];
       staged = SB + 1;
-      pin = false;  // (whatever was on its way belongs to a row block that is staged now)
       __syncthreads();
     }
     // column block SB of X = A W^T for this wave's 16 rows: k ascending, as pf_chain_next
@@ -852,25 +857,16 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       Xg[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr)] = xs[r];
       if constexpr (NT > 0) Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
     }
-    // the next row block, if it came in under the previous step: into LDS in front of the step's barrier
+    pf_lds_barrier();  // (LDS only: the A fragments' and D tiles' loads and X's stores stay in flight)
+    if (SB < 7) have = *peek_lds;  // (>= the old value; a failed matrix is caught behind the steps)
+    // the NEXT row block, if it is out: its loads fly under the update
     constexpr int NNX = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
-    if (SB < 7 && pin && staged == SB + 1) {
-      double* const dst = Wl + PH_WOFF(SB + 1) + sr * PH_WLDQ(SB + 1);
+    double vnx[NNX];
+    const bool pre = SB < 7 && have > SB + 1 && staged == SB + 1;
+    if (pre) {
+      const double* const src = Wg + (size_t)(16 * (SB + 1) + sr) * 128;
 #pragma unroll
-      for (int i = 0; i < NNX; i++)
-        if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vin[i];
-      staged = SB + 2;
-    }
-    __syncthreads();
-    if (SB < 6) have = *peek_lds;  // (>= the old value; a failed matrix shows at the next blocking wait)
-    // the row block after that, if it is out: its loads fly under the update and the next solve
-    double vout[4] = {0.0, 0.0, 0.0, 0.0};
-    const bool pout = SB < 6 && have > SB + 2 && staged == SB + 2;
-    if (pout) {
-      constexpr int NN2 = (SB < 6) ? (16 * (SB + 3) + 31) / 32 : 1;
-      const double* const src = Wg + (size_t)(16 * (SB + 2) + sr) * 128;
-#pragma unroll
-      for (int i = 0; i < NN2; i++) vout[i] = (sc0 + 32 * i < 16 * (SB + 3)) ? src[sc0 + 32 * i] : 0.0;
+      for (int i = 0; i < NNX; i++) vnx[i] = (sc0 + 32 * i < 16 * (SB + 2)) ? src[sc0 + 32 * i] : 0.0;
     }
     // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15   (NT == 0: the streamed
     // panel solve of a tile task -- no diagonal block)
@@ -896,8 +892,15 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vout, pout,
-                                     peek_lds);
+    if (pre) {
+      double* const dst = Wl + PH_WOFF(SB + 1) + sr * PH_WLDQ(SB + 1);
+#pragma unroll
+      for (int i = 0; i < NNX; i++)
+        if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vnx[i];
+      staged = SB + 2;
+      pf_lds_barrier();
+    }
+    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds);
   } else {
     return have;
   }
@@ -922,26 +925,32 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
   double* const Mb = a.K + (size_t)b * a.mstride;
   double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
   const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
-  if (J > 0) {  // the tile workers' pre-updates of the two blocks (panels 0 .. J-1)
+  // ONE wait and ONE acquire for everything the helper starts from: the tile workers' pre-updates of its two blocks (panels
+  // 0 .. J-1) and the row blocks of W_JJ that are out already (it used to poll and acquire again inside step 0, behind the A
+  // fragments' loads: 11 us from "ready" to the end of step 0 by the in-kernel stamps)
+  int have0 = 0;
+  {
     if (tid == 0) {
-      const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
-      const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-      const bool ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      bool ok = true;
+      if (J > 0) {
+        const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
+        const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
+        ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      }
+      const unsigned* const wrow = flags + PS_HDR + (size_t)a.B * nblk * (3 + nblk) + (size_t)b * nblk;
+      int cnt = (int)ps_ld(wrow + J);
+      if (cnt >= 7) cnt = (ps_ld(flags + PS_HDR + (size_t)b * nblk + J) >= 1u) ? 8 : 7;
       ps_acquire();
-      *ok_lds = ok ? 1 : 0;
+      if (__hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) cnt = -2;  // the matrix has failed
+      *ok_lds = ok ? cnt : -1;
     }
     __syncthreads();
-    const int ok = *ok_lds;
+    have0 = *ok_lds;
     __syncthreads();
-    if (!ok) return -1;
+    if (have0 < 0) return have0;
   }
   if (tr && tid == 0) tr[J * 8 + 2] = wall_clock64();
-  double af[32];
-  {
-    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
-#pragma unroll
-    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
-  }
+  // (the D tiles first: the first rank-16 update needs all of them, the solves need the A fragments four at a time)
   d4 dt[5];
   int tio[5], tjo[5], tco[5];  // wave-uniform: row offsets of the tile's row blocks in a staged X column block; tile origin in the LDS tile
 #pragma unroll
@@ -961,11 +970,34 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
       dt[u] = (d4){0.0, 0.0, 0.0, 0.0};
     }
   }
-  const double vz[4] = {0.0, 0.0, 0.0, 0.0};
-  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vz, false, peek_lds)
-                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, vz, false, peek_lds);
+  // row blocks 0 and 1 of W (if out) first, then the A fragments: all in flight together; the staging stores only wait for their
+  // own loads (loads return in order) and the barrier behind them leaves the A fragments in flight
+  double af[32];
+  int staged0 = 0;
+  {
+    const double* const Wg = a.W + ((size_t)b * nblk + J) * (128 * 128);
+    const int sr = tid >> 5, sc0 = tid & 31;
+    double w0 = 0.0, w1 = 0.0;
+    if (have0 >= 1 && sc0 < 16) w0 = Wg[(size_t)sr * 128 + sc0];
+    if (have0 >= 2) w1 = Wg[(size_t)(16 + sr) * 128 + sc0];
+    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
+#pragma unroll
+    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+    if (have0 >= 1 && sc0 < 16) Wl[PH_WOFF(0) + sr * PH_WLDQ(0) + sc0] = w0;
+    if (have0 >= 2) Wl[PH_WOFF(1) + sr * PH_WLDQ(1) + sc0] = w1;
+    staged0 = have0 >= 2 ? 2 : (have0 >= 1 ? 1 : 0);
+    pf_lds_barrier();
+  }
+  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds)
+                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds);
   if (have < 0) return have;
   if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
+  // (a factorisation that failed while the helper followed it releases every flag: look before the next block is taken over)
+  if (tid == 0) *ok_lds = __hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? -2 : 0;
+  __syncthreads();
+  const int gone = *ok_lds;
+  __syncthreads();
+  if (gone < 0) return gone;
   // ---- z_J is out (the last wait was for wready[J]): the right-hand side, as pf_chain_next -- X read back from this wave's
   // own stores (drained first)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1035,8 +1067,7 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
   }
   d4 dt[5];
   const int tz[5] = {0, 0, 0, 0, 0};
-  const double vz[4] = {0.0, 0.0, 0.0, 0.0};
-  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, vz, false, peek_lds);
+  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, peek_lds);
   if (have < 0) return have;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   {
