@@ -586,6 +586,45 @@ static __device__ __forceinline__ void pf_diag_update(d4 (&dt)[5], const double*
   }
 }
 
+// A-operand fragments of 16 rows x 128 columns for the f64 16x16x4 MFMA: lane (lr, lk) wants A[row lr][4 t + lk], t = 0 .. 31 -- as
+// 8-byte loads that is 32 B per row per instruction.  Loaded instead as 32 contiguous bytes per lane (two 16-byte loads, a whole
+// 128-B line per row per pair of instructions) and transposed 4 x 4 across the four 16-lane rows with the gfx950 lane-swap
+// instructions (v_permlane32_swap: rows 2, 3 of one register <-> rows 0, 1 of another; v_permlane16_swap: odd rows <-> even rows):
+// the same values in the same registers, half the memory instructions and full lines (handed-off blocks arrive at 60-120 GB/s per
+// workgroup, MI355X_MICROARCH.md "handoff-payload": the 128 KB block is most of a chain step's entry).
+static __device__ __forceinline__ void pf_swap_rows32(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+static __device__ __forceinline__ void pf_swap_rows16(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// rowp = &A[this lane's row][0] (32-byte aligned), lk = lane >> 4
+static __device__ __forceinline__ void pf_load_afrag(const double* __restrict__ rowp, int lk, double (&af)[32]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v* const q = reinterpret_cast<const d2v*>(rowp + 4 * lk);
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const d2v u = q[8 * g], v = q[8 * g + 1];
+    af[4 * g] = u[0];
+    af[4 * g + 1] = u[1];
+    af[4 * g + 2] = v[0];
+    af[4 * g + 3] = v[1];
+  }
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    pf_swap_rows32(af[4 * g], af[4 * g + 2]);
+    pf_swap_rows32(af[4 * g + 1], af[4 * g + 3]);
+    pf_swap_rows16(af[4 * g], af[4 * g + 1]);
+    pf_swap_rows16(af[4 * g + 2], af[4 * g + 3]);
+  }
+}
+
 // The chain's own share of block column J (PsArgs::fat): the two blocks the next factorisation waits for never leave the
 // chain's workgroup.  W_JJ is still in LDS (transposed in the upper triangle of the tile, diagonal blocks in Minv), z_J in
 // zpart; the tile workers have applied the panels 0 .. J-1 to blocks (J+1, J) and (J+1, J+1) beforehand (subrdy / diagrdy).
@@ -629,9 +668,7 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   // ---- operands: A fragments (k = 4 t + lk of row 16 w + lr), this lane's rows of y, the D tiles of this wave
   double af[32];
   {
-    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
-#pragma unroll
-    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+    pf_load_afrag(Ab + (size_t)(16 * w + lr) * ld, lk, af);
   }
   double yv[4];
   {
@@ -980,9 +1017,7 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
     double w0 = 0.0, w1 = 0.0;
     if (have0 >= 1 && sc0 < 16) w0 = Wg[(size_t)sr * 128 + sc0];
     if (have0 >= 2) w1 = Wg[(size_t)(16 + sr) * 128 + sc0];
-    const double* const ap = Ab + (size_t)(16 * w + lr) * ld + lk;
-#pragma unroll
-    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+    pf_load_afrag(Ab + (size_t)(16 * w + lr) * ld, lk, af);
     if (have0 >= 1 && sc0 < 16) Wl[PH_WOFF(0) + sr * PH_WLDQ(0) + sc0] = w0;
     if (have0 >= 2) Wl[PH_WOFF(1) + sr * PH_WLDQ(1) + sc0] = w1;
     staged0 = have0 >= 2 ? 2 : (have0 >= 1 ? 1 : 0);
@@ -1061,9 +1096,7 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
   double* const Ab = a.K + (size_t)b * a.mstride + (size_t)I * 128 * ld + (size_t)J * 128;
   double af[32];
   {
-    const double* const ap = Ab + (unsigned)((16 * w + lr) * ld + lk);
-#pragma unroll
-    for (int t = 0; t < 32; t++) af[t] = ap[4 * t];
+    pf_load_afrag(Ab + (unsigned)((16 * w + lr) * ld), lk, af);
   }
   d4 dt[5];
   const int tz[5] = {0, 0, 0, 0, 0};

@@ -692,6 +692,87 @@ static __device__ __forceinline__ int ps_ll_update(const PsArgs& a, const double
   return 0;
 }
 
+// One QUADRANT (64 x 64) of a P block, the four-way split of the chain pairs' critical pre-update: 64 rows of X_I and 64 rows of
+// X_Jc per chunk -- half the bytes of a 128 x 32 column slice, which stages 128 + 128 rows and reads 160 of them -- on an
+// EIGHT-stage ring of 128-row images (the same 128 KB of LDS): seven chunks in flight instead of three.  The last panel's term is
+// pure latency (its 8 chunks, written a microsecond ago by two other workgroups, arrive at the hand-off rate of
+// MI355X_MICROARCH.md "handoff-payload"): 6.3 us -> see DESIGN.md section 10 with three 32 KB chunks in flight.  Waves as 4 x 2, each
+// 16 rows x 32 columns; wave w stages rows 16 w .. 16 w + 15 of the image (waves 0-3: X_I, 4-7: X_Jc): two instructions per
+// wave and chunk, "at most r younger chunks outstanding" = vmcnt(2 r).  Per element the k order of every other update path.
+static __device__ __forceinline__ void q8_wait_vm(int r) {
+  switch (r) {
+    case 0: s4_wait_vm<0>(); break;
+    case 1: s4_wait_vm<2>(); break;
+    case 2: s4_wait_vm<4>(); break;
+    case 3: s4_wait_vm<6>(); break;
+    case 4: s4_wait_vm<8>(); break;
+    case 5: s4_wait_vm<10>(); break;
+    default: s4_wait_vm<12>(); break;
+  }
+}
+static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const double* XA, const double* XB, double* C, int npan,
+                                                        unsigned* xrI, unsigned* xrJ, unsigned* err, int* sh_q, unsigned lds0,
+                                                        const unsigned (&voffX)[2], int ld, int w, int lane, int tid, int I,
+                                                        unsigned long long* tr) {
+  constexpr unsigned QST = 128 * S4_ROWB;  // one stage: 64 rows of each operand
+  constexpr int NST = 8;
+  static_assert(NST * QST <= PF_LDS_BYTES, "the quadrant ring lives in the chain role's LDS array");
+  const int wr = w >> 1, wc = w & 1;
+  unsigned pa[4], pb[4];
+  d4 acc[1][2];
+  s4_frag_addr(pa, lds0, wr * 16, lane);
+  s4_frag_addr(pb, lds0 + 64 * S4_ROWB, wc * 32, lane);
+  gk_load_c<1, 2, -64>(C, (size_t)ld, acc, wr * 16, wc * 32, lane);
+  // this wave's source: image row R = 16 w + ... is row R of X_I's 64 (waves 0-3) or row R - 64 of X_Jc's 64 (waves 4-7)
+  const double* const Xsrc = w < 4 ? XA : XB - (size_t)64 * ld;
+  int q = 0;
+  while (q < npan) {
+    if (tid == 0) {
+      int qq = q;
+      bool ok = true;
+#define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
+      while (qq < npan && PS_READY(qq)) qq++;
+      if (qq == q) {  // caught up with the factorisation: wait for the next panel
+        ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
+        qq = q + 1;
+        while (ok && qq < npan && PS_READY(qq)) qq++;
+      }
+#undef PS_READY
+      ps_acquire();
+      *sh_q = ok ? qq : -1;
+      if (tr && q == 0) tr[1] = wall_clock64();
+      if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
+    }
+    __syncthreads();
+    const int qq = *sh_q;
+    if (qq < 0) return -1;  // abandoned
+    int nch = (qq - q) * 8;
+#ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
+    if ((BGP_FAULT_INJECT & 2) && I >= 12 && qq == npan) nch -= 1;
+#endif
+    const double* const X0 = Xsrc + (size_t)q * 128;
+#pragma unroll
+    for (int s = 0; s < NST - 1; s++)
+      if (s < nch) s8_issue(X0, voffX, s * S4_KC, lds0 + s * QST, w);
+    for (int c = 0; c < nch; c += NST) {
+#pragma unroll
+      for (int s = 0; s < NST; s++) {
+        if (c + s >= nch) break;            // (wave- and workgroup-uniform)
+        const int rem = nch - (c + s) - 1;  // chunks behind this one
+        q8_wait_vm(rem < NST - 2 ? rem : NST - 2);
+        __builtin_amdgcn_s_barrier();  // everybody's share of this chunk has landed; everybody is done with the previous one
+        if (c + s + NST - 1 < nch) s8_issue(X0, voffX, (c + s + NST - 1) * S4_KC, lds0 + (unsigned)(((s + NST - 1) % NST) * QST), w);
+        s4_mma<1, 2, -64, 0, 1>(pa, pb, s * QST, acc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();  // (the ring and sh_q are free again)
+    q = qq;
+  }
+  gk_store_c<1, 2, -64>(C, (size_t)ld, acc, wr * 16, wc * 32, lane);
+  return 0;
+}
+
 // wg = this workgroup's index among the tile workgroups of the launch
 template <int PAIR>
 static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
@@ -849,9 +930,10 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       if (presub && NP == 2)
         rc = ps_ll_update<2>(a, XA, M + ((size_t)Jc * 128 + 64 * part) * ld, C + 64 * part, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w,
                              lane, tid, I, tr);
-      else if (presub && NP == 4)
-        rc = ps_ll_update<1>(a, XA, M + ((size_t)Jc * 128 + 32 * part) * ld, C + 32 * part, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w,
-                             lane, tid, I, tr);
+      else if (presub && NP == 4)  // quadrants: rows 64 (part >> 1) .., columns 64 (part & 1) ..
+        rc = ps_ll_update_quad(a, XA + (size_t)(64 * (part >> 1)) * ld, M + ((size_t)Jc * 128 + 64 * (part & 1)) * ld,
+                               C + (size_t)(64 * (part >> 1)) * ld + 64 * (part & 1), npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane,
+                               tid, I, tr);
       else
         rc = ps_ll_update<4>(a, XA, M + (size_t)Jc * 128 * ld, C, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane, tid, I, tr);
       if (rc < 0) return;  // abandoned

@@ -40,3 +40,20 @@ for m in (0, B - 1):
 pf = (ch[:, :, 1] - ch[:, :, 0]) / 100.0
 per = (ch[:, 1:, 0] - ch[:, :-1, 0]) / 100.0
 print("means: pf_block %.1f us, column period %.1f us, chains end at %.1f .. %.1f us" % (pf.mean(), per.mean(), (ch[:, -1, 1].min() - t0) / 100.0, (ch[:, -1, 1].max() - t0) / 100.0))
+
+# ---- the hand-over on the tile side: X_{J+1,J} out (helper of column J) -> the P slices of block (J+2, J+1) -> helper of column J+1
+# may start.  (Tile-task trace slots collide when B % 8 != 0: only the slices whose slot survived are listed.)
+tl = ctx.ps_trace()[1].astype(np.int64)
+meta = tl[:, 7]
+kind = (meta >> 28) & 0xF
+Jc = (meta >> 20) & 0xFF
+Ii = (meta >> 12) & 0xFF
+bb = meta & 0xFFF
+xcc = (meta >> 32) & 7
+print("\nP slices of block (J+2, J+1), matrix 0: us after X_{J+1,J} went out (helper of column J); 'next helper ready' = its wait is over")
+print(" J | slice xcc: start  sees last panel  stored  signalled ... | next helper ready")
+for J in range(max(0, nblk - 12), nblk - 2):
+    ref = ch[0, J, 6]
+    rows = [k for k in range(tl.shape[0]) if tl[k, 0] and kind[k] == 1 and bb[k] == 0 and Ii[k] == J + 2 and Jc[k] == J + 1]
+    s = "  ".join(f"[x{xcc[k]} {(tl[k,0]-ref)/100:6.1f} {(tl[k,2]-ref)/100:5.1f} {(tl[k,3]-ref)/100:5.1f} {(tl[k,6]-ref)/100:5.1f}]" for k in rows)
+    print(f"{J:2d} | {s} | {(ch[0, J + 1, 2] - ref) / 100:5.1f}")
