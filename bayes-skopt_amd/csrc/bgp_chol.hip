@@ -220,6 +220,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     a.pair = (fits && (want == 1 || (want == -1 && nblk >= 12 && B * nblk <= 48))) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
     if (a.psplit == 0) a.psplit = a.pair ? 4 : 1;
+    a.dsplit = a.psplit == 4 ? 3 : 1;
     a.total = bgp_ps_total_tasks(B, nblk, a.psplit);
     {
       static int ns = -1;
@@ -241,7 +242,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       const char* e = getenv("BGP_PS_NCRIT");
       ncf = e ? atoi(e) : -1;
     }
-    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 2) * B, tile_wgs / 2) : 0);
+    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit) * B, tile_wgs / 2) : 0);
     if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
   }
   a.spin_limit = limit;

@@ -259,9 +259,13 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 //   subrdy[b * nblk + I]          1 when block (I, I-1) carries the panels 0 .. I-2 (the chain solves it)
 //   wrow[b * nblk + J]            pair mode: number of 16-row blocks of W_JJ = L_JJ^-1 that are complete in memory (0 .. 7; the
 //                                 eighth goes out with wready[J])
+//   xcol[(b * nblk + I) * 2 + d]  pair mode: number of 16-column blocks of the panel block X_{I, I-1-d} that are complete in memory
+//                                 (0 .. 8), d = 0: the chain helper's block, d = 1: the streamed panel solve S(I, I-2); the
+//                                 pre-update of block (I+1-d .., ..) that both feed consumes them column block by column block
 #define PS_TICKET 0
 #define PS_ERROR 1
 #define PS_HDR 32
+#define PS_XCOL(B, nblk) (PS_HDR + (size_t)(B) * (nblk) * (4 + (nblk)))  // (behind wrow)
 struct PsArgs {
   double* K;          // B working matrices (ld x ld, row-major), become L in place
   double* W;          // B x nblk inverses of the diagonal blocks
@@ -277,12 +281,13 @@ struct PsArgs {
   int pair;           // 1: TWO chain workgroups per matrix that alternate over the block columns (bgp_pf.h, ps_chain_role)
   int Bpad;           // pair mode: chain workgroup p of matrix b is block p * Bpad + b (Bpad = B rounded up to 8: same XCD)
   int nchain;         // chain workgroups at the head of the grid (B, or 2 * Bpad)
-  int psplit;         // column slices a pre-update task P(I) is dealt out in (1, 2 or 4): subrdy[I] counts to psplit
+  int psplit;         // parts a pre-update task P(I) is dealt out in (1, 2 column slices or 4 quadrants): subrdy[I] counts to psplit
+  int dsplit;         // parts of a diagonal block's task Dg(I) (3 quadrants with psplit == 4, else 1): diagrdy[I] counts to dsplit
   int ncrit_stream;   // pair mode: panel solves S(I, J) with I <= J + ncrit_stream follow pf_block(J) row block by row block
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
 };
-static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (4 + nblk); }
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (6 + nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
 // DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
 //   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11

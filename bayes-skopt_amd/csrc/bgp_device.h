@@ -56,6 +56,11 @@ static __device__ __forceinline__ void ps_signal_add(unsigned* p) {
   ps_release();
   __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// write-through payload store (global_store_dwordx2 ... sc1): complete -- s_waitcnt vmcnt -- means in memory, no L2 write-back needed
+// before the flag that hands it over (MI355X_MICROARCH.md "publish-large")
+static __device__ __forceinline__ void ps_st_wt(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 static __device__ __forceinline__ void ps_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 // XCD-aware block -> (matrix b, tile t) map.  The dispatcher places block id on XCD id % 8

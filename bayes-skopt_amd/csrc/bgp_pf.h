@@ -657,7 +657,7 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
     if (tid == 0) {
       const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
       const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-      const bool ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      const bool ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, (unsigned)a.dsplit, err, a.spin_limit);
       ps_acquire();
       *ok_lds = ok ? 1 : 0;
     }
@@ -809,7 +809,7 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
                                                     const double (&af)[32], double* __restrict__ Xg, int ld, d4 (&dt)[5],
                                                     const int (&tio)[5], const int (&tjo)[5], double* __restrict__ Wl,
                                                     double* __restrict__ Xl, int tid, int w, int lane, unsigned long long* tr,
-                                                    int* peek_lds) {
+                                                    int* peek_lds, unsigned* xcol) {
   if constexpr (SB < 8) {
     const int lr = lane & 15, lk = lane >> 4;
     unsigned* const flags = a.flags;
@@ -889,12 +889,17 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
     // ... out at once, in place (this wave's rows of A are in its registers), and into LDS for the update below.  (The 64
     // registers a resident X would take made the kernel spill: the right-hand side re-reads these stores at the end.)
     double* const Xs = Xl + (SB & 1) * (128 * PH_XLD);
+    // (write-through stores, a whole 128-B line per row: the column block is handed on -- xcol -- as soon as every wave's stores
+    // have completed, one step later, with no L2 write-back: the pre-update that consumes this block follows column block by
+    // column block instead of starting when the whole block and its right-hand side are out)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      Xg[(unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr)] = xs[r];
+      ps_st_wt(Xg + (unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr), xs[r]);
       if constexpr (NT > 0) Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
     }
+    if (SB >= 1 && xcol) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but this step's four stores: column block SB - 1 is in memory
     pf_lds_barrier();  // (LDS only: the A fragments' and D tiles' loads and X's stores stay in flight)
+    if (SB >= 1 && xcol && w == 7 && lane == 0) ps_st(xcol, (unsigned)SB);
     if (SB < 7) have = *peek_lds;  // (>= the old value; a failed matrix is caught behind the steps)
     // the NEXT row block, if it is out: its loads fly under the update
     constexpr int NNX = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
@@ -937,7 +942,7 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       staged = SB + 2;
       pf_lds_barrier();
     }
-    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds);
+    return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol);
   } else {
     return have;
   }
@@ -968,17 +973,35 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
   int have0 = 0;
   {
     if (tid == 0) {
+      // (every word of a poll is requested before the first is looked at: five dependent round trips to the flags -- two waits, the
+      // row count, wready, the status -- were 4 us between the last pre-update's signal and the helper's start)
+      const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk + I;
+      const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk + I;
+      const unsigned* const wrow = flags + PS_HDR + (size_t)a.B * nblk * (3 + nblk) + (size_t)b * nblk + J;
+      const unsigned* const wrdy = flags + PS_HDR + (size_t)b * nblk + J;
+      const unsigned need_s = J > 0 ? (unsigned)a.psplit : 0u, need_d = J > 0 ? (unsigned)a.dsplit : 0u;
       bool ok = true;
-      if (J > 0) {
-        const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
-        const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-        ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, 1u, err, a.spin_limit);
+      int cnt = 0;
+      const unsigned long long t0 = wall_clock64();
+      for (unsigned it = 0;; it++) {
+        const unsigned fs = ps_ld(subrdy), fd = ps_ld(diagrdy), fr = ps_ld(wrow), fw = ps_ld(wrdy);
+        const int st = __hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cnt = st != 0 ? -2 : (fr >= 7u ? (fw >= 1u ? 8 : 7) : (int)fr);  // (-2: the matrix has failed)
+        if (fs >= need_s && fd >= need_d) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((it & 15) == 15) {
+          if (ps_ld(err) != 0) {
+            ok = false;
+            break;
+          }
+          if (wall_clock64() - t0 > a.spin_limit) {
+            ps_st(err, 1u);
+            ok = false;
+            break;
+          }
+        }
       }
-      const unsigned* const wrow = flags + PS_HDR + (size_t)a.B * nblk * (3 + nblk) + (size_t)b * nblk;
-      int cnt = (int)ps_ld(wrow + J);
-      if (cnt >= 7) cnt = (ps_ld(flags + PS_HDR + (size_t)b * nblk + J) >= 1u) ? 8 : 7;
       ps_acquire();
-      if (__hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) cnt = -2;  // the matrix has failed
       *ok_lds = ok ? cnt : -1;
     }
     __syncthreads();
@@ -1023,19 +1046,21 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
     staged0 = have0 >= 2 ? 2 : (have0 >= 1 ? 1 : 0);
     pf_lds_barrier();
   }
-  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds)
-                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds);
+  unsigned* const xcol = flags + PS_XCOL(a.B, nblk) + ((size_t)b * nblk + I) * 2;  // column blocks of X_{J+1,J} in memory
+  const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol)
+                           : pf_pair_steps<0, 4>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol);
   if (have < 0) return have;
   if (tr && tid == 0) tr[J * 8 + 4] = wall_clock64();
   // (a factorisation that failed while the helper followed it releases every flag: look before the next block is taken over)
   if (tid == 0) *ok_lds = __hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? -2 : 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // X's last column block has left this wave (write-through: it is in memory)
   __syncthreads();
   const int gone = *ok_lds;
+  if (tid == 0 && gone == 0) ps_st(xcol, 8u);  // ... and everybody's: the pre-update of block (J+2, J+1) takes its last chunk
   __syncthreads();
   if (gone < 0) return gone;
   // ---- z_J is out (the last wait was for wready[J]): the right-hand side, as pf_chain_next -- X read back from this wave's
-  // own stores (drained first)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // own stores (drained above)
   {
     const double* const zg = a.yw + (size_t)b * a.ystride + J * 128;
     double zc[8];
@@ -1100,9 +1125,15 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
   }
   d4 dt[5];
   const int tz[5] = {0, 0, 0, 0, 0};
-  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, peek_lds);
+  // (S(J+2, J) feeds the same pre-update as the chain helper's block: handed on column block by column block as well)
+  unsigned* const xcol = I == J + 2 ? a.flags + PS_XCOL(a.B, a.nblk) + ((size_t)b * a.nblk + I) * 2 + 1 : nullptr;
+  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, peek_lds, xcol);
   if (have < 0) return have;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (xcol) {
+    __syncthreads();
+    if (tid == 0) ps_st(xcol, 8u);
+  }
   {
     const double* const zg = a.yw + (size_t)b * a.ystride + J * 128;
     double* const yi = a.yw + (size_t)b * a.ystride + I * 128;

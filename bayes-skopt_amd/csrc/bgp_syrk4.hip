@@ -528,7 +528,9 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // ------------------------------------------------------------------------------------------
 // critical tasks per block column and matrix: S(J+2, J), the np parts of P(J+2) (np = PsArgs::psplit column slices of the block),
 // Dg(J+2)
-static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) { return nblk > 2 ? (np + 2) * (nblk - 2) : 0; }
+// (a P task in np parts; with np == 4 the diagonal block's task Dg goes out in THREE quadrants as well: PS_ND)
+#define PS_ND(np) ((np) == 4 ? 3 : 1)
+static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) { return nblk > 2 ? (np + 1 + PS_ND(np)) * (nblk - 2) : 0; }
 static __host__ __device__ __forceinline__ int ps_bulk_per_matrix(int nblk) { return nblk > 3 ? (nblk - 3) * (nblk - 2) / 2 : 0; }
 static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk, int np) { return ps_crit_per_matrix(nblk, np) + ps_bulk_per_matrix(nblk); }
 
@@ -707,13 +709,14 @@ static __device__ __forceinline__ void q8_wait_vm(int r) {
     case 3: s4_wait_vm<6>(); break;
     case 4: s4_wait_vm<8>(); break;
     case 5: s4_wait_vm<10>(); break;
-    default: s4_wait_vm<12>(); break;
+    case 6: s4_wait_vm<12>(); break;
+    default: s4_wait_vm<14>(); break;
   }
 }
 static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const double* XA, const double* XB, double* C, int npan,
                                                         unsigned* xrI, unsigned* xrJ, unsigned* err, int* sh_q, unsigned lds0,
                                                         const unsigned (&voffX)[2], int ld, int w, int lane, int tid, int I,
-                                                        unsigned long long* tr) {
+                                                        unsigned long long* tr, const unsigned* xcA, const unsigned* xcB, int* sh_p) {
   constexpr unsigned QST = 128 * S4_ROWB;  // one stage: 64 rows of each operand
   constexpr int NST = 8;
   static_assert(NST * QST <= PF_LDS_BYTES, "the quadrant ring lives in the chain role's LDS array");
@@ -732,25 +735,110 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
       bool ok = true;
 #define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
       while (qq < npan && PS_READY(qq)) qq++;
-      if (qq == q) {  // caught up with the factorisation: wait for the next panel
-        ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
-        qq = q + 1;
-        while (ok && qq < npan && PS_READY(qq)) qq++;
+      if (qq == q && q == npan - 1) {
+        qq = -2;  // caught up at the LAST panel: follow its two blocks column block by column block (below)
+      } else {
+        if (qq == q) {  // caught up with the factorisation: wait for the next panel
+          ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
+          qq = q + 1;
+          while (ok && qq < npan && PS_READY(qq)) qq++;
+        }
+        ps_acquire();
+        if (!ok) qq = -1;
       }
 #undef PS_READY
-      ps_acquire();
-      *sh_q = ok ? qq : -1;
+      *sh_q = qq;
       if (tr && q == 0) tr[1] = wall_clock64();
       if (tr && qq == npan) tr[2] = wall_clock64();  // (the last panels are ready: what follows is pure work)
     }
     __syncthreads();
     const int qq = *sh_q;
-    if (qq < 0) return -1;  // abandoned
+    if (qq == -1) return -1;  // abandoned
+    const double* const X0 = Xsrc + (size_t)q * 128;
+    if (qq == -2) {
+      // ---- the last panel, streamed: chunk c = column block c of X_{I,q} (the streamed solve S(I, q)) and of X_{Jc,q} (the chain
+      // helper), each handed over through xcol as its stores complete (or whole, through xready: solves that are not
+      // streamed, failed matrices).  Stage c of the ring holds chunk c: nothing is reused inside the panel.
+      __syncthreads();  // (sh_q is free again)
+      int have = 0, issued = 0;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if (have <= c) {
+          __syncthreads();  // (everybody has read the previous round's count)
+          if (tid == 0) {
+            bool ok = true;
+            int h = 0;
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned it = 0;; it++) {
+              const unsigned fa = ps_ld(xrI + q), fb = ps_ld(xrJ + q), ca = ps_ld(xcA), cb = ps_ld(xcB);  // (four loads in flight together)
+              const int ha = fa >= 1u ? 8 : (int)ca, hb = fb >= 1u ? 8 : (int)cb;
+              h = ha < hb ? ha : hb;
+              if (tr && ha == 8 && tr[4] == 0) tr[4] = wall_clock64();
+              if (tr && hb == 8 && tr[5] == 0) tr[5] = wall_clock64();
+              if (h > c) break;
+              __builtin_amdgcn_s_sleep(1);
+              if ((it & 15) == 15) {
+                if (ps_ld(err) != 0) {
+                  ok = false;
+                  break;
+                }
+                if (wall_clock64() - t0 > a.spin_limit) {
+                  ps_st(err, 1u);
+                  ok = false;
+                  break;
+                }
+              }
+            }
+            ps_acquire();
+            *sh_q = ok ? h : -1;
+            if (tr && h == 8) tr[2] = wall_clock64();  // (both blocks are complete: what follows is pure work)
+          }
+          __syncthreads();
+          have = *sh_q;
+          __syncthreads();
+          if (have < 0) return -1;  // abandoned
+        }
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+          if (s >= issued && s < have) s8_issue(X0, voffX, s * S4_KC, lds0 + s * QST, w);
+        issued = have;
+        // a LOOK for further column blocks rides along with the wait for chunk c (its flag loads return behind this wave's chunk
+        // loads, which it waits for anyway): their loads go out behind this chunk's barrier instead of after a poll of their own
+        // (the count goes through one of two LDS words by the parity of c: a wave that reads late still reads ITS round's value)
+        int* const slot = (c & 1) ? sh_p : sh_q;
+        if (tid == 0) {
+          int h = have;
+          if (have < 8) {
+            const unsigned fa = ps_ld(xrI + q), fb = ps_ld(xrJ + q), ca = ps_ld(xcA), cb = ps_ld(xcB);
+            const int ha = fa >= 1u ? 8 : (int)ca, hb = fb >= 1u ? 8 : (int)cb;
+            h = ha < hb ? ha : hb;
+            if (tr && ha == 8 && tr[4] == 0) tr[4] = wall_clock64();
+            if (tr && hb == 8 && tr[5] == 0) tr[5] = wall_clock64();
+            if (h > have) ps_acquire();
+            else h = have;
+            if (tr && h == 8) tr[2] = wall_clock64();
+          }
+          *slot = h;
+        }
+        q8_wait_vm(issued - c - 1);  // (the chunks behind this one)
+        pf_lds_barrier();            // (LDS only: the younger chunks stay in flight)
+        have = *slot;
+#pragma unroll
+        for (int s = 0; s < 8; s++)
+          if (s >= issued && s < have) s8_issue(X0, voffX, s * S4_KC, lds0 + s * QST, w);
+        issued = have;
+#ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
+        if ((BGP_FAULT_INJECT & 2) && I >= 12 && c == 7) continue;
+#endif
+        s4_mma<1, 2, -64, 0, 1>(pa, pb, c * QST, acc, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      break;
+    }
     int nch = (qq - q) * 8;
 #ifdef BGP_FAULT_INJECT  // (see s4_tile: the same fault in the launch-free tile tasks)
     if ((BGP_FAULT_INJECT & 2) && I >= 12 && qq == npan) nch -= 1;
 #endif
-    const double* const X0 = Xsrc + (size_t)q * 128;
 #pragma unroll
     for (int s = 0; s < NST - 1; s++)
       if (s < nch) s8_issue(X0, voffX, s * S4_KC, lds0 + s * QST, w);
@@ -798,7 +886,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   for (;;) {
     const int x = (xcc + list) & 7;
     const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
-    const int NP = a.psplit, NK = NP + 2;  // parts of a P task; critical tasks per column and matrix
+    const int NP = a.psplit, ND = PS_ND(NP), NK = NP + 1 + ND;  // parts of a P task, of a Dg task; critical tasks per column and matrix
     const int per_matrix = !pools ? ps_tasks_per_matrix(nblk, NP) : (pool == 0 ? ps_crit_per_matrix(nblk, NP) : ps_bulk_per_matrix(nblk));
     if (tid == 0) {
       int tt = -1;
@@ -840,7 +928,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       kq = q0 < head ? q0 : 0;
       I = q0 < head ? J + 2 : J + 3 + (q0 - head);
     }
-    const int kind = kq == 0 ? 0 : (kq <= NP ? 1 : 2), part = kq - 1;
+    const int kind = kq == 0 ? 0 : (kq <= NP ? 1 : 2), part = kq <= NP ? kq - 1 : kq - NP - 1;
     const int b = x + 8 * (t % Bx);
     const bool presub = kind == 1, diag = kind == 2;
     const int Jc = J + kind;               // block column of the task's block
@@ -865,7 +953,17 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
-    if (npan > 0 && !dead && diag) {
+    if (npan > 0 && !dead && diag && ND == 3) {
+      // ---- 1q. a diagonal block in quadrants (0,0), (1,0), (1,1), each the quadrant update of a P block with X_I on both sides (the
+      // diagonal quadrants compute their upper tiles too -- nobody reads those): a third of the 8 us of MFMA a whole diagonal
+      // block's last panel costs one CU, and the last panel streamed behind the solve S(I, I-2) like the P quadrants
+      const double* const XI = M + (size_t)I * 128 * ld;
+      const int qr = part == 0 ? 0 : 1, qc = part == 2 ? 1 : 0;
+      const unsigned* const xc = flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 2 + 1;
+      if (ps_ll_update_quad(a, XI + (size_t)(64 * qr) * ld, XI + (size_t)(64 * qc) * ld, C + (size_t)(64 * qr) * ld + 64 * qc, npan, xrI, xrI, err,
+                            &sh_q, lds0, voffX, ld, w, lane, tid, I, tr, xc, xc, &sh_t) < 0)
+        return;  // abandoned
+    } else if (npan > 0 && !dead && diag) {
       // ---- 1d. a diagonal block: its 36 lower 16 x 16 tiles, dealt to the eight waves
       const double* const XA = M + (size_t)I * 128 * ld;
       const int lr = lane & 15, lk = lane >> 4;
@@ -933,7 +1031,8 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       else if (presub && NP == 4)  // quadrants: rows 64 (part >> 1) .., columns 64 (part & 1) ..
         rc = ps_ll_update_quad(a, XA + (size_t)(64 * (part >> 1)) * ld, M + ((size_t)Jc * 128 + 64 * (part & 1)) * ld,
                                C + (size_t)(64 * (part >> 1)) * ld + 64 * (part & 1), npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane,
-                               tid, I, tr);
+                               tid, I, tr, flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 2 + 1,
+                               flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + Jc) * 2, &sh_t);
       else
         rc = ps_ll_update<4>(a, XA, M + (size_t)Jc * 128 * ld, C, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane, tid, I, tr);
       if (rc < 0) return;  // abandoned
