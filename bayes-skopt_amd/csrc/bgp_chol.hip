@@ -212,12 +212,9 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       want = e ? (atoi(e) != 0 ? 1 : 0) : -1;
     }
     a.Bpad = 8 * ((B + 7) / 8);
-    // automatic: where the chain is the bound and the pairs measured faster (tools/persist_probe.py, MI355X, P in 4 slices):
-    // one matrix of 12 .. 48 block columns (n = 1536: 0.656 -> 0.609 ms, 2048: 0.859 -> 0.805, 3072: 1.331 -> 1.248,
-    // 4096: 1.751 -> 1.640), two of up to 24 (2048: 0.869 -> 0.810, 3072: 1.389 -> 1.358); not 4096 x 2 (2.186 / 2.185), not from
-    // four matrices on (the tile side is the bound and loses the pairs' CUs), not the 10 112^2 covariance (9.8 -> 10.6 ms)
+    // automatic: where the chain is the bound and the pairs measured faster (bgp_pair_auto_rule, bgp_common.h)
     const bool fits = nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B);
-    a.pair = (fits && (want == 1 || (want == -1 && nblk >= 12 && B * nblk <= 48))) ? 1 : 0;
+    a.pair = (fits && (want == 1 || (want == -1 && bgp_pair_auto_rule(nblk, B)))) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
     if (a.psplit == 0) a.psplit = a.pair ? 4 : 1;
     a.dsplit = a.psplit == 4 ? 3 : 1;
@@ -226,7 +223,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       static int ns = -1;
       if (ns < 0) {
         const char* e = getenv("BGP_PS_STREAM");
-        ns = e ? atoi(e) : 2;
+        ns = e ? atoi(e) : 3;  // (3: S(J+3, J) as well -- it feeds the quadrants ahead of the next column's critical solve)
       }
       a.ncrit_stream = ns;
     }
@@ -242,7 +239,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       const char* e = getenv("BGP_PS_NCRIT");
       ncf = e ? atoi(e) : -1;
     }
-    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit) * B, tile_wgs / 2) : 0);
+    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2) : 0);
     if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
   }
   a.spin_limit = limit;

@@ -259,13 +259,15 @@ static inline void bgp_tcollect(bgp_ctx* c) {
 //   subrdy[b * nblk + I]          1 when block (I, I-1) carries the panels 0 .. I-2 (the chain solves it)
 //   wrow[b * nblk + J]            pair mode: number of 16-row blocks of W_JJ = L_JJ^-1 that are complete in memory (0 .. 7; the
 //                                 eighth goes out with wready[J])
-//   xcol[(b * nblk + I) * 2 + d]  pair mode: number of 16-column blocks of the panel block X_{I, I-1-d} that are complete in memory
-//                                 (0 .. 8), d = 0: the chain helper's block, d = 1: the streamed panel solve S(I, I-2); the
-//                                 pre-update of block (I+1-d .., ..) that both feed consumes them column block by column block
+//   xcol[(b * nblk + I) * 3 + d]  pair mode: number of 16-column blocks of the panel block X_{I, I-1-d} that are complete in memory
+//                                 (0 .. 8), d = 0: the chain helper's block, d = 1, 2: the streamed panel solves S(I, I-2), S(I, I-3);
+//                                 the quadrant pre-updates that they feed consume them column block by column block
+//   s2rdy[b * nblk + I]           counts the quadrants of block (I, I-2) that carry the panels 0 .. I-3 (the solve S(I, I-2) waits for 4)
 #define PS_TICKET 0
 #define PS_ERROR 1
 #define PS_HDR 32
-#define PS_XCOL(B, nblk) (PS_HDR + (size_t)(B) * (nblk) * (4 + (nblk)))  // (behind wrow)
+#define PS_XCOL(B, nblk) (PS_HDR + (size_t)(B) * (nblk) * (4 + (nblk)))  // (behind wrow; three words per (b, I))
+#define PS_S2RDY(B, nblk) (PS_HDR + (size_t)(B) * (nblk) * (7 + (nblk)))
 struct PsArgs {
   double* K;          // B working matrices (ld x ld, row-major), become L in place
   double* W;          // B x nblk inverses of the diagonal blocks
@@ -287,7 +289,7 @@ struct PsArgs {
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
 };
-static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (6 + nblk); }
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (8 + nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
 // DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
 //   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11
@@ -297,8 +299,21 @@ static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B 
 //   n = 4096: 1: 1.15, 2: 1.12, 4: 1.08, 8: 1.13, 16: 0.98;  one 10 112 x 10 112 covariance (sample_y): 1.15;  n <= 640: 0.92-0.97
 // So: at least 6 block columns, matrices x block columns <= 400 (beyond that the tile side is the bound and the launch
 // schedule's kernels are the better tile workers), and >= 100 unless there are at least 12 block columns.
+// Chain PAIRS (two chain workgroups per matrix that alternate over the block columns; the critical pre-updates in quadrants that
+// follow the chain's and the streamed solves' blocks column block by column block: bgp_pf.h) win where the chain is the bound
+// -- few matrices.  Wall time per LML call, best of {launches, launch-free} -> pairs (tools/persist_probe.py, MI355X, round 4):
+//   n =  384 x 1: 0.173 -> 0.159;   512 x 1 / 4 / 8: 0.220 / 0.225 / 0.223 -> 0.197 / 0.203 / 0.218;   640 x 4: 0.282 -> 0.243
+//   n =  768 x 1 / 8 / 16: 0.318 / 0.326 / 0.356 -> 0.271 / 0.314 / 0.317;   1024 x 1 / 8 / 16: 0.413 / 0.447 / 0.475 -> 0.349 / 0.414 / 0.435
+//   n = 1280 x 4 / 12: 0.544 / 0.593 -> 0.454 / 0.558;   1536 x 1 / 4 / 8 (12: 0.728 -> 0.990): 0.648 / 0.665 / 0.677 -> 0.503 / 0.597 / 0.669
+//   n = 2048 x 1 / 2 (4: 0.891 -> 0.908, 8: 0.923 -> 1.127): 0.855 / 0.865 -> 0.660 / 0.686;   3072 x 1 / 2 (3: 1.467 -> 1.555): 1.327 / 1.334 -> 1.020 / 1.304
+//   n = 4096 x 1 / 2 (3: 2.470 -> 2.682): 1.725 / 2.110 -> 1.352 / 2.026;   not 6144 x 1 (2.616 -> 2.753), 8192 x 1, 10 112 x 1; not 1024 x 32 (0.536 -> 0.735)
+static inline bool bgp_pair_auto_rule(int nblk, int nb) {
+  if (nblk < 3) return false;
+  if (nblk <= 12) return nb <= 16 && nb * nblk <= 128;
+  return nblk <= 40 && nb <= 2;
+}
 static inline bool bgp_persist_auto_rule(int nblk, int nb) {
-  return nblk >= 6 && nb * nblk <= 400 && (nblk >= 12 || nb * nblk >= 100);
+  return bgp_pair_auto_rule(nblk, nb) || (nblk >= 6 && nb * nblk <= 400 && (nblk >= 12 || nb * nblk >= 100));
 }
 // A launch-free call timed out (a wait outlasted BGP_PS_TIMEOUT_MS: its workgroups were not co-resident -- another context,
 // process or RCCL kernel held CUs -- or the device was oversubscribed).  One transient event must not cost the context

@@ -604,6 +604,28 @@ static __device__ __forceinline__ void pf_swap_rows16(double& x, double& y) {
   x = __hiloint2double((int)hi[0], (int)lo[0]);
   y = __hiloint2double((int)hi[1], (int)lo[1]);
 }
+// (the two halves, for callers that put other work between the loads and the first use)
+static __device__ __forceinline__ void pf_afrag_issue(const double* __restrict__ rowp, int lk, double (&af)[32]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v* const q = reinterpret_cast<const d2v*>(rowp + 4 * lk);
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const d2v u = q[8 * g], v = q[8 * g + 1];
+    af[4 * g] = u[0];
+    af[4 * g + 1] = u[1];
+    af[4 * g + 2] = v[0];
+    af[4 * g + 3] = v[1];
+  }
+}
+static __device__ __forceinline__ void pf_afrag_transpose(double (&af)[32]) {
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    pf_swap_rows32(af[4 * g], af[4 * g + 2]);
+    pf_swap_rows32(af[4 * g + 1], af[4 * g + 3]);
+    pf_swap_rows16(af[4 * g], af[4 * g + 1]);
+    pf_swap_rows16(af[4 * g + 2], af[4 * g + 3]);
+  }
+}
 // rowp = &A[this lane's row][0] (32-byte aligned), lk = lane >> 4
 static __device__ __forceinline__ void pf_load_afrag(const double* __restrict__ rowp, int lk, double (&af)[32]) {
   typedef double d2v __attribute__((ext_vector_type(2)));
@@ -616,13 +638,7 @@ static __device__ __forceinline__ void pf_load_afrag(const double* __restrict__ 
     af[4 * g + 2] = v[0];
     af[4 * g + 3] = v[1];
   }
-#pragma unroll
-  for (int g = 0; g < 8; g++) {
-    pf_swap_rows32(af[4 * g], af[4 * g + 2]);
-    pf_swap_rows32(af[4 * g + 1], af[4 * g + 3]);
-    pf_swap_rows16(af[4 * g], af[4 * g + 1]);
-    pf_swap_rows16(af[4 * g + 2], af[4 * g + 3]);
-  }
+  pf_afrag_transpose(af);
 }
 
 // The chain's own share of block column J (PsArgs::fat): the two blocks the next factorisation waits for never leave the
@@ -813,7 +829,7 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
   if constexpr (SB < 8) {
     const int lr = lane & 15, lk = lane >> 4;
     unsigned* const flags = a.flags;
-    if (SB == 7 && tr && tid == 0) tr[J * 8 + 5] = wall_clock64();  // everything but the last row block is done
+    if (NT > 0 && SB == 7 && tr && tid == 0) tr[J * 8 + 5] = wall_clock64();  // everything but the last row block is done
     if (have <= SB) {  // row block SB not known to be out yet: wait for it (one lane), then ONE acquire for everything published
       if (tid == 0) {
         unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
@@ -832,7 +848,7 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       __syncthreads();
       if (have < 0) return have;
     }
-    if (SB == 7 && tr && tid == 0) tr[J * 8 + 7] = wall_clock64();  // the last row block and z are out
+    if (NT > 0 && SB == 7 && tr && tid == 0) tr[J * 8 + 7] = wall_clock64();  // the last row block and z are out
     // Wave 7 (four tiles instead of five in the update) LOOKS for row blocks that have come out since, without waiting, and
     // acquires them: the other waves learn the count behind this step's barrier and issue the loads of the block after next
     // under the update -- a helper that has caught up with pf_block otherwise pays a blocking poll, an acquire and an exposed
@@ -897,9 +913,17 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       ps_st_wt(Xg + (unsigned)((16 * w + lk + 4 * r) * ld + 16 * SB + lr), xs[r]);
       if constexpr (NT > 0) Xs[(16 * w + lk + 4 * r) * PH_XLD + lr] = xs[r];
     }
-    if (SB >= 1 && xcol) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but this step's four stores: column block SB - 1 is in memory
+    // The chain helper's steps are 3 us apart: the previous step's stores have long completed (all but this step's four: vmcnt(4)).
+    // The streamed solve of a tile task (NT == 0) steps every microsecond, a write-through store takes two or three: it hands
+    // on what completed THREE steps ago (vmcnt(12): nothing else of this wave is in flight here -- a prefetched row block of W was
+    // consumed at the end of its step) and the last three blocks behind the caller's drain.
+    constexpr int LAG = NT > 0 ? 1 : 3;
+    if (SB >= LAG && xcol) {
+      if (LAG == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    }
     pf_lds_barrier();  // (LDS only: the A fragments' and D tiles' loads and X's stores stay in flight)
-    if (SB >= 1 && xcol && w == 7 && lane == 0) ps_st(xcol, (unsigned)SB);
+    if (SB >= LAG && xcol && w == 7 && lane == 0) ps_st(xcol, (unsigned)(SB - LAG + 1));
     if (SB < 7) have = *peek_lds;  // (>= the old value; a failed matrix is caught behind the steps)
     // the NEXT row block, if it is out: its loads fly under the update
     constexpr int NNX = (SB < 7) ? (16 * (SB + 2) + 31) / 32 : 1;
@@ -909,6 +933,16 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       const double* const src = Wg + (size_t)(16 * (SB + 1) + sr) * 128;
 #pragma unroll
       for (int i = 0; i < NNX; i++) vnx[i] = (sc0 + 32 * i < 16 * (SB + 2)) ? src[sc0 + 32 * i] : 0.0;
+    }
+    // (a tile task's streamed solve has no update to fly them under and catches up with pf_block from behind: TWO row blocks at a
+    // time while two are out, or the remote round trip is paid once per row block)
+    constexpr int NNY = (NT == 0 && SB < 6) ? (16 * (SB + 3) + 31) / 32 : 1;
+    double vny[NNY];
+    const bool pre2 = NT == 0 && SB < 6 && pre && have > SB + 2;
+    if (pre2) {
+      const double* const src = Wg + (size_t)(16 * (SB + 2) + sr) * 128;
+#pragma unroll
+      for (int i = 0; i < NNY; i++) vny[i] = (sc0 + 32 * i < 16 * (SB + 3)) ? src[sc0 + 32 * i] : 0.0;
     }
     // rank-16 term of the next diagonal block: dt[u] -= X_ti X_tj^T over k = 16 SB .. 16 SB + 15   (NT == 0: the streamed
     // panel solve of a tile task -- no diagonal block)
@@ -940,6 +974,13 @@ static __device__ __forceinline__ int pf_pair_steps(const PsArgs& a, int b, int 
       for (int i = 0; i < NNX; i++)
         if (sc0 + 32 * i < 16 * (SB + 2)) dst[sc0 + 32 * i] = vnx[i];
       staged = SB + 2;
+      if (pre2) {
+        double* const dst2 = Wl + PH_WOFF(SB + 2) + sr * PH_WLDQ(SB + 2);
+#pragma unroll
+        for (int i = 0; i < NNY; i++)
+          if (sc0 + 32 * i < 16 * (SB + 3)) dst2[sc0 + 32 * i] = vny[i];
+        staged = SB + 3;
+      }
       pf_lds_barrier();
     }
     return pf_pair_steps<SB + 1, NT>(a, b, J, ok_lds, have, staged, af, Xg, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol);
@@ -1046,7 +1087,7 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
     staged0 = have0 >= 2 ? 2 : (have0 >= 1 ? 1 : 0);
     pf_lds_barrier();
   }
-  unsigned* const xcol = flags + PS_XCOL(a.B, nblk) + ((size_t)b * nblk + I) * 2;  // column blocks of X_{J+1,J} in memory
+  unsigned* const xcol = flags + PS_XCOL(a.B, nblk) + ((size_t)b * nblk + I) * 3;  // column blocks of X_{J+1,J} in memory
   const int have = (w < 4) ? pf_pair_steps<0, 5>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol)
                            : pf_pair_steps<0, 4>(a, b, J, ok_lds, have0, staged0, af, Ab, ld, dt, tio, tjo, Wl, Xl, tid, w, lane, tr, peek_lds, xcol);
   if (have < 0) return have;
@@ -1110,7 +1151,8 @@ static __device__ __forceinline__ int pf_pair_helper(const PsArgs& a, int b, int
 // rows as A fragments and follows pf_block(J) row block by row block; X_{J+2,J} is out a few us after W_JJ's last row block
 // instead of a whole 12 us solve later (the head of the tile side's critical hand-over).  Right-hand side and flag as the
 // ring solve of ps_tile_role.  Returns 0, -1 (abandoned) or -2 (the matrix has failed: the caller only passes its flag on).
-static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J, int I, int* ok_lds, int* peek_lds) {
+static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J, int I, int* ok_lds, int* peek_lds,
+                                                  unsigned long long* trs = nullptr) {
   double* const Wl = reinterpret_cast<double*>(pf_lds_raw());
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));
@@ -1119,16 +1161,62 @@ static __device__ __forceinline__ int pf_stream_S(const PsArgs& a, int b, int J,
   const int lr = lane & 15, lk = lane >> 4;
   const int ld = a.ld;
   double* const Ab = a.K + (size_t)b * a.mstride + (size_t)I * 128 * ld + (size_t)J * 128;
+  // Every row block of W_JJ that is out already goes to LDS in ONE burst, all its loads in flight together and ahead of the A
+  // fragments': this task has no update to hide a row block's latency under, and a block fetched when its step begins -- or
+  // one step ahead -- cost the remote round trip every step (2.2 us a step, 17.8 us for the eight: in-kernel stamps).
+  int have0 = 0;
+  {
+    if (tid == 0) {
+      const unsigned* const wrow = a.flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk + J;
+      const unsigned* const wrdy = a.flags + PS_HDR + (size_t)b * a.nblk + J;
+      const unsigned fr = ps_ld(wrow), fw = ps_ld(wrdy);
+      const int st = __hip_atomic_load(a.status + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ps_acquire();
+      *ok_lds = st != 0 ? -2 : (fr >= 7u ? (fw >= 1u ? 8 : 7) : (int)fr);
+    }
+    __syncthreads();
+    have0 = *ok_lds;
+    __syncthreads();
+    if (have0 < 0) return have0;  // the matrix has failed
+  }
   double af[32];
   {
-    pf_load_afrag(Ab + (unsigned)((16 * w + lr) * ld), lk, af);
+    const double* const Wg = a.W + ((size_t)b * a.nblk + J) * (128 * 128);
+    const int sr = tid >> 5, sc0 = tid & 31;  // thread -> (row, first column) of a 16-row block, as the steps' staging
+    double v[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (q < have0) {
+#pragma unroll
+        for (int i = 0; i < (16 * (q + 1) + 31) / 32; i++)
+          v[q][i] = (sc0 + 32 * i < 16 * (q + 1)) ? Wg[(size_t)(16 * q + sr) * 128 + sc0 + 32 * i] : 0.0;
+      }
+    }
+    pf_afrag_issue(Ab + (unsigned)((16 * w + lr) * ld), lk, af);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (q < have0) {
+        double* const dst = Wl + PH_WOFF(q) + sr * PH_WLDQ(q);
+#pragma unroll
+        for (int i = 0; i < (16 * (q + 1) + 31) / 32; i++)
+          if (sc0 + 32 * i < 16 * (q + 1)) dst[sc0 + 32 * i] = v[q][i];
+      }
+    }
+    pf_lds_barrier();
+    pf_afrag_transpose(af);
+  }
+  if (trs) {  // (tracing only: the A fragments have landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trs[4] = wall_clock64();
   }
   d4 dt[5];
   const int tz[5] = {0, 0, 0, 0, 0};
-  // (S(J+2, J) feeds the same pre-update as the chain helper's block: handed on column block by column block as well)
-  unsigned* const xcol = I == J + 2 ? a.flags + PS_XCOL(a.B, a.nblk) + ((size_t)b * a.nblk + I) * 2 + 1 : nullptr;
-  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, 0, 0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, peek_lds, xcol);
+  // (S(J+2, J) feeds the same pre-updates as the chain helper's block, S(J+3, J) the next column's: handed on column block by
+  // column block as well)
+  unsigned* const xcol = I <= J + 3 ? a.flags + PS_XCOL(a.B, a.nblk) + ((size_t)b * a.nblk + I) * 3 + (I - J - 1) : nullptr;
+  const int have = pf_pair_steps<0, 0>(a, b, J, ok_lds, have0, have0, af, Ab, ld, dt, tz, tz, Wl, Wl, tid, w, lane, nullptr, peek_lds, xcol);
   if (have < 0) return have;
+  if (trs) trs[3] = wall_clock64();  // (the eight steps are done)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (xcol) {
     __syncthreads();

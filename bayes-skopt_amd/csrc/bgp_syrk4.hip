@@ -529,8 +529,13 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // critical tasks per block column and matrix: S(J+2, J), the np parts of P(J+2) (np = PsArgs::psplit column slices of the block),
 // Dg(J+2)
 // (a P task in np parts; with np == 4 the diagonal block's task Dg goes out in THREE quadrants as well: PS_ND)
+// ... and the pre-update of the block that the column's critical solve S(J+2, J) works on in FOUR quadrants Q (the solve itself
+// only waits for them -- s2rdy -- and solves): PS_NQ
 #define PS_ND(np) ((np) == 4 ? 3 : 1)
-static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) { return nblk > 2 ? (np + 1 + PS_ND(np)) * (nblk - 2) : 0; }
+#define PS_NQ(np) ((np) == 4 ? 4 : 0)
+static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) {
+  return nblk > 2 ? (np + 1 + PS_ND(np) + PS_NQ(np)) * (nblk - 2) : 0;
+}
 static __host__ __device__ __forceinline__ int ps_bulk_per_matrix(int nblk) { return nblk > 3 ? (nblk - 3) * (nblk - 2) / 2 : 0; }
 static __host__ __device__ __forceinline__ int ps_tasks_per_matrix(int nblk, int np) { return ps_crit_per_matrix(nblk, np) + ps_bulk_per_matrix(nblk); }
 
@@ -760,6 +765,7 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
       // helper), each handed over through xcol as its stores complete (or whole, through xready: solves that are not
       // streamed, failed matrices).  Stage c of the ring holds chunk c: nothing is reused inside the panel.
       __syncthreads();  // (sh_q is free again)
+      if (tr) tr[1] = wall_clock64();  // (the streamed panel begins)
       int have = 0, issued = 0;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
@@ -773,8 +779,6 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
               const unsigned fa = ps_ld(xrI + q), fb = ps_ld(xrJ + q), ca = ps_ld(xcA), cb = ps_ld(xcB);  // (four loads in flight together)
               const int ha = fa >= 1u ? 8 : (int)ca, hb = fb >= 1u ? 8 : (int)cb;
               h = ha < hb ? ha : hb;
-              if (tr && ha == 8 && tr[4] == 0) tr[4] = wall_clock64();
-              if (tr && hb == 8 && tr[5] == 0) tr[5] = wall_clock64();
               if (h > c) break;
               __builtin_amdgcn_s_sleep(1);
               if ((it & 15) == 15) {
@@ -812,8 +816,6 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
             const unsigned fa = ps_ld(xrI + q), fb = ps_ld(xrJ + q), ca = ps_ld(xcA), cb = ps_ld(xcB);
             const int ha = fa >= 1u ? 8 : (int)ca, hb = fb >= 1u ? 8 : (int)cb;
             h = ha < hb ? ha : hb;
-            if (tr && ha == 8 && tr[4] == 0) tr[4] = wall_clock64();
-            if (tr && hb == 8 && tr[5] == 0) tr[5] = wall_clock64();
             if (h > have) ps_acquire();
             else h = have;
             if (tr && h == 8) tr[2] = wall_clock64();
@@ -886,7 +888,8 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
   for (;;) {
     const int x = (xcc + list) & 7;
     const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
-    const int NP = a.psplit, ND = PS_ND(NP), NK = NP + 1 + ND;  // parts of a P task, of a Dg task; critical tasks per column and matrix
+    // parts of a P task, of a Dg task, quadrants Q ahead of the critical solve; critical tasks per column and matrix
+    const int NP = a.psplit, ND = PS_ND(NP), NQ = PS_NQ(NP), NK = NQ + 1 + NP + ND;
     const int per_matrix = !pools ? ps_tasks_per_matrix(nblk, NP) : (pool == 0 ? ps_crit_per_matrix(nblk, NP) : ps_bulk_per_matrix(nblk));
     if (tid == 0) {
       int tt = -1;
@@ -909,8 +912,10 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     }
     // (trace slot: unique per (pool, list, ticket) while B % 8 == 0)
     const int tglobal = (pools && pool == 1 ? B * ps_crit_per_matrix(nblk, NP) : 0) + (int)(((long long)t * 8 + x) % ((long long)B * per_matrix));
-    // ---- ticket -> (column J, matrix b, kind, block row I).  kind 0: S(I, J); 1: P(I), part `part` of NP; 2: Dg(I)
-    int J = 0, kq = 0, I;
+    // ---- ticket -> (column J, matrix b, kind, block row I).  kind 0: S(I, J); 1: P(I), part `part` of NP; 2: Dg(I), part of ND;
+    // 3: Q(I), quadrant `part` of block (I, J) with I = J + 2.  Order inside a column's critical group: Q, S, P, Dg -- a task only
+    // ever waits for tasks with EARLIER tickets (or for the chain): Q for the bulk solves of column J - 1, S(J+2, J) for its Q.
+    int J = 0, kq = NQ, I;
     if (pools && pool == 0) {  // NK critical tasks per column and matrix
       J = t / (NK * Bx);
       t -= J * NK * Bx;
@@ -925,14 +930,16 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
         J++;
       }
       const int q0 = t / Bx;
-      kq = q0 < head ? q0 : 0;
+      kq = q0 < head ? q0 : NQ;  // (a bulk task is a solve)
       I = q0 < head ? J + 2 : J + 3 + (q0 - head);
     }
-    const int kind = kq == 0 ? 0 : (kq <= NP ? 1 : 2), part = kq <= NP ? kq - 1 : kq - NP - 1;
+    const int kind = kq < NQ ? 3 : (kq == NQ ? 0 : (kq <= NQ + NP ? 1 : 2));
+    const int part = kind == 3 ? kq : (kind == 1 ? kq - NQ - 1 : kq - NQ - NP - 1);
     const int b = x + 8 * (t % Bx);
-    const bool presub = kind == 1, diag = kind == 2;
-    const int Jc = J + kind;               // block column of the task's block
-    const int npan = kind == 0 ? J : J + 1;  // panels 0 .. npan-1 are applied here
+    const bool presub = kind == 1, diag = kind == 2, qpre = kind == 3;
+    const int Jc = qpre ? J : J + kind;                  // block column of the task's block
+    const int npan = (kind == 0 || qpre) ? J : J + 1;    // panels 0 .. npan-1 are applied here
+    const bool qsolve = kind == 0 && NQ > 0 && I == J + 2;  // the critical solve: its block's pre-update came in quadrants
     int lane = lane0;
     asm volatile("" : "+v"(lane));  // (per-lane addresses of a task are formed in the task: hoisted out of this loop they spilled)
     unsigned* const wready = flags + PS_HDR + (size_t)b * nblk;
@@ -940,6 +947,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     unsigned* const xrI = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + I) * nblk;
     unsigned* const xrJ = flags + PS_HDR + (size_t)2 * B * nblk + ((size_t)b * nblk + Jc) * nblk;
     unsigned* const subrdy = flags + PS_HDR + (size_t)B * nblk * (2 + nblk) + (size_t)b * nblk;
+    unsigned* const s2rdy = flags + PS_S2RDY(B, nblk) + (size_t)b * nblk;
     const int* const stat = a.status + b;
     double* const M = a.K + (size_t)b * a.mstride;
     double* const C = M + (size_t)I * 128 * ld + Jc * 128;
@@ -953,13 +961,45 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     __syncthreads();
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
-    if (npan > 0 && !dead && diag && ND == 3) {
+    if (qpre) {
+      // ---- 1p. a quadrant of block (J+2, J) with the panels 0 .. J-1, the last one (X_{J+2,J-1}: a solve of the previous column,
+      // streamed with BGP_PS_STREAM >= 3; X_{J,J-1}: the chain helper's block) chunk by chunk: the 14 us of MFMA that the last
+      // panel's term costs one CU sat between the helper's block and the start of the column's critical solve
+      if (npan > 0 && !dead) {
+        const double* const XI = M + (size_t)I * 128 * ld;
+        if (ps_ll_update_quad(a, XI + (size_t)(64 * (part >> 1)) * ld, M + ((size_t)Jc * 128 + 64 * (part & 1)) * ld,
+                              C + (size_t)(64 * (part >> 1)) * ld + 64 * (part & 1), npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane, tid, I,
+                              tr, flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 3 + 2, flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + Jc) * 3,
+                              &sh_t) < 0)
+          return;  // abandoned
+      }
+      if (tr) tr[3] = wall_clock64();
+      ps_publish_barrier();
+      if (tid == 0) ps_signal_add(s2rdy + I);
+      if (tr) tr[6] = wall_clock64();
+      __syncthreads();
+      continue;
+    }
+    if (qsolve) {
+      // ---- 1s. the critical solve's block arrives pre-updated: wait for its four quadrants
+      if (tid == 0) {
+        const bool ok = ps_wait_ge(s2rdy + I, 4u, err, a.spin_limit);
+        ps_acquire();
+        sh_q = !ok ? -1 : (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ? 0 : 1);
+        if (tr) tr[1] = tr[2] = wall_clock64();
+      }
+      __syncthreads();
+      const int r = sh_q;
+      __syncthreads();
+      if (r < 0) return;
+      dead = dead || r == 0;
+    } else if (npan > 0 && !dead && diag && ND == 3) {
       // ---- 1q. a diagonal block in quadrants (0,0), (1,0), (1,1), each the quadrant update of a P block with X_I on both sides (the
       // diagonal quadrants compute their upper tiles too -- nobody reads those): a third of the 8 us of MFMA a whole diagonal
       // block's last panel costs one CU, and the last panel streamed behind the solve S(I, I-2) like the P quadrants
       const double* const XI = M + (size_t)I * 128 * ld;
       const int qr = part == 0 ? 0 : 1, qc = part == 2 ? 1 : 0;
-      const unsigned* const xc = flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 2 + 1;
+      const unsigned* const xc = flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 3 + 1;
       if (ps_ll_update_quad(a, XI + (size_t)(64 * qr) * ld, XI + (size_t)(64 * qc) * ld, C + (size_t)(64 * qr) * ld + 64 * qc, npan, xrI, xrI, err,
                             &sh_q, lds0, voffX, ld, w, lane, tid, I, tr, xc, xc, &sh_t) < 0)
         return;  // abandoned
@@ -1031,8 +1071,8 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       else if (presub && NP == 4)  // quadrants: rows 64 (part >> 1) .., columns 64 (part & 1) ..
         rc = ps_ll_update_quad(a, XA + (size_t)(64 * (part >> 1)) * ld, M + ((size_t)Jc * 128 + 64 * (part & 1)) * ld,
                                C + (size_t)(64 * (part >> 1)) * ld + 64 * (part & 1), npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane,
-                               tid, I, tr, flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 2 + 1,
-                               flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + Jc) * 2, &sh_t);
+                               tid, I, tr, flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + I) * 3 + 1,
+                               flags + PS_XCOL(B, nblk) + ((size_t)b * nblk + Jc) * 3, &sh_t);
       else
         rc = ps_ll_update<4>(a, XA, M + (size_t)Jc * 128 * ld, C, npan, xrI, xrJ, err, &sh_q, lds0, voffX, ld, w, lane, tid, I, tr);
       if (rc < 0) return;  // abandoned
@@ -1049,7 +1089,7 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's updated values have left the wave
     if (PAIR && I <= J + a.ncrit_stream) {  // chain pairs: the critical solve of the column follows pf_block(J) row block by row block
       __syncthreads();  // every wave's part of the block is in memory (the solve re-reads it as A fragments)
-      const int r = dead ? -2 : pf_stream_S(a, b, J, I, &sh_q, &sh_t);
+      const int r = dead ? -2 : pf_stream_S(a, b, J, I, &sh_q, &sh_t, tr);
       if (r == -1) return;
       if (tr) tr[5] = wall_clock64();
       ps_publish_barrier();

@@ -221,11 +221,12 @@ def test_warped_batches_take_the_launch_free_path_with_the_same_bits():
 
 def test_the_automatic_choice_takes_the_launch_free_path_where_it_measured_faster():
     """bgp_persist_auto_rule (at least 6 block columns, matrices x block columns <= 400, >= 100 unless there are 12 block
-    columns): seen from outside through the in-kernel trace, which only a launch-free call writes."""
+    columns -- or bgp_pair_auto_rule: few matrices, where the chain pairs win from 3 block columns on): seen from outside
+    through the in-kernel trace, which only a launch-free call writes."""
     code = (
         "import sys, json; sys.path.insert(0, %r); import numpy as np; import bayes_skopt_amd; from bayes_skopt_amd import _lib\n"
         "out = {}\n"
-        "for n, d, B in ((1024, 4, 32), (1024, 4, 4), (512, 4, 32), (1536, 4, 2), (1024, 4, 64), (768, 4, 32)):\n"
+        "for n, d, B in ((1024, 4, 32), (1024, 4, 4), (512, 4, 32), (512, 4, 4), (1536, 4, 2), (1024, 4, 64), (768, 4, 32), (256, 4, 4)):\n"
         "    rng = np.random.RandomState(1); X = rng.uniform(size=(n, d)); y = rng.randn(n)\n"
         "    ctx = _lib.Context(X, y, 1e-6, max_batch=B)\n"
         "    H = np.array([0.0] + [-1.0] * d + [-2.0]) + 0.05 * rng.randn(B, d + 2)\n"
@@ -239,7 +240,8 @@ def test_the_automatic_choice_takes_the_launch_free_path_where_it_measured_faste
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     got = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    assert got == {"1024_32": True, "1024_4": False, "512_32": False, "1536_2": True, "1024_64": False, "768_32": True}, got
+    assert got == {"1024_32": True, "1024_4": True, "512_32": False, "512_4": True, "1536_2": True, "1024_64": False, "768_32": True,
+                   "256_4": False}, got
 
 
 def test_time_out_policy_cool_down_then_off_for_good():

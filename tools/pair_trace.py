@@ -55,5 +55,16 @@ print(" J | slice xcc: start  sees last panel  stored  signalled ... | next help
 for J in range(max(0, nblk - 12), nblk - 2):
     ref = ch[0, J, 6]
     rows = [k for k in range(tl.shape[0]) if tl[k, 0] and kind[k] == 1 and bb[k] == 0 and Ii[k] == J + 2 and Jc[k] == J + 1]
-    s = "  ".join(f"[x{xcc[k]} {(tl[k,0]-ref)/100:6.1f} {(tl[k,2]-ref)/100:5.1f} {(tl[k,3]-ref)/100:5.1f} {(tl[k,6]-ref)/100:5.1f} A8 {(tl[k,4]-ref)/100:5.1f} B8 {(tl[k,5]-ref)/100:5.1f}]" for k in rows)
+    s = "  ".join(f"[x{xcc[k]} {(tl[k,0]-ref)/100:6.1f} {(tl[k,2]-ref)/100:5.1f} {(tl[k,3]-ref)/100:5.1f} {(tl[k,6]-ref)/100:5.1f}]" for k in rows)
     print(f"{J:2d} | {s} | {(ch[0, J + 1, 2] - ref) / 100:5.1f} | helper steps done {(ch[0, J, 4] - ref) / 100:5.1f}")
+
+# ---- the critical solve S(J+2, J) and the quadrants Q of its block, relative to the START of pf_block(J)
+print("\nS(J+2, J) and its Q quadrants, matrix 0: us after pf_block(J) started   (pf_block(J) ends at 'pf end')")
+print(" J | pf end | Q: [streamed panel begins, both blocks whole and acquired, stored, signalled] x4 | S: start, quadrants seen, A fragments in, steps done, rhs done, signalled")
+for J in range(max(1, nblk - 12), nblk - 2):
+    ref = ch[0, J, 0]
+    qs = [k for k in range(tl.shape[0]) if tl[k, 0] and kind[k] == 3 and bb[k] == 0 and Ii[k] == J + 2 and Jc[k] == J]
+    ss = [k for k in range(tl.shape[0]) if tl[k, 0] and kind[k] == 0 and bb[k] == 0 and Ii[k] == J + 2 and Jc[k] == J]
+    sq = "  ".join(f"[{(tl[k,1]-ref)/100:5.1f} {(tl[k,2]-ref)/100:5.1f} {(tl[k,3]-ref)/100:5.1f} {(tl[k,6]-ref)/100:5.1f}]" for k in qs)
+    st = "  ".join(f"[{(tl[k,0]-ref)/100:6.1f} {(tl[k,2]-ref)/100:5.1f} {(tl[k,4]-ref)/100:5.1f} {(tl[k,3]-ref)/100:5.1f} {(tl[k,5]-ref)/100:5.1f} {(tl[k,6]-ref)/100:5.1f}]" for k in ss)
+    print(f"{J:2d} | {(ch[0, J, 1] - ref) / 100:5.1f} | {sq} | {st}")
