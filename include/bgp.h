@@ -220,8 +220,8 @@ int bgp_sample_y_batch(bgp_ctx* ctx, int B, const int* pidx, const double* h_ker
  * context creation: BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
  * (see bgp_set_persist) and the A/B switches BGP_KBUILD1=1 (unpipelined Gram build), BGP_SMALL_SPLIT=1 (n <= 128 through
  * the two-launch path), BGP_FUSED_GRAM=1 (Gram tiles generated inside the first trailing update); process-wide:
- * BGP_PANEL_WIDTH, BGP_ROWQUAD_T, BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_NCRIT, BGP_PS_TRACE
- * (DESIGN.md sections 6 and 10).  A BGP_* variable the library does not read is reported once on stderr. */
+ * BGP_PANEL_WIDTH, BGP_ROWQUAD_T, BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_NCRIT, BGP_PS_TRACE,
+ * BGP_PS_PAIR, BGP_PS_PSPLIT, BGP_PS_STREAM, BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  A BGP_* variable the library does not read is reported once on stderr. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */
@@ -239,7 +239,8 @@ int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
 /* Launch-free factorisation of small batches (one persistent kernel per bgp_lml_batch call -- and per covariance of
  * bgp_sample_y -- instead of ~3 launches per block column; same bits): 1 = whenever the batch fits (<= 64 matrices,
  * n > 128), 0 = never, -1 = as BGP_PERSIST says (unset: where it measured faster on MI355X: at least 6 block columns of
- * 128, matrices x block columns <= 400).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
+ * 128, matrices x block columns <= 400; and -- with two chain workgroups per matrix -- few matrices from 3 block columns on:
+ * bgp_persist_auto_rule / bgp_pair_auto_rule).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
  * sklearn/_gpr.py:587. */
 int bgp_set_persist(bgp_ctx* ctx, int mode);
 /* Bookkeeping of that path: out[0] = launch-free calls enqueued by this context, out[1] = of which timed out (a wait

@@ -10,7 +10,13 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SUM=$OUT/${TAG}_pmc.txt
 : > $SUM
-for shape in "lml 1024 8 32 20" "lml 2048 16 16 20" "lml 4096 32 1 20" "cov 1000 8 10000 6"; do
+# second argument "pairs": the shapes the chain pairs take (bgp_pair_auto_rule) instead of the single-chain ones
+if [ "${2:-}" = "pairs" ]; then
+  SHAPES=("lml 4096 32 1 20" "lml 2048 16 1 20" "lml 2048 16 2 20" "lml 1024 8 8 20")
+else
+  SHAPES=("lml 1024 8 32 20" "lml 2048 16 16 20" "lml 4096 32 1 20" "cov 1000 8 10000 6")
+fi
+for shape in "${SHAPES[@]}"; do
   name=$(echo $shape | tr ' ' '_')
   echo "===== $shape" >> $SUM
   python3 $ROOT/tools/lf_shape.py $shape >> $SUM 2>/dev/null
