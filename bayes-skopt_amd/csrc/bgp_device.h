@@ -43,6 +43,23 @@ static __device__ __forceinline__ bool ps_wait_ge(const unsigned* p, unsigned wa
     }
   }
 }
+// ... for TWO words at once (both requested before either is looked at: one round trip to the flags instead of two)
+static __device__ __forceinline__ bool ps_wait_ge2(const unsigned* p, unsigned want, const unsigned* q, unsigned wantq, unsigned* err,
+                                                   unsigned long long limit) {
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned it = 0;; it++) {
+    const unsigned a = ps_ld(p), b = ps_ld(q);
+    if (a >= want && b >= wantq) return true;
+    __builtin_amdgcn_s_sleep(2);
+    if ((it & 15) == 15) {
+      if (ps_ld(err) != 0) return false;
+      if (wall_clock64() - t0 > limit) {
+        ps_st(err, 1u);
+        return false;
+      }
+    }
+  }
+}
 // EVERY thread, after its last payload store: drain, meet.  Then ONE lane: ps_signal_*.
 static __device__ __forceinline__ void ps_publish_barrier() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

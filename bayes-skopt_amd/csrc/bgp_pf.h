@@ -673,7 +673,7 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
     if (tid == 0) {
       const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
       const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-      const bool ok = ps_wait_ge(subrdy + I, (unsigned)a.psplit, err, a.spin_limit) && ps_wait_ge(diagrdy + I, (unsigned)a.dsplit, err, a.spin_limit);
+      const bool ok = ps_wait_ge2(subrdy + I, (unsigned)a.psplit, diagrdy + I, (unsigned)a.dsplit, err, a.spin_limit);
       ps_acquire();
       *ok_lds = ok ? 1 : 0;
     }

@@ -674,7 +674,7 @@ static __device__ __forceinline__ int ps_ll_update(const PsArgs& a, const double
 #define PS_READY(p) (ps_ld(xrI + (p)) >= 1u && ps_ld(xrJ + (p)) >= 1u)
       while (qq < npan && PS_READY(qq)) qq++;
       if (qq == q) {  // caught up with the factorisation: wait for the next panel
-        ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
+        ok = ps_wait_ge2(xrI + q, 1u, xrJ + q, 1u, err, a.spin_limit);
         qq = q + 1;
         while (ok && qq < npan && PS_READY(qq)) qq++;
       }
@@ -744,7 +744,7 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
         qq = -2;  // caught up at the LAST panel: follow its two blocks column block by column block (below)
       } else {
         if (qq == q) {  // caught up with the factorisation: wait for the next panel
-          ok = ps_wait_ge(xrI + q, 1u, err, a.spin_limit) && ps_wait_ge(xrJ + q, 1u, err, a.spin_limit);
+          ok = ps_wait_ge2(xrI + q, 1u, xrJ + q, 1u, err, a.spin_limit);
           qq = q + 1;
           while (ok && qq < npan && PS_READY(qq)) qq++;
         }
