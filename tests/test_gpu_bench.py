@@ -60,7 +60,7 @@ def test_bench_single_gpu_line():
     assert set(d["shard_projection"]["evals_per_s"]) == {"1", "2", "4", "8"}
     lf = d["launch_free"]
     shapes = {k: v for k, v in lf.items() if k.startswith("n")}
-    assert set(shapes) == {"n4096_B1", "n2048_B16", "n1024_B32"} and all(v["bit_identical"] for v in shapes.values())
+    assert set(shapes) == {"n4096_B1", "n2048_B16", "n1024_B32", "n2048_B1", "n1024_B8"} and all(v["bit_identical"] for v in shapes.values())
     assert all(0 < v["launch_free_ms"] < 3 * v["launches_ms"] for v in shapes.values())
     assert lf["timeouts"] == 0 and all(v["calls"] >= 18 and 0 < v["launch_free_frac"] < 1 for v in shapes.values())
     assert "fresh child process" in lf["measured_in"]
