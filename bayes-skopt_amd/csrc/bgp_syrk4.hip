@@ -523,14 +523,18 @@ void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw
 // their own (the first ncrit of the launch): a task the chain is going to wait for never queues behind a long update
 // (each list is in topological order and together they hold every task: still no deadlock; a workgroup whose pool is
 // exhausted helps the other one).
+// Chain pairs (PsArgs::psplit == 4; bgp_pf.h: pf_pair_helper): the per-column cycle of the chain runs THROUGH the critical tasks, and
+// one CU applies a panel to a 128 x 128 block in 14 us (0.307 TF of fp64 MFMA per CU).  They go out in 64 x 64 QUADRANTS on
+// workgroups of their own (ps_ll_update_quad) -- P(J+2) in four, Dg(J+2) in three, and four quadrants Q of block (J+2, J) AHEAD
+// of the critical solve S(J+2, J), which then only waits for them (s2rdy) and solves -- and every quadrant consumes its LAST
+// panel chunk by chunk behind the blocks that feed it: the chain helper's X_{J+1,J} and the streamed solves (pf_stream_S)
+// publish a count of 16-column blocks that are complete in memory (xcol; write-through stores), chunk c of the panel is column
+// block c.  Order inside a column's critical group: Q, S, P, Dg (still topological: Q waits for solves of column J-1 only).
 // Per C element the operations and their order are those of syrk4_kernel / trsm4_kernel (accumulator = C, MFMA k-steps
 // ascending, A-negate): bit-identical factors.
 // ------------------------------------------------------------------------------------------
-// critical tasks per block column and matrix: S(J+2, J), the np parts of P(J+2) (np = PsArgs::psplit column slices of the block),
-// Dg(J+2)
-// (a P task in np parts; with np == 4 the diagonal block's task Dg goes out in THREE quadrants as well: PS_ND)
-// ... and the pre-update of the block that the column's critical solve S(J+2, J) works on in FOUR quadrants Q (the solve itself
-// only waits for them -- s2rdy -- and solves): PS_NQ
+// critical tasks per block column and matrix: S(J+2, J), the np parts of P(J+2) (np = PsArgs::psplit: 2 column slices or 4
+// quadrants), the PS_ND(np) parts of Dg(J+2) and the PS_NQ(np) quadrants Q ahead of S(J+2, J)
 #define PS_ND(np) ((np) == 4 ? 3 : 1)
 #define PS_NQ(np) ((np) == 4 ? 4 : 0)
 static __host__ __device__ __forceinline__ int ps_crit_per_matrix(int nblk, int np) {
