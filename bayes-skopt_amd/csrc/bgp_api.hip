@@ -256,7 +256,7 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_FUSED_TRSM", "BGP_FUSED_TRSM", "BGP_KBUILD1", "BGP_PANELS",
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
                                 "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_NCRIT", "BGP_PS_PAIR", "BGP_PS_PSPLIT", "BGP_PS_STREAM", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;

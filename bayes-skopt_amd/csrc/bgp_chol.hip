@@ -277,8 +277,6 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
                       int K, int jstart, int colmode, int B, const S4Gen* gen);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k, int augmented);
-void bgp_launch_ptrsm(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
-                      int ystride, int nblk, int k, int kp0, int Kpre);
 
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k) {
@@ -338,37 +336,19 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     // with the LDS-DMA kernels, whose look-ahead column launches are cheap enough), 2 below (P = 2, 3, 4 are equal
     // within noise at n = 1024); BGP_PANELS fixes it.
     const int P = ctx->panels_auto ? (nblk >= 12 ? 4 : 2) : ctx->panels;
-    // BGP_FUSED_TRSM = 1 / 2 / 3 (experiment): no look-ahead column launch for the columns with 1 / <= 2 / <= 3 pending panels --
-    // their panel solve applies them (ptrsm_kernel), a three-tile launch in front of potrf their diagonal block
-    static int fused_trsm = -1;
-    if (fused_trsm < 0) {
-      const char* e = getenv("BGP_FUSED_TRSM");
-      fused_trsm = (e && atoi(e) > 0) ? atoi(e) : 0;
-    }
-    const int ftmax = gen ? 0 : fused_trsm;
     int k = 0;
     while (k < nblk) {
       const int np = std::min(P, nblk - k);
       for (int j = 0; j < np; j++) {
-        const bool ft = j > 0 && j <= ftmax;      // this column's pending panels go into its panel solve
-        const bool ftn = j + 1 <= ftmax;          // ... and the next column's into ITS panel solve: no look-ahead launch for it
-        if (ft) {  // the diagonal block of column k+j with the panels k .. k+j-1
-          bgp_tbegin(ctx, 5, st);
-          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * j, k + j, 3, B, nullptr);
-          bgp_tend(ctx, st);
-        }
         bgp_tbegin(ctx, 1, st);
         hipLaunchKernelGGL((potrf_kernel<0, 0, 0>), dim3(B), dim3(PF_THREADS), 0, st, dK, dW, dyw, dacc, dlml, dstatus,
                            ctx->n, ld, mstride, ystride, nblk, k + j, PfGen());
         bgp_tend(ctx, st);
         if (k + j + 1 >= nblk) break;
         bgp_tbegin(ctx, 2, st);
-        if (ft)
-          bgp_launch_ptrsm(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, k, 128 * j);
-        else
-          bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
+        bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k + j, 0);
         bgp_tend(ctx, st);
-        if (!ftn && j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
+        if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 5, st);
           bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
           bgp_tend(ctx, st);

@@ -265,13 +265,11 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
 }
 
 // Tile list of one launch, in blocks of T rows:  nt128 = trailing 128-row blocks, colmode 0: every tile with
-// I >= J, colmode 1: only the tiles inside the first 128 columns (the look-ahead block column), colmode 3: only the diagonal
-// 128 x 128 block of that column.
+// I >= J, colmode 1: only the tiles inside the first 128 columns (the look-ahead block column).
 template <int T>
 static __host__ __device__ __forceinline__ int s4_ntile(int nt128, int colmode) {
   const int nt = nt128 * (128 / T);
   if (!colmode) return nt * (nt + 1) / 2;
-  if (colmode == 3) return (T == 128) ? 1 : 3;  // the diagonal 128 x 128 block of the block column only
   return (T == 128) ? nt : 2 * nt - 1;
 }
 
@@ -341,9 +339,6 @@ static __device__ __forceinline__ S4Tile s4_decode(int q, int total, int ntile, 
       break;
     } else if (!colmode) {
       s4_panel_decode(t, nt128 * (128 / T), ti, tj, pw);
-    } else if (colmode == 3) {  // (0,0), (1,0), (1,1) of the block's 64-row tiles
-      ti = (T == 128) ? 0 : (t > 0 ? 1 : 0);
-      tj = (T == 128) ? 0 : (t > 1 ? 1 : 0);
     } else if (T == 128 || t < nt128 * 2) {
       ti = t;
       tj = 0;
@@ -499,156 +494,6 @@ __global__ void __launch_bounds__(256, 3)
     part += __shfl_xor(part, 8);
     if ((lane & 15) == 0) yi[row] -= part;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// Panel solve of a block column INSIDE a multi-panel group (bgp_chol.hip): the group's earlier panels kp0 .. k-1 (Kpre = 128 (k -
-// kp0) columns) have not been applied to column k yet -- the look-ahead column launch of syrk4_kernel that did it read and wrote
-// every block of the column for as little as 128 columns of work (HBM-bound at K = 128: 39 TF).  Here a workgroup applies them to
-// its 64 x 128 half block and solves it in one pass over memory:
-//   1. A -= X_i X_k^T on the ring (64 rows of X_i + the 128 rows of block row k's panel per chunk), waves as 2 x 2 with 32 x 64
-//      each (2 x 4 MFMA tiles: syrk4_kernel's arithmetic -- accumulator = the block, k ascending, A-negate);
-//   2. the updated half block goes through LDS, 64 columns at a time, from the accumulators' layout (wave = 32 x 64) into
-//      A-operand fragments in registers (wave = 16 rows x 128 columns, 32 doubles per lane: it never returns to memory);
-//   3. X = A W_kk^T with the A operand from those registers and W_kk's chunks on a two-stage ring, right-hand side and in-place
-//      store as trsm4_kernel (same operations per element, same order).
-// 52 KB of LDS: three workgroups per CU.
-// ------------------------------------------------------------------------------------------
-#define PT_TLD 66  // doubles per row of the 64 x 64 transposition tile
-__global__ void __launch_bounds__(256, 3)
-    ptrsm_kernel(double* __restrict__ Kbuf, const double* __restrict__ Wbuf, double* __restrict__ yw,
-                 const int* __restrict__ status, int ld, size_t mstride, int ystride, int nblk, int k, int B, int kp0, int Kpre) {
-  constexpr unsigned AOPB = 64 * S4_ROWB, STAGEB = (64 + 128) * S4_ROWB;  // phase 1 ring: two stages of 64 + 128 rows
-  constexpr unsigned WS0 = 36864, WS1 = 0, WSTB = 128 * S4_ROWB;          // phase 3 ring: W_kk's chunks
-  static_assert(64 * PT_TLD * 8 <= WS0 && 2 * STAGEB <= WS0 + WSTB, "LDS layout");
-  const int nrb = nblk - k - 1;
-  int b, t;
-  bgp_map_block(blockIdx.x, 2 * nrb, B, b, t);
-  if (b >= B || status[b] != 0) return;
-  __shared__ __attribute__((aligned(1024))) char smem[WS0 + WSTB];
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  double* const Th = reinterpret_cast<double*>(smem);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lk = lane >> 4;
-  const int ib = k + 1 + (t >> 1), half = t & 1;
-  double* const Mb = Kbuf + (size_t)b * mstride;
-  double* A = Mb + (size_t)(ib * 128 + half * 64) * ld + k * 128;
-  const double* W = Wbuf + ((size_t)b * nblk + k) * (128 * 128);
-  unsigned voffA[2], voffB[4], voffW[4];
-  s4_src<64>(voffA, ld, w, lane);
-  s4_src<128>(voffB, ld, w, lane);
-  s4_src<128>(voffW, 128, w, lane);
-  double af[32];
-  {
-    // ---- 1. the pending panels
-    const double* const XA = Mb + (size_t)(ib * 128 + half * 64) * ld + kp0 * 128;
-    const double* const XB = Mb + (size_t)(k * 128) * ld + kp0 * 128;
-    const int wr = w >> 1, wc = w & 1;
-    unsigned pa[4], pb[4];
-    s4_frag_addr(pa, lds0, wr * 32, lane);
-    s4_frag_addr(pb, lds0 + AOPB, wc * 64, lane);
-    d4 acc[2][4];
-    s4_issue<64>(XA, voffA, 0, lds0, w);
-    s4_issue<128>(XB, voffB, 0, lds0 + AOPB, w);
-    gk_load_c<2, 4, -64>(A, (size_t)ld, acc, wr * 32, wc * 64, lane);
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 4; j++) asm volatile("" : "+v"(acc[i][j]));  // (the block's loads are waited for here, not inside the loop)
-    const int nch = Kpre / S4_KC;
-    for (int c = 0; c < nch; c += 2) {
-#pragma unroll
-      for (int s = 0; s < 2; s++) {
-        S4_WAIT_VM0();
-        __builtin_amdgcn_s_barrier();
-        if (c + s + 1 < nch) {
-          const unsigned nb = lds0 + (unsigned)((s ^ 1) * STAGEB);
-          s4_issue<64>(XA, voffA, (c + s + 1) * S4_KC, nb, w);
-          s4_issue<128>(XB, voffB, (c + s + 1) * S4_KC, nb + AOPB, w);
-        }
-        s4_mma<2, 4, -64, 0, 1>(pa, pb, s * STAGEB, acc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();  // the ring is free
-    s4_issue_from<128>(W, voffW, 0, lds0 + WS0, w, 0);  // (W_kk's first chunk flies under the transposition: its stage lies behind the tile)
-    // ---- 2. accumulators -> A fragments, 64 columns at a time
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      if (wc == h) {
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) Th[(wr * 32 + i * 16 + lk + 4 * r) * PT_TLD + j * 16 + lr] = acc[i][j][r];
-      }
-      pf_lds_barrier();  // (LDS only: W_kk's first chunk stays in flight)
-#pragma unroll
-      for (int tt = 0; tt < 16; tt++) af[16 * h + tt] = Th[(16 * w + lr) * PT_TLD + 4 * tt + lk];
-      pf_lds_barrier();
-    }
-  }
-  // ---- 3. the solve: chunk c (k in [16 c, 16 c + 16)) reaches the column blocks j >= c
-  const int r0 = w * 16;
-  unsigned pw0[4], pw1[4];
-  s4_frag_addr(pw0, lds0 + WS0, 0, lane);
-  s4_frag_addr(pw1, lds0 + WS1, 0, lane);
-  typedef __attribute__((address_space(3))) const double* lds_cdp;
-  d4 acc[1][8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) acc[0][j] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    S4_WAIT_VM0();
-    __builtin_amdgcn_s_barrier();  // chunk c of W_kk has landed for everybody; everybody is done with chunk c - 1
-    if (c + 1 < 8) s4_issue_from<128>(W, voffW, (c + 1) * S4_KC, lds0 + (((c + 1) & 1) ? WS1 : WS0), w, 16 * (c + 1));
-    const unsigned(&pw)[4] = (c & 1) ? pw1 : pw0;
-    double bb[2][8];
-#pragma unroll
-    for (int j = c; j < 8; j++) bb[0][j] = *(lds_cdp)(uintptr_t)(pw[0] + j * 16 * S4_ROWB);
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      const int cur = kk & 1, nxt = cur ^ 1;
-      if (kk < 3) {
-#pragma unroll
-        for (int j = c; j < 8; j++) bb[nxt][j] = *(lds_cdp)(uintptr_t)(pw[kk + 1] + j * 16 * S4_ROWB);
-      }
-#pragma unroll
-      for (int j = c; j < 8; j++) acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[4 * c + kk], bb[cur][j], acc[0][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // in place (this workgroup's rows were read into its registers long ago), right-hand side as trsm4_kernel
-  const double* zk = yw + (size_t)b * ystride + k * 128;
-  double zc[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) zc[j] = zk[GK_COLB(0, j, lane)];
-  double* yi = yw + (size_t)b * ystride + ib * 128 + half * 64;
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    const int row = GK_ROWB(r0, 0, lane, r);
-    double part = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const double x = acc[0][j][r];
-      A[(size_t)row * ld + GK_COLB(0, j, lane)] = x;
-      part += x * zc[j];
-    }
-    part += __shfl_xor(part, 1);
-    part += __shfl_xor(part, 2);
-    part += __shfl_xor(part, 4);
-    part += __shfl_xor(part, 8);
-    if ((lane & 15) == 0) yi[row] -= part;
-  }
-}
-
-void bgp_launch_ptrsm(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
-                      int ystride, int nblk, int k, int kp0, int Kpre) {
-  const int B8 = 8 * ((B + 7) / 8);
-  hipLaunchKernelGGL(ptrsm_kernel, dim3(B8 * 2 * (nblk - k - 1)), dim3(256), 0, st, dK, dW, dyw, dstatus, ld, mstride, ystride,
-                     nblk, k, B, kp0, Kpre);
 }
 
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
