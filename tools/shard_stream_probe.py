@@ -1,5 +1,11 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo")
+#!/usr/bin/env python3
+"""Wall time of one LML call for the per-GPU shares of config C's strong-scaling split (16 / 32 / 64 matrices of n = 2048, d = 16)
+under whatever BGP_STREAMS / BGP_PERSIST the environment sets.  usage: BGP_STREAMS=2 BGP_PERSIST=0 shard_stream_probe.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bayes_skopt_amd
 from bayes_skopt_amd import _lib
