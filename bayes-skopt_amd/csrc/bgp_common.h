@@ -309,7 +309,8 @@ static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B 
 //   n = 4096 x 1 / 2 (3: 2.470 -> 2.682): 1.725 / 2.110 -> 1.352 / 2.026;   not 6144 x 1 (2.616 -> 2.753), 8192 x 1, 10 112 x 1; not 1024 x 32 (0.536 -> 0.735)
 static inline bool bgp_pair_auto_rule(int nblk, int nb) {
   if (nblk < 3) return false;
-  if (nblk <= 12) return nb <= 16 && nb * nblk <= 128;
+  if (nblk <= 10) return nb <= 16 && nb * nblk * nblk <= 1200;  // (1280 x 12: 0.601 -> 0.554, 1152 x 14: 0.543 -> 0.500, 896 x 16: 0.414 -> 0.369)
+  if (nblk <= 12) return nb <= 8;  // (1408 x 8: 0.622 -> 0.588, x 9: 0.647 -> 0.726; 1536 x 8: 0.679 -> 0.668, x 9: 0.717 -> 0.854)
   return nblk <= 40 && nb <= 2;
 }
 static inline bool bgp_persist_auto_rule(int nblk, int nb) {
