@@ -239,7 +239,12 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
       const char* e = getenv("BGP_PS_NCRIT");
       ncf = e ? atoi(e) : -1;
     }
-    a.ncrit = ncf >= 0 ? ncf : (nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2) : 0);
+    // Chain pairs with more block columns: their 12 critical tasks per column and matrix are SHORT (quadrants that follow their
+    // inputs) and numerous -- behind the long bulk solves of one list they start late: a pool of 48 (one matrix) / 96 workgroups
+    // (n = 4096 x 1: 1.361 -> 1.330 ms, x 2: 2.022 -> 1.861; 1536 x 4: 0.588 -> 0.545, x 8: 0.666 -> 0.578, x 9: 0.847 -> 0.651)
+    const int auto_crit = nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2)
+                                     : (a.pair && a.psplit == 4 ? std::min(B == 1 ? 48 : 96, tile_wgs / 2) : 0);
+    a.ncrit = ncf >= 0 ? ncf : auto_crit;
     if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
   }
   a.spin_limit = limit;

@@ -300,18 +300,21 @@ static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B 
 // So: at least 6 block columns, matrices x block columns <= 400 (beyond that the tile side is the bound and the launch
 // schedule's kernels are the better tile workers), and >= 100 unless there are at least 12 block columns.
 // Chain PAIRS (two chain workgroups per matrix that alternate over the block columns; the critical pre-updates in quadrants that
-// follow the chain's and the streamed solves' blocks column block by column block: bgp_pf.h) win where the chain is the bound
-// -- few matrices.  Wall time per LML call, best of {launches, launch-free} -> pairs (tools/persist_probe.py, MI355X, round 4):
-//   n =  384 x 1: 0.173 -> 0.159;   512 x 1 / 4 / 8: 0.220 / 0.225 / 0.223 -> 0.197 / 0.203 / 0.218;   640 x 4: 0.282 -> 0.243
-//   n =  768 x 1 / 8 / 16: 0.318 / 0.326 / 0.356 -> 0.271 / 0.314 / 0.317;   1024 x 1 / 8 / 16: 0.413 / 0.447 / 0.475 -> 0.349 / 0.414 / 0.435
-//   n = 1280 x 4 / 12: 0.544 / 0.593 -> 0.454 / 0.558;   1536 x 1 / 4 / 8 (12: 0.728 -> 0.990): 0.648 / 0.665 / 0.677 -> 0.503 / 0.597 / 0.669
-//   n = 2048 x 1 / 2 (4: 0.891 -> 0.908, 8: 0.923 -> 1.127): 0.855 / 0.865 -> 0.660 / 0.686;   3072 x 1 / 2 (3: 1.467 -> 1.555): 1.327 / 1.334 -> 1.020 / 1.304
-//   n = 4096 x 1 / 2 (3: 2.470 -> 2.682): 1.725 / 2.110 -> 1.352 / 2.026;   not 6144 x 1 (2.616 -> 2.753), 8192 x 1, 10 112 x 1; not 1024 x 32 (0.536 -> 0.735)
+// follow the chain's and the streamed solves' blocks column block by column block, on a critical pool of their own: bgp_pf.h,
+// bgp_chol.hip) win where the chain is the bound -- few matrices.  Wall ms per LML call, best of {launches, launch-free} ->
+// pairs (tools/persist_probe.py, MI355X, round 4):
+//   n =  384 x 1: 0.173 -> 0.159;   512 x 1 / 4 / 8: 0.220 / 0.225 / 0.223 -> 0.197 / 0.203 / 0.218;   768 x 1 / 16: 0.318 / 0.356 -> 0.271 / 0.317
+//   n = 1024 x 1 / 8 / 16 (32: 0.528 -> 0.630): 0.413 / 0.447 / 0.475 -> 0.349 / 0.414 / 0.430;   1280 x 12: 0.601 -> 0.554;   1152 x 14: 0.543 -> 0.500
+//   n = 1408 x 9 / 12 (16: 0.663 -> 0.671): 0.639 / 0.652 -> 0.611 / 0.624;   1536 x 1 / 4 / 8 / 9 / 12 (16: 0.763 -> 0.789): 0.650 / 0.664 / 0.675 / 0.712 / 0.729 -> 0.506 / 0.546 / 0.579 / 0.659 / 0.722
+//   n = 1792 x 4 / 8 (12: 0.919 -> 0.953): 0.765 / 0.789 -> 0.623 / 0.662;   2048 x 1 / 2 / 4 / 8 (12: 1.207 -> 1.284, 16: 1.305 -> 1.503): 0.861 / 0.865 / 0.889 / 0.925 -> 0.653 / 0.673 / 0.746 / 0.839
+//   n = 2560 x 4 / 6 (8: 1.275 -> 1.381): 1.154 / 1.234 -> 1.081 / 1.230;   3072 x 1 / 2 / 3 / 4 (6: 1.798 -> 1.908): 1.326 / 1.341 / 1.473 / 1.639 -> 1.023 / 1.195 / 1.399 / 1.609
+//   n = 3584 x 2 / 3 (4: 2.191 -> 2.179): 1.636 / 1.904 -> 1.504 / 1.817;   4096 x 1 / 2 / 3 (4: 2.831 -> 2.969): 1.730 / 2.112 / 2.472 -> 1.327 / 1.862 / 2.398
+//   n = 4992 x 1 / 5120 x 1 (x 2: 2.906 -> 2.893) / 6144 x 1: 2.113 / 2.190 / 2.629 -> 1.601 / 1.641 / 2.326;   not 7168 x 1 (3.195 -> 3.189), 8192 x 1 (4.201 -> 4.406), 10 112 x 1
 static inline bool bgp_pair_auto_rule(int nblk, int nb) {
   if (nblk < 3) return false;
-  if (nblk <= 10) return nb <= 16 && nb * nblk * nblk <= 1200;  // (1280 x 12: 0.601 -> 0.554, 1152 x 14: 0.543 -> 0.500, 896 x 16: 0.414 -> 0.369)
-  if (nblk <= 12) return nb <= 8;  // (1408 x 8: 0.622 -> 0.588, x 9: 0.647 -> 0.726; 1536 x 8: 0.679 -> 0.668, x 9: 0.717 -> 0.854)
-  return nblk <= 40 && nb <= 2;
+  if (nblk <= 10) return nb <= 16 && nb * nblk * nblk <= 1200;
+  if (nblk <= 12) return nb <= 12;
+  return nb <= 8 && nb * nblk * nblk <= (nb <= 3 ? 3100 : 2400);  // (the tile side's work goes with matrices x block columns^2)
 }
 static inline bool bgp_persist_auto_rule(int nblk, int nb) {
   return bgp_pair_auto_rule(nblk, nb) || (nblk >= 6 && nb * nblk <= 400 && (nblk >= 12 || nb * nblk >= 100));
