@@ -231,7 +231,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int tile_wgs = std::min(a.total, ncu - a.nchain);
   {
     // critical pool of the tile role: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
-    // workgroups of their own, one per task of a column.  Measured: with up to ~10 block columns the chain waits less
+    // workgroups of their own, one per task of a column.  Measured in round 3: with up to ~10 block columns the chain waits less
     // (n = 1024 x 32: 0.63 -> 0.59 ms, 975 x 50: 0.93 -> 0.84); with more, these left-looking tasks are long and want the
     // look-ahead the single list gives them (n = 2048 x 9: 1.20 -> 1.37 ms with the pool).  BGP_PS_NCRIT fixes the number.
     static int ncf = -2;
@@ -242,7 +242,10 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     // Chain pairs with more block columns: their 12 critical tasks per column and matrix are SHORT (quadrants that follow their
     // inputs) and numerous -- behind the long bulk solves of one list they start late: a pool of 48 (one matrix) / 96 workgroups
     // (n = 4096 x 1: 1.361 -> 1.330 ms, x 2: 2.022 -> 1.861; 1536 x 4: 0.588 -> 0.545, x 8: 0.666 -> 0.578, x 9: 0.847 -> 0.651)
-    const int auto_crit = nblk <= 10 ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2)
+    // One chain workgroup per matrix, re-measured at the end of round 4: the pool only pays from ~40 matrices on (975 x 50: 0.743 ->
+    // 0.725 ms, 896 x 48: 0.543 -> 0.527); below, the single list is 2-5 % faster now (1024 x 32: 0.528 -> 0.518, x 24: 0.518 ->
+    // 0.493, 1152 x 24: 0.580 -> 0.555, 975 x 25: 0.525 -> 0.508)
+    const int auto_crit = nblk <= 10 ? ((a.pair || B > 32) ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2) : 0)
                                      : (a.pair && a.psplit == 4 ? std::min(B == 1 ? 48 : 96, tile_wgs / 2) : 0);
     a.ncrit = ncf >= 0 ? ncf : auto_crit;
     if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
