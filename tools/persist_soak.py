@@ -8,7 +8,9 @@ import numpy as np
 import bayes_skopt_amd  # noqa
 from bayes_skopt_amd import _lib
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for n, d, B in ((2048, 16, 16), (4096, 32, 1), (2048, 16, 9), (4096, 32, 8), (2048, 16, 1), (3000, 8, 5)):
+# (single chain workgroup: 2048 x 16, 2048 x 9, 4096 x 8, 3000 x 5; chain pairs: 4096 x 1 / 2, 2048 x 1 / 8, 1536 x 12, 1024 x 16, 640 x 3)
+for n, d, B in ((2048, 16, 16), (4096, 32, 1), (2048, 16, 9), (4096, 32, 8), (2048, 16, 1), (3000, 8, 5), (4096, 32, 2), (2048, 16, 8),
+                (1536, 12, 12), (1024, 8, 16), (640, 4, 3)):
     rng = np.random.RandomState(0)
     X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
     ctx = _lib.Context(X, y, np.full(n, 1e-10), max_batch=B)
