@@ -85,6 +85,26 @@ def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit
     assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
 
 
+@pytest.mark.parametrize("switches", [
+    {"BGP_PS_PAIR": "1", "BGP_PS_STREAM": "0"},   # chain pairs, no panel solve follows the factorisation row block by row block
+    {"BGP_PS_PAIR": "1", "BGP_PS_STREAM": "2"},   # ... only the column's critical one
+    {"BGP_PS_PAIR": "1", "BGP_PS_PSPLIT": "2"},   # the critical pre-update in two column slices (no quadrants, no Q tasks)
+    {"BGP_PS_PAIR": "1", "BGP_PS_PSPLIT": "1"},   # ... whole
+    {"BGP_PS_PAIR": "0", "BGP_PS_PSPLIT": "4"},   # quadrant tasks behind ONE chain workgroup per matrix
+    {"BGP_PS_PAIR": "1", "BGP_PS_NCRIT": "5"},    # fewer pool workgroups than critical tasks of a column
+], ids=lambda d: ",".join(f"{k[7:]}={v}" for k, v in d.items()))
+def test_the_documented_switches_of_the_launch_free_path_keep_the_bits(switches):
+    """INTEGRATION.md lists BGP_PS_PAIR / BGP_PS_PSPLIT / BGP_PS_STREAM / BGP_PS_NCRIT: whatever they are set to, the factors,
+    statuses and log-likelihoods are those of the launch schedule (failing matrices included)."""
+    shapes = [(1024, 8, 5), (2048, 16, 2), (640, 5, 3), (1536, 4, 9)]
+    ref, _ = _run({"BGP_PERSIST": "0"}, shapes)
+    got, err = _run(dict({"BGP_PERSIST": "1"}, **switches), shapes)
+    assert "timed out" not in err, err[-1500:]
+    for k in ref:
+        assert got[k]["lml"] == ref[k]["lml"] and got[k]["status"] == ref[k]["status"], k
+        assert got[k]["Lsum"] == ref[k]["Lsum"] and got[k]["zsum"] == ref[k]["zsum"], k
+
+
 def test_a_wait_that_times_out_falls_back_with_the_right_answer():
     """BGP_PS_TIMEOUT_MS bounds every in-kernel wait.  With an absurdly small bound the first waits give up, both
     kernels drain, the host says so once and redoes the batch on the multi-launch path: same bits, no hang."""
