@@ -42,9 +42,21 @@ class BayesGPR(RegressorMixin, BaseEstimator):
     """Gaussian process regressor of which the kernel hyper-parameters are inferred in a fully
     Bayesian framework (constructor arguments as ``bask/bayesgpr.py:148-159``).
 
-    Extra, MI355X-specific keyword: ``device`` (HIP device ordinal, default 0) and
-    ``max_batch`` (matrices factorised concurrently; default = half the walkers).
+    Extra, MI355X-specific keyword: ``device`` (HIP device ordinal, default 0),
+    ``max_batch`` (matrices factorised concurrently; default = half the walkers) and ``mvn`` -- how
+    ``sample_y`` turns a predictive mean / covariance into function draws:
+
+    * ``"reference"``: mean and covariance come from the device, the draw is numpy's legacy
+      ``RandomState.multivariate_normal`` (SVD) on the host, exactly what the reference does
+      (``sklearn/_gpr.py:522-526`` behind ``bask/bayesgpr.py:669-718``): a seeded call returns the
+      reference's own variates;
+    * ``"cholesky"``: ``mean + chol(cov + jitter I) z`` entirely on the device (same distribution, other
+      variates; the only practical choice for thousands of query points, where the SVD takes minutes);
+    * ``"auto"`` (default): ``"reference"`` up to ``MVN_REFERENCE_MAX_POINTS`` (256) query points,
+      ``"cholesky"`` beyond.  The generator is consumed identically in both modes.
     """
+
+    MVN_REFERENCE_MAX_POINTS = 256
 
     def __init__(
         self,
@@ -60,6 +72,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         device=0,
         max_batch=None,
         shard_ensemble=False,
+        mvn="auto",
     ):
         self._kernel = None if kernel is None else kernel.clone_with_theta(kernel.theta)
         self.kernel = kernel
@@ -77,6 +90,9 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         # exact single-ensemble sharding over the ranks of an initialised process group
         # (distributed.shard_log_prob; every rank must be constructed with the same random_state/data)
         self.shard_ensemble = bool(shard_ensemble)
+        if mvn not in ("auto", "reference", "cholesky"):
+            raise ValueError("mvn must be 'auto', 'reference' or 'cholesky', got %r" % (mvn,))
+        self.mvn = mvn
         self._sampler = None
         self.chain_ = None
         self.pos_ = None
@@ -731,20 +747,39 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % status)
         return self._ctx.pvrs(Hk, X, np.atleast_2d(thompson_points))
 
-    def sample_y(self, X, sample_mean=False, noise=False, n_samples=1, random_state=0):
-        """Function realisations of the GP(s) (``bask/bayesgpr.py:637-718``).  The multivariate
-        normal draw uses a device Cholesky factor of the predictive covariance instead of numpy's
-        SVD (``sklearn/_gpr.py:522-526``): same distribution, different variates."""
+    def _mvn_mode(self, m, mvn=None):
+        """'reference' (numpy's SVD draw on the host from the device-built mean / covariance) or 'cholesky' (device)."""
+        mode = self.__dict__.get("mvn", "auto") if mvn is None else mvn
+        if mode not in ("auto", "reference", "cholesky"):
+            raise ValueError("mvn must be 'auto', 'reference' or 'cholesky', got %r" % (mode,))
+        if mode == "auto":
+            mode = "reference" if m <= self.MVN_REFERENCE_MAX_POINTS else "cholesky"
+        return mode
+
+    def sample_y(self, X, sample_mean=False, noise=False, n_samples=1, random_state=0, mvn=None):
+        """Function realisations of the GP(s) (``bask/bayesgpr.py:637-718``).  Predictive means and
+        covariances are built on the device; the multivariate normal draw is numpy's legacy SVD draw on the
+        host (``mvn="reference"``: the reference's own variates, ``sklearn/_gpr.py:522-526``) or
+        ``mean + chol(cov) z`` on the device (``mvn="cholesky"``: same distribution, other variates).
+        ``mvn=None`` takes the estimator's setting (default ``"auto"``: reference variates up to
+        ``MVN_REFERENCE_MAX_POINTS`` query points)."""
         rng = check_random_state(random_state)
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        mode = self._mvn_mode(X.shape[0], mvn)
         if sample_mean:
             cm = nullcontext(self) if noise else self.noise_set_to_zero()
             with cm:
+                if mode == "reference":
+                    # sklearn's sample_y: predict(return_cov=True), then rng.multivariate_normal(mean, cov, n).T
+                    y_mean, y_cov = self.predict(X, return_cov=True)
+                    return _legacy_mvn(rng, y_mean, y_cov, n_samples).T
                 return self._draw(X, n_samples, rng)
         # hyper-posterior draws: one chain row (with replacement) and one function per sample.  The generator is
         # consumed in the reference's order -- all row indices first, then one normal vector per sample -- and the
-        # device builds all posteriors and factorises all predictive covariances in batched calls.
+        # device builds all posteriors and predictive covariances in batched calls.
         ind = rng.choice(len(self.chain_), size=n_samples, replace=True)
+        if mode == "reference":
+            return self._draw_rows_reference(self.chain_[ind], X, rng, noise).T
         Z = np.vstack([rng.standard_normal((1, X.shape[0])) for _ in range(n_samples)])
         return self._draw_rows(self.chain_[ind], X, Z, noise).T
 
@@ -754,11 +789,70 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         chosen chain row with the noise off -- same generator consumption here (row index, then the normal vector,
         per draw), one batched device call for all draws.  Returns (n_draws, m)."""
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        if self._mvn_mode(X.shape[0]) == "reference":
+            # row index and MVN draw alternate on the generator, as in the reference's loop: the rows cannot be chosen
+            # ahead of the draws, so every draw is one device predict (mean, covariance) + one host SVD
+            out = np.empty((n_draws, X.shape[0]))
+            for i in range(n_draws):
+                row = self.chain_[rng.choice(len(self.chain_), size=1, replace=True)[0]]
+                out[i] = self._draw_rows_reference(row[None, :], X, rng, noise=False)[0]
+            return out
         rows, Z = [], []
         for _ in range(n_draws):
             rows.append(self.chain_[rng.choice(len(self.chain_), size=1, replace=True)[0]])
             Z.append(rng.standard_normal((1, X.shape[0])))
         return self._draw_rows(np.array(rows), X, np.vstack(Z), noise=False)
+
+    def _draw_rows_reference(self, rows, X, rng, noise):
+        """The reference's per-sample loop (``bask/bayesgpr.py:679-706``) with the device doing what the theta setter
+        and ``predict(return_cov=True)`` do there -- ONE batched posterior build over the distinct chain rows, the
+        predictive means / covariances in chunks -- and the host doing what numpy does there: one legacy
+        ``multivariate_normal`` (SVD) per sample, in sample order, on the caller's generator.  (len(rows), m)."""
+        rows = np.atleast_2d(rows)
+        n_theta = len(self.kernel_.theta)
+        m = X.shape[0]
+        out = np.empty((len(rows), m))
+        if self.warp_inputs:
+            validate_zeroone(X)
+            d = self._X_train_.shape[1]
+            backup = (np.copy(self.warp_alphas_), np.copy(self.warp_betas_))
+            try:
+                for i, row in enumerate(rows):  # every draw has its own warped training inputs
+                    self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
+                    self.rewarp()
+                    mean, cov = self._mean_cov_rows(row[None, :n_theta], X, noise)
+                    out[i] = _legacy_mvn(rng, mean[0], cov[0], 1)[0]
+            finally:
+                self.create_warpers(*backup)
+                self.rewarp()
+            return out
+        # the covariances of a chunk of samples at a time (m^2 doubles each)
+        chunk = max(1, int((256 << 20) // (8 * m * m)))
+        for lo in range(0, len(rows), chunk):
+            mean, cov = self._mean_cov_rows(rows[lo : lo + chunk, :n_theta], X, noise)
+            for i in range(mean.shape[0]):
+                out[lo + i] = _legacy_mvn(rng, mean[i], cov[i], 1)[0]
+        return out
+
+    def _mean_cov_rows(self, thetas, X, noise):
+        """Predictive mean and covariance (y units) of the GP of every chain row: batched device posterior build over the
+        distinct rows + batched device predict with the full covariance; ``theta`` / ``alpha_`` / ``L_`` stay untouched."""
+        H = self._canonical(thetas)
+        uniq, inverse = np.unique(H, axis=0, return_inverse=True)
+        res = self._ctx.posterior(uniq, want_alpha=False)
+        if np.any(res["status"] != 0):
+            bad = int(np.flatnonzero(res["status"])[0])
+            raise np.linalg.LinAlgError(
+                _PD_MESSAGE % self.kernel_,
+                "%d-th leading minor of the array is not positive definite" % res["status"][bad],
+            )
+        Hk = uniq.copy()
+        if not noise:
+            Hk[:, -1] = -np.inf  # noise_set_to_zero(): the factors keep the noise, the predictive kernel drops it
+        mean, _var, cov = self._ctx.predict(Hk, X, return_cov=True)
+        inverse = np.asarray(inverse).ravel()
+        y_mean = self.y_train_std_ * mean[inverse] + self.y_train_mean_
+        return y_mean, cov[inverse] * self.y_train_std_**2
 
     def _draw_rows(self, rows, X, Z, noise):
         """f_i = mean_i + chol(cov_i) Z[i] for the GP of chain row i (kernel parameters and, with input warping, its
@@ -835,6 +929,13 @@ class BayesGPR(RegressorMixin, BaseEstimator):
                 ctx.close()
             except Exception:
                 pass
+
+
+def _legacy_mvn(rng, mean, cov, n_samples):
+    """``rng.multivariate_normal(mean, cov, n_samples)`` -- numpy's legacy SVD-based draw, the call scikit-learn's
+    ``sample_y`` makes (``sklearn/_gpr.py:522-526``); (n_samples, m).  Its "covariance is not symmetric positive-
+    semidefinite" warning is the reference's too (noise-free predictive covariances are numerically singular)."""
+    return np.atleast_2d(rng.multivariate_normal(np.ravel(mean), cov, n_samples))
 
 
 def _eval_warp_priors(warp_priors, W, d):

@@ -51,12 +51,18 @@
 // ------------------------------------------------------------------------------------------
 #ifdef PF_TRACE  // phase timestamps of workgroup 0 (tools/potrf_bench.hip); compiled out of the product library
 __device__ unsigned long long pf_trace[32];
+__device__ unsigned long long pf_trace_w[8 * 32];  // per wave: [2 sb] start of the wave's step, [2 sb + 1] its end (before the barrier)
 #define PF_T(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) pf_trace[i] = wall_clock64(); } while (0)
+#define PF_TW(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) pf_trace_w[(threadIdx.x >> 6) * 32 + (i)] = wall_clock64(); } while (0)
 extern "C" int bgp_debug_potrf_trace(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_trace), sizeof(pf_trace)) == hipSuccess ? 0 : 1;
 }
+extern "C" int bgp_debug_potrf_trace_w(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pf_trace_w), sizeof(pf_trace_w)) == hipSuccess ? 0 : 1;
+}
 #else
 #define PF_T(i)
+#define PF_TW(i)
 #endif
 #include "bgp_pf.h"
 

@@ -9,6 +9,9 @@
 #ifndef PF_T
 #define PF_T(i)
 #endif
+#ifndef PF_TW
+#define PF_TW(i)
+#endif
 #define PF_LD 130   // LDS leading dimension of the 128x128 block (== 2 mod 32: conflict-free MFMA operand reads)
 #define PF_MLD 18   // leading dimension of the 16x16 inverse blocks
 
@@ -341,6 +344,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   const int u6 = (w < 4) ? w - 1 : w - 2;  // 0..5 for the update waves
 #pragma unroll 1
   for (int sb = 0; sb < 8; sb++) {
+    PF_TW(2 * sb);
     if (w == 0) {
       if (sb > 1) {  // pending panel block of the previous row
 #pragma unroll
@@ -458,6 +462,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       if (sb == 7) w7 = pf_wsum(w7, s, Minv, nullptr, 7, u6, u6, 6, lane);  // block J = u6 (W row 6 went 5 - u6)
       if (wrow) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's W blocks have left the wave
     }
+    PF_TW(2 * sb + 1);
     __syncthreads();
     PF_T(2 + sb * 3);
     failed = fail_lds;

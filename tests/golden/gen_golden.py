@@ -496,7 +496,45 @@ def gen_sample_y(out):
              mean_noisy=mean, cov_noisy=cov)
 
 
+def gen_mvn(out):
+    """SURVEY 8c golden (8): the reference's OWN seeded function draws -- scikit-learn's sample_y (sklearn/_gpr.py:522-526:
+    predict(return_cov=True), then numpy's legacy RandomState.multivariate_normal, i.e. standard normals times the SVD factor of
+    the covariance) as bask/bayesgpr.py:669-678 reaches it: noise switched off (case "nf": WhiteKernel(0) at the query points,
+    factors of the noisy kernel) or left on (case "ny").  m = 6, 24 and 64 query points; the generator state is one
+    RandomState(5) per call, 3 draws each.  The smallest singular value of every covariance is stored: directions whose singular
+    value is numerically zero are arbitrary in ANY implementation and enter a draw with weight sqrt(s)."""
+    n, d = 60, 2
+    X, y = synth(n, d, 77)
+    k = sk.ConstantKernel(1.3) * sk.Matern(length_scale=[0.35, 0.5], nu=2.5) + sk.WhiteKernel(0.02)
+    gpr = GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
+    k0 = sk.ConstantKernel(1.3) * sk.Matern(length_scale=[0.35, 0.5], nu=2.5) + sk.WhiteKernel(1e-300)
+    gpr0 = GaussianProcessRegressor(kernel=k0, optimizer=None, alpha=1e-10)
+    gpr0.fit(X, y)
+    gpr0.L_, gpr0.alpha_ = gpr.L_, gpr.alpha_   # factors of the noisy kernel, noise-free prior at the query points
+    rec = dict(X=X, y=y, theta=gpr.kernel_.theta, seed=5, ndraw=3)
+    for m in (6, 24, 64):
+        Xq = np.random.RandomState(100 + m).uniform(size=(m, d))
+        rec["Xq_%d" % m] = Xq
+        for tag, g in (("nf", gpr0), ("ny", gpr)):
+            mean, cov = g.predict(Xq, return_cov=True)
+            draws = g.sample_y(Xq, n_samples=3, random_state=5)      # (m, 3)
+            again = np.random.RandomState(5).multivariate_normal(mean, cov, 3).T
+            assert np.array_equal(draws, again)
+            sv = np.linalg.svd(cov, compute_uv=False)
+            rec["%s_draws_%d" % (tag, m)] = draws
+            rec["%s_mean_%d" % (tag, m)] = mean
+            rec["%s_cov_%d" % (tag, m)] = cov
+            rec["%s_smin_%d" % (tag, m)] = sv.min()
+            print("mvn", tag, m, "singular values %.3g .. %.3g" % (sv.max(), sv.min()))
+    np.savez_compressed(os.path.join(out, "mvn.npz"), **rec)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:   # e.g.  python tests/golden/gen_golden.py gen_mvn
+        for name in sys.argv[1:]:
+            globals()[name](HERE)
+        print("done")
+        sys.exit(0)
     gen_lml_small(HERE)
     gen_lml_sizes(HERE)
     gen_grad(HERE)
@@ -504,5 +542,6 @@ if __name__ == "__main__":
     gen_reference_tier1(HERE)
     gen_sizes_posterior(HERE)
     gen_sample_y(HERE)
+    gen_mvn(HERE)
     gen_dense(HERE)
     print("done")

@@ -170,3 +170,78 @@ def test_sample_y_is_the_reference_distribution(lib):
     tol = 6.0 * np.sqrt(2.0 / nd)  # (a sample covariance entry scatters by ~ sqrt((1 + rho^2) / N) of the scale)
     assert np.abs(cdev - g["cov"]).max() / scale.max() < tol and np.abs(cref - g["cov"]).max() / scale.max() < tol
     ctx.close()
+
+
+def _mvn_gp(g):
+    """A BayesGPR whose median GP is the golden's: kernel 1.3 * Matern52([0.35, 0.5]) + White(0.02), y as given."""
+    import bayes_skopt_amd as bask
+    from bayes_skopt_amd.kernels import ConstantKernel, Matern
+
+    X, y = g["X"], g["y"]
+    gp = bask.BayesGPR(kernel=ConstantKernel(1.3) * Matern(length_scale=[0.35, 0.5], nu=2.5), normalize_y=False,
+                       random_state=0)
+    gp.fit(X, y, n_desired_samples=40, n_burnin=1, n_walkers_per_thread=20, progress=False)
+    gp.theta = g["theta"]
+    return gp
+
+
+def test_sample_y_reference_variates_equal_sklearns_seeded_draws():
+    """Row a8 with the reference's OWN variates (SURVEY 8c golden (8), tests/golden/mvn.npz): BayesGPR.sample_y(mvn="reference")
+    -- mean and covariance from the device (bgp_predict_batch with cov), numpy's legacy SVD multivariate normal on the host,
+    as sklearn/_gpr.py:522-526 behind bask/bayesgpr.py:669-678 -- returns scikit-learn's seeded draws: 1e-9 absolute at 6,
+    24 and 64 query points, noise off (the reference's default) and on.  "auto" takes this mode up to 256 query points."""
+    g = load_golden("mvn.npz")
+    gp = _mvn_gp(g)
+    for m in (6, 24, 64):
+        Xq = g["Xq_%d" % m]
+        for tag, noise in (("nf", False), ("ny", True)):
+            want = g["%s_draws_%d" % (tag, m)]
+            got = gp.sample_y(Xq, sample_mean=True, noise=noise, n_samples=int(g["ndraw"]), random_state=int(g["seed"]),
+                              mvn="reference")
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+            auto = gp.sample_y(Xq, sample_mean=True, noise=noise, n_samples=int(g["ndraw"]), random_state=int(g["seed"]))
+            np.testing.assert_array_equal(auto, got)
+            # the device parameters themselves against scikit-learn's predict(return_cov=True)
+            cm = gp.noise_set_to_zero() if not noise else None
+            if cm is not None:
+                with cm:
+                    mean, cov = gp.predict(Xq, return_cov=True)
+            else:
+                mean, cov = gp.predict(Xq, return_cov=True)
+            np.testing.assert_allclose(mean, g["%s_mean_%d" % (tag, m)], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(cov, g["%s_cov_%d" % (tag, m)], rtol=1e-6, atol=1e-9 * np.abs(cov).max())
+    # the Cholesky draw describes the same distribution with other variates, and both modes consume the generator alike
+    r1, r2 = np.random.RandomState(9), np.random.RandomState(9)
+    a = gp.sample_y(g["Xq_24"], sample_mean=True, n_samples=5, random_state=r1, mvn="reference")
+    b = gp.sample_y(g["Xq_24"], sample_mean=True, n_samples=5, random_state=r2, mvn="cholesky")
+    assert a.shape == b.shape == (24, 5) and not np.allclose(a, b)
+    np.testing.assert_array_equal(r1.get_state()[1], r2.get_state()[1])
+    with pytest.raises(ValueError):
+        gp.sample_y(g["Xq_6"], mvn="svd")
+
+
+def test_sample_y_reference_variates_per_hyper_sample_follow_the_reference_loop():
+    """sample_mean=False (bask/bayesgpr.py:679-706): all chain-row indices first, then per sample the theta setter and
+    sklearn's sample_y on the SAME generator.  The batched device build + per-sample host SVD draw against that loop
+    restated with the oracle; theta / alpha_ untouched; generator consumed as in the Cholesky mode."""
+    from oracle import gp_oracle as O
+
+    g = load_golden("mvn.npz")
+    gp = _mvn_gp(g)
+    X, y, Xq = g["X"], g["y"], g["Xq_24"]
+    theta0, alpha0 = gp.theta.copy(), gp.alpha_.copy()
+    r1 = np.random.RandomState(3)
+    got = gp.sample_y(Xq, n_samples=6, random_state=r1, mvn="reference")
+    rng = np.random.RandomState(3)
+    ind = rng.choice(len(gp.chain_), size=6, replace=True)
+    want = np.empty((24, 6))
+    for i, j in enumerate(ind):
+        want[:, i] = O.sample_y(X, y, np.full(len(y), 1e-10), gp.chain_[j], Xq, 1, rng, noise_zero=True)[:, 0]
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(r1.get_state()[1], rng.get_state()[1])
+    np.testing.assert_array_equal(gp.theta, theta0)
+    np.testing.assert_array_equal(gp.alpha_, alpha0)
+    r2 = np.random.RandomState(3)
+    other = gp.sample_y(Xq, n_samples=6, random_state=r2, mvn="cholesky")
+    assert other.shape == got.shape
+    np.testing.assert_array_equal(r1.get_state()[1], r2.get_state()[1])

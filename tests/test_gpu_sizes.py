@@ -179,7 +179,7 @@ def test_batched_sample_y_equals_item_by_item(lib, bask):
     gp.fit(X, y, n_desired_samples=60, n_burnin=3, n_walkers_per_thread=20, progress=False)
     Xq = np.random.RandomState(12).uniform(size=(m, d))
     theta_before, alpha_before = gp.theta.copy(), gp.alpha_.copy()
-    out = gp.sample_y(Xq, n_samples=9, random_state=5)
+    out = gp.sample_y(Xq, n_samples=9, random_state=5, mvn="cholesky")
     assert out.shape == (m, 9)
     np.testing.assert_array_equal(gp.theta, theta_before)
     np.testing.assert_array_equal(gp.alpha_, alpha_before)

@@ -10,6 +10,7 @@
 #include "bgp_common.h"
 
 extern "C" int bgp_debug_potrf_trace(unsigned long long* out);
+extern "C" int bgp_debug_potrf_trace_w(unsigned long long* out);
 void bgp_launch_potrf(bgp_ctx* ctx, hipStream_t st, int B, double* dK, double* dW, double* dyw, double* dacc,
                       double* dlml, int* dstatus, int ld, size_t mstride, int ystride, int k);
 
@@ -87,6 +88,15 @@ int main(int argc, char** argv) {
     printf("\n  post-factor+barrier:");
     for (int sb = 0; sb < 8; sb++) printf(" %.2f", us(4 + sb * 3, 2 + sb * 3));
     printf("\n");
+    unsigned long long tw[8 * 32];
+    if (bgp_debug_potrf_trace_w(tw) == 0) {
+      // per wave and step: when the wave's step work ended, relative to the step's start on wave 0 (us)
+      for (int w = 0; w < 8; w++) {
+        printf("  wave %d work (us):", w);
+        for (int sb = 0; sb < 8; sb++) printf(" %.2f", (double)(tw[w * 32 + 2 * sb + 1] - tw[2 * sb]) * 0.01);
+        printf("\n");
+      }
+    }
   }
   return 0;
 }
