@@ -63,6 +63,10 @@ SIGNATURES = {
     "bgp_pvrs_prepare": (C.c_int, [_vp, _dp, C.c_int, _ip]),
     "bgp_sample_y": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, C.c_int, _dp, C.c_double, _dp]),
     "bgp_sample_y_batch": (C.c_int, [_vp, C.c_int, _ip, _dp, C.c_int, _dp, _dp, C.c_double, _dp, _ip]),
+    "bgp_lml_batch_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _ip]),
+    "bgp_posterior_batch_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
+    "bgp_predict_batch_gram": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "bgp_comm_abort": (C.c_int, [_vp]),
     "bgp_comm_available": (C.c_int, []),
     "bgp_comm_unique_id": (C.c_int, [_vp]),
     "bgp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
@@ -307,6 +311,65 @@ class Context:
             self.resident_H = H.copy()
         return {"L": L, "alpha": a, "K_inv": Ki, "lml": lml, "status": st}
 
+    # ---- generic kernel expression trees: host-evaluated kernel matrices in, device arithmetic behind them
+    def _Kstack(self, K):
+        K = _c(K)
+        if K.ndim == 2:
+            K = K[None, :, :]
+        if K.ndim != 3 or K.shape[1:] != (self.n, self.n):
+            raise ValueError(f"kernel matrices must be (B, {self.n}, {self.n}), got {K.shape}")
+        return K
+
+    def lml_gram(self, K, use_alpha=True, return_status=False):
+        """Log-marginal likelihood of B host-evaluated kernel matrices ``kernel_(X_train)`` (alpha added on the device)."""
+        K = self._Kstack(K)
+        B = K.shape[0]
+        lml = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        _check(self._lib.bgp_lml_batch_gram(self._h, B, _p(K), int(bool(use_alpha)), _p(lml), _p(st)), "bgp_lml_batch_gram")
+        return (lml, st) if return_status else lml
+
+    def posterior_gram(self, K, use_alpha=True, want_L=False, want_alpha=True, want_K_inv=False):
+        K = self._Kstack(K)
+        B, n = K.shape[0], self.n
+        L = np.empty((B, n, n)) if want_L else None
+        a = np.empty((B, n)) if want_alpha else None
+        Ki = np.empty((B, n, n)) if want_K_inv else None
+        lml = np.empty(B)
+        st = np.zeros(B, dtype=np.int32)
+        nul = C.cast(None, _dp)
+        self.resident_H = None  # (the resident posteriors belong to no canonical vector)
+        _check(self._lib.bgp_posterior_batch_gram(self._h, B, _p(K), int(bool(use_alpha)), _p(L) if want_L else nul,
+                                                  _p(a) if want_alpha else nul, _p(Ki) if want_K_inv else nul, _p(lml),
+                                                  _p(st)), "bgp_posterior_batch_gram")
+        return {"L": L, "alpha": a, "K_inv": Ki, "lml": lml, "status": st}
+
+    def predict_gram(self, Ks, kss, Kss=None):
+        """Predict for the B resident posteriors from host-evaluated ``Ks`` (B, m, n) = kernel_(Xq, X_train),
+        ``kss`` (B, m) = kernel_.diag(Xq) and, for the full covariance, ``Kss`` (B, m, m) = kernel_(Xq)."""
+        Ks = _c(Ks)
+        if Ks.ndim == 2:
+            Ks = Ks[None]
+        B, m, n = Ks.shape
+        if n != self.n:
+            raise ValueError(f"Ks must have {self.n} columns, got {n}")
+        kss = _c(np.broadcast_to(np.asarray(kss, dtype=np.float64), (B, m)))
+        mean = np.empty((B, m))
+        var = np.empty((B, m))
+        nul = C.cast(None, _dp)
+        cov = None
+        if Kss is not None:
+            Kss = _c(np.broadcast_to(np.asarray(Kss, dtype=np.float64), (B, m, m)))
+            cov = np.empty((B, m, m))
+        _check(self._lib.bgp_predict_batch_gram(self._h, B, m, _p(Ks), _p(kss), _p(Kss) if Kss is not None else nul,
+                                                _p(mean), _p(var), _p(cov) if cov is not None else nul),
+               "bgp_predict_batch_gram")
+        return (mean, var, cov) if cov is not None else (mean, var)
+
+    def has_pending(self):
+        """A batch handed to ``lml_submit`` has not been collected yet."""
+        return bool(self._pending)
+
     def predict(self, H_kernel, Xq, return_cov=False):
         H = self._H(H_kernel)
         B = H.shape[0]
@@ -522,6 +585,11 @@ class Comm:
 
     def barrier(self):
         _check(self._lib.bgp_comm_barrier(self._h), "bgp_comm_barrier")
+
+    def abort(self):
+        """ncclCommAbort: the peers' collectives fail at once instead of waiting for this rank."""
+        if getattr(self, "_h", None):
+            self._lib.bgp_comm_abort(self._h)
 
     def nranks(self):
         """Ranks RCCL itself counts in the communicator (ncclCommCount)."""

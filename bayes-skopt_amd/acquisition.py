@@ -117,6 +117,7 @@ def evaluate_acquisitions(X, gpr, acquisition_functions=None, n_samples=10, prog
     if len(trace_i) > 0 and has_unc:
         specs = [(j, _device_acq_spec(a, kwargs)) for j, a in enumerate(acqs) if isinstance(a, UncertaintyAcquisition)]
         if (DEVICE_ACQUISITIONS and not getattr(gpr, "warp_inputs", False) and hasattr(gpr, "_acq_hyper_samples")
+                and not getattr(gpr, "_generic", False)
                 and len(specs) <= _ACQ_MAX and all(sp is not None for _, sp in specs)):
             # build, predict, acquisition closed forms and the average over the draws in one device pass: the
             # (draws x candidates) means and variances stay in HBM

@@ -174,6 +174,31 @@ class BayesGPR(RegressorMixin, BaseEstimator):
     def _canonical(self, theta):
         return self._plan.canonical(theta, self._X_train_.shape[1])
 
+    # ---- generic kernel expression trees (kernels.GramPlan): the host evaluates the kernel object, as the reference does for
+    # every kernel (sklearn/_gpr.py:582); the device factorises, solves, inverts and forms the predictive products
+    @property
+    def _generic(self):
+        return self._plan is not None and self._plan.generic
+
+    def _kernel_at(self, theta):
+        """The kernel object at ``theta`` (``kernel_.clone_with_theta``, sklearn/_gpr.py:571-576); log(0) noise levels pass."""
+        with np.errstate(divide="ignore"):
+            return self.kernel_.clone_with_theta(np.asarray(theta, dtype=np.float64))
+
+    def _gram_stack(self, Thetas, X=None):
+        """(B, n, n) stack of ``kernel(X_train)`` for every row of ``Thetas`` (no alpha: the device adds it)."""
+        X = self.X_train_ if X is None else X
+        return np.stack([self._kernel_at(t)(X) for t in np.atleast_2d(Thetas)])
+
+    def _gram_lml(self, Thetas, Ws=None):
+        """LML of every row (host kernel matrices, device factorisation).  ``Ws``: per-row input warps (B, 2d)."""
+        Thetas = np.atleast_2d(Thetas)
+        if Ws is None:
+            K = self._gram_stack(Thetas)
+        else:  # every walker sees the training inputs through its own Beta-CDF warp (bask/bayesgpr.py:353-365)
+            K = np.stack([self._kernel_at(t)(self._ctx.beta_cdf(self._X_train_, w)) for t, w in zip(Thetas, Ws)])
+        return self._ctx.lml_gram(K)
+
     def log_marginal_likelihood(self, theta=None, eval_gradient=False, clone_kernel=True):
         """``sklearn/_gpr.py:537-652`` on the device.  theta may be (p,) or a (B, p) block."""
         if theta is None:
@@ -182,6 +207,8 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             return self.log_marginal_likelihood_value_
         theta = np.asarray(theta, dtype=np.float64)
         single = theta.ndim == 1
+        if self._generic:
+            return self._gram_lml_and_grad(theta, eval_gradient)
         H = self._canonical(theta)
         if eval_gradient:
             lml, gh, _ = self._ctx.lml_grad(H)
@@ -189,6 +216,28 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             return (float(lml[0]), g[0]) if single else (lml, g)
         lml = self._ctx.lml(H)
         return float(lml[0]) if single else lml
+
+    def _gram_lml_and_grad(self, theta, eval_gradient):
+        """``sklearn/_gpr.py:579-647`` for a generic tree: ``K, K_gradient = kernel(X, eval_gradient=True)`` on the host;
+        factorisation, alpha, K^-1 and the LML on the device; the contraction ``1/2 sum_ij (alpha_i alpha_j - K^-1_ij)
+        dK_ij/dtheta_k`` of the host-evaluated gradient tensor with them (``:615-647``)."""
+        single = theta.ndim == 1
+        T = np.atleast_2d(theta)
+        if not eval_gradient:
+            lml = self._gram_lml(T)
+            return float(lml[0]) if single else lml
+        X = self.X_train_
+        vals, grads = np.empty(len(T)), np.empty((len(T), T.shape[1]))
+        for i, t in enumerate(T):
+            K, Kg = self._kernel_at(t)(X, eval_gradient=True)
+            res = self._ctx.posterior_gram(K, want_alpha=True, want_K_inv=True)
+            if res["status"][0] != 0:
+                vals[i], grads[i] = -np.inf, 0.0
+                continue
+            a, Ki = res["alpha"][0], res["K_inv"][0]
+            vals[i] = res["lml"][0]
+            grads[i] = 0.5 * (np.einsum("i,ijk,j->k", a, Kg, a) - np.einsum("ij,ijk->k", Ki, Kg))
+        return (float(vals[0]), grads[0]) if single else (vals, grads)
 
     # ------------------------------------------------------------------ theta / posterior
     @property
@@ -208,7 +257,10 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         self._build_posterior(theta)
 
     def _build_posterior(self, theta):
-        res = self._ctx.posterior(self._canonical(theta), want_L=False, want_alpha=True, want_K_inv=False)
+        if self._generic:
+            res = self._ctx.posterior_gram(self._gram_stack(theta), want_alpha=True)
+        else:
+            res = self._ctx.posterior(self._canonical(theta), want_L=False, want_alpha=True, want_K_inv=False)
         if res["status"][0] != 0:
             raise np.linalg.LinAlgError(
                 _PD_MESSAGE % self.kernel_,
@@ -216,11 +268,17 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             )
         self.alpha_ = res["alpha"][0]
         self._post_theta = np.array(theta, copy=True)
+        self._gram_resident = np.array(theta, copy=True) if self._generic else None
         self._L = self._K_inv = None
 
     def _fetch_factor(self, which):
         if self._post_theta is None:
             raise AttributeError("no posterior has been built yet")
+        if self._generic:
+            res = self._ctx.posterior_gram(self._gram_stack(self._post_theta), want_L=(which == "L"), want_alpha=False,
+                                           want_K_inv=(which == "K_inv"))
+            self._gram_resident = np.array(self._post_theta, copy=True)
+            return res[which][0]
         res = self._ctx.posterior(self._canonical(self._post_theta), want_L=(which == "L"), want_alpha=False,
                                   want_K_inv=(which == "K_inv"))
         return res[which][0]
@@ -334,6 +392,13 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         """First half of ``_log_prob_batch``: put the block's LML batch on the device and return at once with the
         priors of the same block (evaluated while the device factorises)."""
         Theta = np.atleast_2d(Theta)
+        if self._generic:  # host kernel matrices: nothing to overlap the priors with
+            d = self._X_train_.shape[1] if self.warp_inputs else 0
+            Tgp, W = (Theta[:, : Theta.shape[1] - 2 * d], Theta[:, Theta.shape[1] - 2 * d :]) if d else (Theta, None)
+            lp = _eval_priors(priors, Tgp)
+            if W is not None:
+                lp = lp + _eval_warp_priors(warp_priors, W, d)
+            return lp, ("gram", Tgp, W), False
         if self.warp_inputs:
             d = self._X_train_.shape[1]
             Tgp, W = Theta[:, : Theta.shape[1] - 2 * d], Theta[:, Theta.shape[1] - 2 * d :]
@@ -357,6 +422,8 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         lp, H, submitted = token
         if submitted:
             lml = self._ctx.lml_wait()
+        elif isinstance(H, tuple) and len(H) == 3 and isinstance(H[0], str):
+            lml = self._gram_lml(H[1], H[2])
         elif self.warp_inputs:
             lml = self._ctx.lml_warped(*H)
         else:
@@ -609,6 +676,14 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             validate_zeroone(X)  # the device warps the query points with the context-level warp
         if self._post_theta is None or getattr(self, "_X_train_", None) is None:
             raise RuntimeError("predict before fit is not supported on the MI355X path")
+        if self._generic:
+            if return_mean_grad:
+                raise NotImplementedError("prediction gradients need kernel_.gradient_x, which only the canonical kernels have")
+            mean, var, cov = self._rows_predict(None, X, noise_zero=False, return_cov=return_cov)
+            y_mean = self.y_train_std_ * mean[0] + self.y_train_mean_
+            if return_cov:
+                return y_mean, cov[0] * self.y_train_std_**2
+            return (y_mean, np.sqrt(var[0] * self.y_train_std_**2)) if return_std else y_mean
         self._make_resident()
         Hk = self._canonical(self._kernel_theta_for_predict())
         if return_cov:
@@ -671,6 +746,11 @@ class BayesGPR(RegressorMixin, BaseEstimator):
 
     def _make_resident(self):
         """Make sure the device holds the posterior that alpha_/L_/K_inv_ describe."""
+        if self._generic:
+            if getattr(self, "_gram_resident", None) is None or not np.array_equal(self._gram_resident, self._post_theta):
+                self._ctx.posterior_gram(self._gram_stack(self._post_theta), want_alpha=False)
+                self._gram_resident = np.array(self._post_theta, copy=True)
+            return
         H = self._canonical(self._post_theta)
         res = self._ctx.resident_H
         if res is None or res.shape[0] < 1 or not np.array_equal(res[0], H[0]):
@@ -683,12 +763,59 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         X = np.atleast_2d(np.asarray(X, dtype=np.float64))
         if self.warp_inputs:
             return self._predict_hyper_samples_warped(np.atleast_2d(thetas), X, noise_zero)
+        if self._generic:
+            mean, var, _ = self._rows_predict(np.atleast_2d(thetas), X, noise_zero)
+            return self.y_train_std_ * mean + self.y_train_mean_, np.sqrt(var * self.y_train_std_**2)
         Hk = self._build_hyper_samples(thetas).copy()
         if noise_zero:
             Hk[:, -1] = -np.inf
         mean, var = self._ctx.predict(Hk, X)
         mu = self.y_train_std_ * mean + self.y_train_mean_
         return mu, np.sqrt(var * self.y_train_std_**2)
+
+    def _rows_predict(self, thetas, X, noise_zero, return_cov=False):
+        """Posterior build + predict for the GP of every row of ``thetas`` under the CURRENT warpers, in the units of the
+        normalised targets: (mean, var, cov | None), each with a leading row axis.  ``thetas=None``: the resident posterior
+        of ``theta`` with the kernel parameters currently in ``kernel_`` (what ``predict`` needs).  Canonical kernels: one
+        batched device build over the distinct rows + one batched device predict.  Generic trees: the kernel object is
+        evaluated on the host (training matrix, cross covariances, prior variances), everything else on the device."""
+        if not self._generic:
+            H = self._canonical(thetas)
+            uniq, inverse = np.unique(H, axis=0, return_inverse=True)
+            res = self._ctx.posterior(uniq, want_alpha=False)
+            self._raise_if_not_pd(res["status"])
+            Hk = uniq.copy()
+            if noise_zero:
+                Hk[:, -1] = -np.inf
+            out = self._ctx.predict(Hk, X, return_cov=return_cov)
+            inverse = np.asarray(inverse).ravel()
+            return out[0][inverse], out[1][inverse], (out[2][inverse] if return_cov else None)
+        Xw = self.warp(X) if self.warp_inputs else X  # BayesGPR.predict warps the query points (bask/bayesgpr.py:630-632)
+        Xt = self.X_train_
+        if thetas is None:
+            self._make_resident()
+            kernels = [self.kernel_]
+        else:
+            thetas = np.atleast_2d(thetas)
+            self._gram_resident = None
+            res = self._ctx.posterior_gram(self._gram_stack(thetas, Xt), want_alpha=False)
+            self._raise_if_not_pd(res["status"])
+            kernels = [self._kernel_at(t) for t in thetas]
+        if noise_zero:
+            kernels = [_with_white_zeroed(k) for k in kernels]
+        Ks = np.stack([k(Xw, Xt) for k in kernels])
+        kss = np.stack([k.diag(Xw) for k in kernels])
+        Kss = np.stack([k(Xw) for k in kernels]) if return_cov else None
+        out = self._ctx.predict_gram(Ks, kss, Kss)
+        return out[0], out[1], (out[2] if return_cov else None)
+
+    def _raise_if_not_pd(self, status):
+        if np.any(status != 0):
+            bad = int(np.flatnonzero(status)[0])
+            raise np.linalg.LinAlgError(
+                _PD_MESSAGE % self.kernel_,
+                "%d-th leading minor of the array is not positive definite" % status[bad],
+            )
 
     def _build_hyper_samples(self, thetas):
         """One batched device posterior build for a set of chain rows; returns the canonical hyper-parameters."""
@@ -725,14 +852,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         for row in rows:
             self.create_warpers(row[n_theta : n_theta + d], row[n_theta + d :])
             self.rewarp()
-            H = self._canonical(row[:n_theta][None, :])
-            res = self._ctx.posterior(H, want_alpha=False)
-            if res["status"][0] != 0:
-                raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % res["status"][0])
-            Hk = H.copy()
-            if noise_zero:
-                Hk[:, -1] = -np.inf
-            mean, var = self._ctx.predict(Hk, X)
+            mean, var, _ = self._rows_predict(row[None, :n_theta], X, noise_zero)
             mus.append(self.y_train_std_ * mean[0] + self.y_train_mean_)
             stds.append(np.sqrt(var[0] * self.y_train_std_**2))
         self.create_warpers(*backup)
@@ -741,11 +861,40 @@ class BayesGPR(RegressorMixin, BaseEstimator):
 
     def _pvrs(self, X, thompson_points, has_alpha_vec):
         """Device side of PVRS / VarianceReduction (``bask/acquisition.py:287-300,328-338``)."""
+        if self._generic:
+            return self._pvrs_gram(np.atleast_2d(X), np.atleast_2d(thompson_points), has_alpha_vec)
         Hk = self._canonical(self._kernel_theta_for_predict())
         status = self._ctx.pvrs_prepare(Hk, has_alpha_vec)
         if status != 0:
             raise np.linalg.LinAlgError("%d-th leading minor of the array is not positive definite" % status)
         return self._ctx.pvrs(Hk, X, np.atleast_2d(thompson_points))
+
+    def _pvrs_gram(self, X, T, has_alpha_vec):
+        """PVRS for a generic kernel tree through the bordered-inverse identity of ``bgp_pvrs``,
+        ``covs_i = sum_t [k_t^T K^-1 k_t + (k(x_t, x_i) - k_i^T K^-1 k_t)^2 / (kappa_i - k_i^T K^-1 k_i)]``, every term read off
+        ONE device predictive covariance ``C = K_** - K_* K^-1 K_*^T`` over [Thompson points; candidates] per candidate chunk:
+        ``C_ti``, ``C_ii`` and ``k_t^T K^-1 k_t = kappa_t - C_tt``.  K carries alpha only when it is a vector (reference quirk,
+        ``bask/acquisition.py:332-333``); the kernel matrices come from the host-evaluated ``kernel_``."""
+        k = self.kernel_
+        Xt = self.X_train_
+        self._gram_resident = None
+        res = self._ctx.posterior_gram(k(Xt)[None], use_alpha=bool(has_alpha_vec), want_alpha=False)
+        self._raise_if_not_pd(res["status"])
+        if self.warp_inputs:
+            X, T = self.warp(X), self.warp(T)
+        nt = T.shape[0]
+        covs = np.empty(X.shape[0])
+        step = max(1, 2048 - nt)
+        for lo in range(0, X.shape[0], step):
+            Q = np.vstack([T, X[lo : lo + step]])
+            kss = k.diag(Q)
+            _mean, _var, C = self._ctx.predict_gram(k(Q, Xt)[None], kss[None], k(Q)[None])
+            C = C[0]
+            tt = kss[:nt] - np.diag(C)[:nt]
+            cross = C[:nt, nt:]
+            cii = np.diag(C)[nt:]
+            covs[lo : lo + step] = tt.sum() + np.sum(cross * cross / cii[None, :], axis=0)
+        return covs
 
     def _mvn_mode(self, m, mvn=None):
         """'reference' (numpy's SVD draw on the host from the device-built mean / covariance) or 'cholesky' (device)."""
@@ -754,6 +903,10 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             raise ValueError("mvn must be 'auto', 'reference' or 'cholesky', got %r" % (mode,))
         if mode == "auto":
             mode = "reference" if m <= self.MVN_REFERENCE_MAX_POINTS else "cholesky"
+        if self._generic:
+            # the device draw builds the predictive covariance from the canonical hyper-parameters; a generic tree has none:
+            # mean / covariance through the host-evaluated kernel, the reference's own SVD draw on the host
+            mode = "reference"
         return mode
 
     def sample_y(self, X, sample_mean=False, noise=False, n_samples=1, random_state=0, mvn=None):
@@ -837,22 +990,8 @@ class BayesGPR(RegressorMixin, BaseEstimator):
     def _mean_cov_rows(self, thetas, X, noise):
         """Predictive mean and covariance (y units) of the GP of every chain row: batched device posterior build over the
         distinct rows + batched device predict with the full covariance; ``theta`` / ``alpha_`` / ``L_`` stay untouched."""
-        H = self._canonical(thetas)
-        uniq, inverse = np.unique(H, axis=0, return_inverse=True)
-        res = self._ctx.posterior(uniq, want_alpha=False)
-        if np.any(res["status"] != 0):
-            bad = int(np.flatnonzero(res["status"])[0])
-            raise np.linalg.LinAlgError(
-                _PD_MESSAGE % self.kernel_,
-                "%d-th leading minor of the array is not positive definite" % res["status"][bad],
-            )
-        Hk = uniq.copy()
-        if not noise:
-            Hk[:, -1] = -np.inf  # noise_set_to_zero(): the factors keep the noise, the predictive kernel drops it
-        mean, _var, cov = self._ctx.predict(Hk, X, return_cov=True)
-        inverse = np.asarray(inverse).ravel()
-        y_mean = self.y_train_std_ * mean[inverse] + self.y_train_mean_
-        return y_mean, cov[inverse] * self.y_train_std_**2
+        mean, _var, cov = self._rows_predict(np.atleast_2d(thetas), X, noise_zero=not noise, return_cov=True)
+        return self.y_train_std_ * mean + self.y_train_mean_, cov * self.y_train_std_**2
 
     def _draw_rows(self, rows, X, Z, noise):
         """f_i = mean_i + chol(cov_i) Z[i] for the GP of chain row i (kernel parameters and, with input warping, its
@@ -931,6 +1070,19 @@ class BayesGPR(RegressorMixin, BaseEstimator):
                 pass
 
 
+def _with_white_zeroed(kernel):
+    """A copy of ``kernel`` with its WhiteKernel (inside nested sums) at level 0: what ``noise_set_to_zero`` does to
+    ``kernel_`` (``bask/bayesgpr.py:327-333``)."""
+    k = clone(kernel)
+    if isinstance(k, WhiteKernel):
+        k.set_params(noise_level=0.0)
+        return k
+    present, white_param = param_for_white_kernel_in_sum(k)
+    if present:
+        k.set_params(**{white_param: WhiteKernel(noise_level=0.0)})
+    return k
+
+
 def _legacy_mvn(rng, mean, cov, n_samples):
     """``rng.multivariate_normal(mean, cov, n_samples)`` -- numpy's legacy SVD-based draw, the call scikit-learn's
     ``sample_y`` makes (``sklearn/_gpr.py:522-526``); (n_samples, m).  Its "covariance is not symmetric positive-
@@ -976,7 +1128,7 @@ class _ShardedLogProb:
         # From here on every rank is committed to ONE collective in ``finish``.  Whatever fails locally in between -- the
         # priors raising, a failed submit, a device error -- is carried in the token and reported THROUGH that collective
         # (status word next to the values): a rank that raised here would leave its peers blocked in the all-gather.
-        if gp.warp_inputs:  # per-walker warps: this rank's finished values are gathered from the host
+        if gp.warp_inputs or gp._generic:  # per-walker warps / host-evaluated kernels: finished values gathered from the host
             try:
                 return ("host", B, gp._log_prob_begin(Theta[lo:hi], priors, warp_priors) if hi > lo else None, None)
             except Exception as exc:
@@ -991,6 +1143,17 @@ class _ShardedLogProb:
             lp = _eval_priors(priors, Theta)  # all rows on every rank, while the device factorises this rank's
         except Exception as exc:
             failure = exc
+        except BaseException:
+            # KeyboardInterrupt / SystemExit: this rank is going down and will never enter the collective.  Collect the pending
+            # batch (otherwise every later call on the context answers BGP_ERR_STATE) and take the group down with it, so that the
+            # peers fail at once instead of sitting in the all-gather until BGP_COMM_TIMEOUT_S.
+            try:
+                if submitted or gp._ctx.has_pending():
+                    gp._ctx.lml_wait()
+            except Exception:
+                pass
+            distributed.abort_process_group()
+            raise
         return ("dev", B, lp, H, submitted, native, hi > lo, failure)
 
     def finish(self, token):

@@ -23,7 +23,30 @@ static std::mutex g_xfer_mutex;
 
 void bgp_xfer_drop_pending() {
   std::lock_guard<std::mutex> lock(g_xfer_mutex);
-  g_xfer.pending.clear();
+  BgpXfer& x = g_xfer;
+  const std::thread::id me = std::this_thread::get_id();
+  size_t keep = 0;
+  for (size_t i = 0; i < x.pending.size(); i++) {
+    const BgpXfer::Pending q = x.pending[i];
+    if (q.owner != me) {
+      x.pending[keep++] = q;
+      continue;
+    }
+    // the copy may still be in flight into its arena block: the block must outlive it (release / forget of the stream clear this)
+    if (std::find(x.busy.begin(), x.busy.end(), q.st) == x.busy.end()) x.busy.push_back(q.st);
+  }
+  x.pending.resize(keep);
+}
+
+void bgp_xfer_forget(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_xfer_mutex);
+  BgpXfer& x = g_xfer;
+  size_t keep = 0;
+  for (size_t i = 0; i < x.pending.size(); i++)
+    if (x.pending[i].st != st) x.pending[keep++] = x.pending[i];
+  x.pending.resize(keep);
+  x.busy.erase(std::remove(x.busy.begin(), x.busy.end(), st), x.busy.end());
+  x.maybe_reset();
 }
 
 char* BgpXfer::take(size_t bytes) {
@@ -58,6 +81,10 @@ void BgpXfer::release(hipStream_t st) {
   }
   pending.resize(keep);
   busy.erase(std::remove(busy.begin(), busy.end(), st), busy.end());
+  maybe_reset();
+}
+
+void BgpXfer::maybe_reset() {
   if (pending.empty() && busy.empty()) {  // nothing staged is in flight any more: the arena starts over
     size_t total = 0;
     for (Block& b : blocks) total += b.cap;
@@ -115,7 +142,7 @@ hipError_t bgp_memcpy2d_async(void* dst, size_t dpitch, const void* src, size_t 
   if (kind == hipMemcpyDeviceToHost) {
     char* stage = x.take(width * height);
     if (!stage) return hipErrorOutOfMemory;
-    x.pending.push_back({st, (char*)dst, dpitch, stage, width, height});
+    x.pending.push_back({st, (char*)dst, dpitch, stage, width, height, std::this_thread::get_id()});
     if (height == 1 || spitch == width) return hipMemcpyAsync(stage, src, width * height, hipMemcpyDeviceToHost, st);
     return hipMemcpy2DAsync(stage, width, src, spitch, width, height, hipMemcpyDeviceToHost, st);
   }
@@ -406,11 +433,18 @@ extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   free_dev(c->ps_trace);
   if (c->ps_herr) (void)hipHostFree(c->ps_herr);
   for (int g = 0; g < BGP_MAX_STREAMS; g++) {
-    if (c->gstream[g]) (void)hipStreamDestroy(c->gstream[g]);
+    if (c->gstream[g]) {
+      (void)hipStreamSynchronize(c->gstream[g]);
+      bgp_xfer_forget(c->gstream[g]);
+      (void)hipStreamDestroy(c->gstream[g]);
+    }
     if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
   }
   if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream) {
+    bgp_xfer_forget(c->stream);  // (synchronised above: nothing of this context is in flight into the arena any more)
+    (void)hipStreamDestroy(c->stream);
+  }
   delete c;
   bool last;
   {

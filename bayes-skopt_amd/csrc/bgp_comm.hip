@@ -132,6 +132,19 @@ static int comm_sync(bgp_comm* c, const char* what) {
   }
 }
 
+// The result of a collective on its way to the caller's buffer.  Transfers above BGP_XFER_DIRECT bytes take bgp_memcpy2d_async's
+// synchronous route, which waits for the stream with the runtime's UNBOUNDED wait -- behind a collective that is a wait for the
+// peers: the bounded wait (time-out, asynchronous-error check, abort) comes first, the copy then finds an idle stream.
+static int comm_sync(bgp_comm* c, const char* what);
+static int comm_download(bgp_comm* c, double* host, size_t count, const char* what) {
+  if (count * sizeof(double) > BGP_XFER_DIRECT) {
+    const int rc = comm_sync(c, what);
+    if (rc) return rc;
+  }
+  BGP_HIP(bgp_memcpy_async(host, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  return comm_sync(c, what);
+}
+
 #define BGP_COMM_LIVE(c, who)                                                                   \
   do {                                                                                          \
     if ((c)->aborted || !(c)->comm) {                                                           \
@@ -273,8 +286,22 @@ extern "C" void bgp_comm_destroy(bgp_comm* c) {
   if (c->dsend) (void)hipFree(c->dsend);
   if (c->drecv) (void)hipFree(c->drecv);
   if (c->hrecv) (void)hipHostFree(c->hrecv);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream) {
+    bgp_xfer_forget(c->stream);
+    (void)hipStreamDestroy(c->stream);
+  }
   delete c;
+}
+
+extern "C" int bgp_comm_abort(bgp_comm* c) {
+  if (!c) {
+    bgp_set_error("bgp_comm_abort: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  if (!c->aborted && c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
+  c->comm = nullptr;
+  c->aborted = 1;
+  return BGP_OK;
 }
 
 // Ranks RCCL itself counts in the communicator (ncclCommCount): what a caller reports as "the group that really formed".
@@ -353,7 +380,8 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
       return BGP_ERR_COMM;
     }
   }
-  for (int round = 0; round < 3; round++) {
+  // at most two rounds: the first may carry "redo" words (launch-free time-outs, read on the device), the second is final
+  for (int round = 0; round < 2; round++) {
     // the context's work of this half-step -> the communicator's stream (device-side dependency, no host wait)
     if (hipEventRecord(c->ev_ctx, ctx->stream) != hipSuccess || hipStreamWaitEvent(c->stream, c->ev_ctx, 0) != hipSuccess) {
       (void)hipGetLastError();
@@ -386,14 +414,18 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
       redo = redo || errors_out[r] == BGP_RANK_REDO;
       memcpy(lml_all + (size_t)r * per_rank, c->hrecv + r * slot, (size_t)per_rank * sizeof(double));
     }
-    // this rank's own launch-free call: note a time-out (and redo the batch by launches) or clear the in-flight mark
-    if (Bp > 0 && !local_error) {
-      const int rr = bgp_lml_redo_if_abandoned(ctx, Bp);
-      if (rr) local_error = rr;  // ... reported in the next round
+    // this rank's own launch-free call: note a time-out (and redo the batch by launches) or clear the in-flight mark -- also
+    // when the rank reports a local failure (a mark left behind would make the NEXT call on the context count a spurious
+    // time-out and redo a healthy batch)
+    if (round == 0) {
+      if (Bp > 0 && !local_error) {
+        const int rr = bgp_lml_redo_if_abandoned(ctx, Bp);
+        if (rr) local_error = rr;  // ... reported in the second round
+      } else {
+        bgp_ps_clear_inflight(ctx);
+      }
     }
-    if (!redo) return BGP_OK;
-    for (int r = 0; r < c->world; r++)
-      if (errors_out[r] == BGP_RANK_REDO) errors_out[r] = 0;  // (settled by the next round)
+    if (!redo || round == 1) return BGP_OK;
   }
   return BGP_OK;
 }
@@ -410,8 +442,7 @@ extern "C" int bgp_comm_allgather(bgp_comm* c, const double* send, size_t count,
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, send, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllGather(c->dsend, c->drecv, count, ncclFloat64, c->comm, c->stream));
-  BGP_HIP(bgp_memcpy_async(recv, c->drecv, count * c->world * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  return comm_sync(c, "bgp_comm_allgather");
+  return comm_download(c, recv, count * c->world, "bgp_comm_allgather");
 }
 
 extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) {
@@ -426,8 +457,7 @@ extern "C" int bgp_comm_allreduce_max(bgp_comm* c, double* inout, size_t count) 
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, inout, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.AllReduce(c->dsend, c->drecv, count, ncclFloat64, ncclMax, c->comm, c->stream));
-  BGP_HIP(bgp_memcpy_async(inout, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  return comm_sync(c, "bgp_comm_allreduce_max");
+  return comm_download(c, inout, count, "bgp_comm_allreduce_max");
 }
 
 extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int root) {
@@ -442,8 +472,7 @@ extern "C" int bgp_comm_broadcast(bgp_comm* c, double* buf, size_t count, int ro
   if (rc) return rc;
   BGP_HIP(bgp_memcpy_async(c->dsend, buf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
   BGP_NCCL(g_rccl.Broadcast(c->dsend, c->drecv, count, ncclFloat64, root, c->comm, c->stream));
-  BGP_HIP(bgp_memcpy_async(buf, c->drecv, count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  return comm_sync(c, "bgp_comm_broadcast");
+  return comm_download(c, buf, count, "bgp_comm_broadcast");
 }
 
 extern "C" int bgp_comm_barrier(bgp_comm* c) {

@@ -22,7 +22,12 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 void bgp_set_error(const char* fmt, ...);
+// A call of THIS thread has failed: none of the downloads it enqueued may be unpacked into its caller's buffers later.  Only the
+// calling thread's entries go (one context per host thread: another thread's context keeps its staged downloads), and their
+// streams stay marked busy -- their copies may still be in flight into the arena -- until they are synchronised or destroyed.
 void bgp_xfer_drop_pending();
+// The stream is about to be destroyed (and has been synchronised): drop what is left of it without unpacking.
+void bgp_xfer_forget(hipStream_t st);
 
 #define BGP_HIP(call)                                                                        \
   do {                                                                                       \
@@ -55,12 +60,14 @@ struct BgpXfer {
     size_t hpitch;
     const char* stage;
     size_t width, height;
+    std::thread::id owner;  // the thread that enqueued the download (a failing call drops ITS OWN downloads only)
   };
   std::vector<Block> blocks;
   std::vector<Pending> pending;
   std::vector<hipStream_t> busy;  // streams with staged host -> device data not yet known to have been consumed
   char* take(size_t bytes);
   void release(hipStream_t st);   // the stream has been synchronised: unpack its downloads, forget its uploads
+  void maybe_reset();             // nothing staged is in flight any more: the arena starts over
 };
 // ONE arena per process behind a mutex (bgp_api.hip): the bookkeeping is keyed by STREAM, so whichever thread synchronises a
 // stream unpacks that stream's downloads -- a thread-local arena left them behind when another thread than the enqueuing one
@@ -341,15 +348,23 @@ static inline bool bgp_ps_allowed(bgp_ctx* c) {
 }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
+// the launch-free call of a batch whose results are discarded anyway: forget it (no time-out is counted, nothing is redone)
+static inline void bgp_ps_clear_inflight(bgp_ctx* c) {
+  c->ps_inflight = 0;
+  if (c->ps_herr) *c->ps_herr = 0;
+}
 int bgp_persist_fits(bgp_ctx* ctx, int B);
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);
 // make the matrix workspace at least `doubles` large (and the per-item side buffers consistent)
 int bgp_grow_workspace(bgp_ctx* ctx, size_t doubles);
-// posterior build on the augmented matrices; use_alpha == 0 drops alpha_diag (PVRS quirk)
+// posterior build on the augmented matrices; use_alpha == 0 drops alpha_diag (PVRS quirk).  Kgram != nullptr: the B kernel
+// matrices come from the host (n x n each, bgp_gram.hip) instead of the device Gram build, h is not read
 int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, double* L, double* alpha, double* K_inv,
-                        double* lml, int* status);
+                        double* lml, int* status, const double* Kgram = nullptr);
+// host kernel matrices -> working matrices (bgp_gram.hip)
+int bgp_gram_load(bgp_ctx* c, int nb, const double* K, int augmented, int use_alpha);
 
 // ---- kernels launched across translation units ----
 // K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).

@@ -167,7 +167,7 @@ static int ensure_resident(bgp_ctx* c, int B) {
 }
 
 int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, double* L, double* alpha, double* K_inv,
-                        double* lml, int* status) {
+                        double* lml, int* status, const double* Kgram) {
   const int npad = c->npad, n = c->n;
   const size_t p = c->d + 2;
   const size_t ld = 2 * (size_t)npad;
@@ -183,13 +183,14 @@ int bgp_posterior_build(bgp_ctx* c, int B, const double* h, int use_alpha, doubl
   chunk = std::min(chunk, c->max_batch);
   for (int off = 0; off < B; off += chunk) {
     const int nb = std::min(chunk, B - off);
-    BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (!Kgram)
+      BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
     // zero the bottom halves ([I | 0] rows), then K into the top-left, identity, rhs
     for (int b = 0; b < nb; b++)
       BGP_HIP(hipMemsetAsync(c->dK + (size_t)b * ld * ld + (size_t)npad * ld, 0, (size_t)npad * ld * sizeof(double),
                              c->stream));
-    rc = bgp_launch_kbuild(c, nb, 0, 1, use_alpha);
+    rc = Kgram ? bgp_gram_load(c, nb, Kgram + (size_t)off * n * n, 1, use_alpha) : bgp_launch_kbuild(c, nb, 0, 1, use_alpha);
     if (rc) return rc;
     hipLaunchKernelGGL(aug_init_kernel, dim3((npad + 255) / 256, nb), dim3(256), 0, c->stream, c->dK, c->dyw, npad, nb);
     rc = bgp_launch_cholesky(c, nb, 1);
@@ -235,6 +236,20 @@ extern "C" int bgp_posterior_batch(bgp_ctx* c, int B, const double* h, double* L
   BGP_HIP(hipSetDevice(c->device));
   c->post_B = 0;
   return bgp_posterior_build(c, B, h, 1, L, alpha, K_inv, lml, status);
+}
+
+// The same posterior build from HOST-evaluated kernel matrices (generic kernel expression trees, bgp_gram.hip): K is B
+// matrices of n x n (kernel_(X_train) without the alpha term), everything behind it as bgp_posterior_batch.
+extern "C" int bgp_posterior_batch_gram(bgp_ctx* c, int B, const double* K, int use_alpha, double* L, double* alpha,
+                                        double* K_inv, double* lml, int* status) {
+  BGP_REQUIRE_IDLE(c, "bgp_posterior_batch_gram");
+  if (!c || !K || B <= 0) {
+    bgp_set_error("bgp_posterior_batch_gram: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  c->post_B = 0;
+  return bgp_posterior_build(c, B, nullptr, use_alpha, L, alpha, K_inv, lml, status, K);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -376,6 +391,87 @@ extern "C" int bgp_predict_batch(bgp_ctx* c, int B, const double* h_kernel, int 
     return BGP_ERR_INVALID;
   }
   return predict_run(c, B, h_kernel, m, Xq, mean, var, cov, nullptr);
+}
+
+// var_i = max(0, kss_i - q_i) with the prior variances kernel_.diag(Xq) supplied by the host (generic kernels)
+__global__ void finish_var_gram_kernel(const double* __restrict__ q, const double* __restrict__ kss, size_t sq, int m,
+                                       double* __restrict__ var) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i >= m) return;
+  const double v = kss[(size_t)b * sq + i] - q[(size_t)b * sq + i];
+  var[(size_t)b * sq + i] = v < 0.0 ? 0.0 : v;
+}
+
+// Predict with HOST-evaluated cross covariances for the B resident posteriors (generic kernel expression trees): Ks is B x m x n
+// (kernel_(Xq, X_train) per item), kss B x m (kernel_.diag(Xq)), Kss B x m x m (kernel_(Xq); only with cov).  The products --
+// mean = K_* alpha, var = kss - rowsum((K_* K^-1) o K_*), cov = K_** - (K_* K^-1) K_*^T -- are the kernels of bgp_predict_batch.
+extern "C" int bgp_predict_batch_gram(bgp_ctx* c, int B, int m, const double* Ks, const double* kss, const double* Kss,
+                                      double* mean, double* var, double* cov) {
+  BGP_REQUIRE_IDLE(c, "bgp_predict_batch_gram");
+  if (!c || !Ks || !kss || !mean || !var || m <= 0 || B <= 0 || (cov && !Kss)) {
+    bgp_set_error("bgp_predict_batch_gram: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  if (B > c->post_B) {
+    bgp_set_error("bgp_predict_batch_gram: %d posteriors requested but %d resident (call bgp_posterior_batch_gram first)", B,
+                  c->post_B);
+    return BGP_ERR_STATE;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  const int npad = c->npad, n = c->n, mpad = pad128(m);
+  const size_t sKs = (size_t)mpad * npad, sCv = (size_t)mpad * mpad;
+  const size_t per_item = sKs + 3 * (size_t)mpad + (cov ? sKs + sCv : 0);
+  const size_t budget = (size_t)1 << 29;
+  int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, budget / per_item));
+  if (chunk >= 8 && chunk < B) chunk &= ~7;
+  int rc = bgp_ensure_scratch(c, (size_t)chunk * per_item + 64);
+  if (rc) return rc;
+  Scratch s{c->dscratch, 0};
+  double* dKs = s.take((size_t)chunk * sKs);
+  double* dq = s.take((size_t)chunk * mpad);
+  double* dout = s.take((size_t)chunk * mpad);
+  double* dkss = s.take((size_t)chunk * mpad);
+  double *dP = nullptr, *dCov = nullptr;
+  if (cov) {
+    dP = s.take((size_t)chunk * sKs);
+    dCov = s.take((size_t)chunk * sCv);
+  }
+  for (int off = 0; off < B; off += chunk) {
+    const int nb = std::min(chunk, B - off);
+    const double* Kinv = c->dKinv + (size_t)off * npad * npad;
+    const double* al = c->dalpha_sol + (size_t)off * npad;
+    // K_* with its zero padding (rows m .. mpad, columns n .. npad)
+    BGP_HIP(hipMemsetAsync(dKs, 0, (size_t)nb * sKs * sizeof(double), c->stream));
+    for (int b = 0; b < nb; b++)
+      BGP_HIP(bgp_memcpy2d_async(dKs + (size_t)b * sKs, (size_t)npad * sizeof(double), Ks + (size_t)(off + b) * m * n,
+                                 (size_t)n * sizeof(double), (size_t)n * sizeof(double), m, hipMemcpyHostToDevice, c->stream));
+    BGP_HIP(bgp_memcpy2d_async(dkss, (size_t)mpad * sizeof(double), kss + (size_t)off * m, (size_t)m * sizeof(double),
+                               (size_t)m * sizeof(double), nb, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(matvec_rows_kernel, dim3((m + 3) / 4, nb), dim3(256), 0, c->stream, dKs, npad, sKs, al, (size_t)npad,
+                       (const int*)nullptr, npad, m, dout, (size_t)mpad);
+    BGP_HIP(bgp_memcpy2d_async(mean + (size_t)off * m, (size_t)m * sizeof(double), dout, (size_t)mpad * sizeof(double),
+                               (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    rc = launch_rowquad(c, dKs, npad, sKs, Kinv, npad, (size_t)npad * npad, nullptr, mpad, npad, nb, dq);
+    if (rc) return rc;
+    if (cov) {
+      bgp_launch_gemm4(c->stream, 0, dKs, Kinv, npad, mpad, npad, npad, dP, npad, nb, sKs, (size_t)npad * npad, sKs, nullptr);
+      BGP_HIP(hipMemsetAsync(dCov, 0, (size_t)nb * sCv * sizeof(double), c->stream));
+      for (int b = 0; b < nb; b++)
+        BGP_HIP(bgp_memcpy2d_async(dCov + (size_t)b * sCv, (size_t)mpad * sizeof(double), Kss + (size_t)(off + b) * m * m,
+                                   (size_t)m * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyHostToDevice, c->stream));
+      bgp_launch_gemm4(c->stream, 2, dP, dKs, npad, mpad, mpad, npad, dCov, mpad, nb, sKs, sKs, sCv, nullptr);
+      for (int b = 0; b < nb; b++)
+        BGP_HIP(bgp_memcpy2d_async(cov + (size_t)(off + b) * m * m, (size_t)m * sizeof(double), dCov + (size_t)b * sCv,
+                                   (size_t)mpad * sizeof(double), (size_t)m * sizeof(double), m, hipMemcpyDeviceToHost,
+                                   c->stream));
+    }
+    hipLaunchKernelGGL(finish_var_gram_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, c->stream, dq, dkss, (size_t)mpad, m, dq);
+    BGP_HIP(hipGetLastError());
+    BGP_HIP(bgp_memcpy2d_async(var + (size_t)off * m, (size_t)m * sizeof(double), dq, (size_t)mpad * sizeof(double),
+                               (size_t)m * sizeof(double), nb, hipMemcpyDeviceToHost, c->stream));
+    BGP_HIP(bgp_stream_sync(c->stream));  // (the next chunk reuses the staged host slices' arena and the scratch)
+  }
+  return BGP_OK;
 }
 
 // ------------------------------------------------------------------------------------------

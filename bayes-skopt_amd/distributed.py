@@ -389,6 +389,17 @@ def destroy_process_group():
     _state.update(backend=None, comm=None, rank=0, world=1, device=None, job_prefix=None)
 
 
+def abort_process_group():
+    """This rank is going down OUTSIDE a collective (KeyboardInterrupt, SystemExit): make the peers fail at once instead of
+    leaving them in the all-gather until ``BGP_COMM_TIMEOUT_S`` -- ``ncclCommAbort`` on the native backend.  The gloo group of
+    the CPU tests has no abort; its own time-out applies there."""
+    if _state["backend"] == "rccl" and _state["comm"] is not None:
+        try:
+            _state["comm"].abort()
+        except Exception:
+            pass
+
+
 def group_info(device=None):
     """What formed: backend, world size, the rank count RCCL itself reports (ncclCommCount; None over gloo) and the
     device index of every rank (all-gathered)."""

@@ -4,15 +4,22 @@ The reference builds its GP kernels from skopt's kernel classes, which are sciki
 plus ``gradient_x`` (``bask/utils.py:6``, ``bask/bayesgpr.py:12``); scikit-learn ships in the image,
 skopt does not, so the host-side kernel *objects* (theta get/set in log space, bounds,
 ``clone_with_theta``; ``sklearn/kernels.py:285-338, 733-760``) are scikit-learn's.  No kernel
-*arithmetic* runs on the host: a kernel expression tree is analysed once into a ``KernelPlan`` that
-maps its ``theta`` to the canonical device vector ``h = [log c, log l_1..log l_d, log s2]``
+*arithmetic* runs on the host for the canonical forms: a kernel expression tree is analysed once into a
+``KernelPlan`` that maps its ``theta`` to the canonical device vector ``h = [log c, log l_1..log l_d, log s2]``
 (``include/bgp.h``), and every K(X, X) / K(X*, X) is evaluated by the HIP kernels.
 
-Supported expression trees (anything else raises ``NotImplementedError`` -- there is no CPU path):
+Canonical expression trees (device Gram build):
     [ConstantKernel *] S(length_scale) [+ WhiteKernel]        form "product"
     [ConstantKernel +] S(length_scale) [+ WhiteKernel]        form "sum"
 with S in {RBF, Matern(nu = 0.5 | 1.5 | 2.5)}, isotropic or anisotropic, in any operand order, any
 hyper-parameter optionally "fixed".
+
+Every OTHER tree scikit-learn can evaluate (two stationary terms, products of stationaries, general Matern nu,
+RationalQuadratic, ExpSineSquared, DotProduct, ... -- the reference accepts any kernel, ``bask/bayesgpr.py:148-159``)
+gets a ``GramPlan``: the host evaluates ``kernel_(X)`` with the kernel object, exactly as the reference does
+(``sklearn/_gpr.py:582``), and the device does the factorisation, the solves, the log-likelihood, the inverse and
+the predictive products (``bgp_lml_batch_gram`` / ``bgp_posterior_batch_gram`` / ``bgp_predict_batch_gram``).
+There is still no CPU path for the factorisation.
 """
 import numpy as np
 from sklearn.gaussian_process.kernels import (  # noqa: F401  (re-exported: the bask kernel vocabulary)
@@ -25,7 +32,7 @@ from sklearn.gaussian_process.kernels import (  # noqa: F401  (re-exported: the 
     WhiteKernel,
 )
 
-__all__ = ["RBF", "ConstantKernel", "Matern", "WhiteKernel", "Sum", "Product", "KernelPlan", "analyse_kernel",
+__all__ = ["RBF", "ConstantKernel", "Matern", "WhiteKernel", "Sum", "Product", "KernelPlan", "GramPlan", "analyse_kernel",
            "param_for_white_kernel_in_sum"]
 
 
@@ -61,8 +68,26 @@ def _stationary_name(k):
     return None
 
 
+class GramPlan:
+    """A kernel expression tree without a canonical device form: its matrices are evaluated on the host with the
+    scikit-learn kernel object (what the reference does for every kernel, ``sklearn/_gpr.py:582``) and handed to
+    the device, which does everything behind them.  ``why`` keeps the reason the canonical analysis gave."""
+
+    generic = True
+    form, stationary = "product", "matern52"  # (what the device context is created with; its Gram build is never used)
+
+    def __init__(self, n_theta, why):
+        self.n_theta = n_theta
+        self.why = why
+
+    def canonical(self, theta, d):
+        raise NotImplementedError("this kernel has no canonical device form (%s): its matrices come from the host" % self.why)
+
+
 class KernelPlan:
     """theta (p,) of one kernel expression tree  <->  canonical h (d+2,)."""
+
+    generic = False
 
     def __init__(self, form, stationary, const, ell, white, n_theta, ard):
         self.form = form  # "product" | "sum"
@@ -134,11 +159,23 @@ def _leaves_in_theta_order(kernel, start=0):
     return [(kernel, start, n_free)], start + n_free
 
 
-def analyse_kernel(kernel):
-    """Analyse a kernel expression tree into a KernelPlan (raises NotImplementedError if the tree
-    is not one of the canonical forms)."""
+def analyse_kernel(kernel, strict=False):
+    """Analyse a kernel expression tree: a ``KernelPlan`` for the canonical forms (device Gram build), a ``GramPlan``
+    (host-evaluated kernel matrices, device arithmetic) for every other tree scikit-learn can evaluate
+    (``bask/bayesgpr.py:148-159`` accepts any kernel).  ``strict=True`` raises ``NotImplementedError`` instead of
+    returning a ``GramPlan``."""
     if not isinstance(kernel, Kernel):
         raise TypeError(f"expected a scikit-learn kernel object, got {type(kernel)}")
+    try:
+        return _analyse_canonical(kernel)
+    except NotImplementedError as exc:
+        if strict:
+            raise
+        with np.errstate(divide="ignore"):
+            return GramPlan(len(kernel.theta), str(exc))
+
+
+def _analyse_canonical(kernel):
     with np.errstate(divide="ignore"):  # a zeroed WhiteKernel has theta = log(0)
         leaves, n_theta = _leaves_in_theta_order(kernel)
     index_of = {id(k): (i0, nf) for k, i0, nf in leaves}

@@ -212,6 +212,27 @@ int bgp_sample_y(bgp_ctx* ctx, int b, const double* h_kernel, int m, const doubl
 int bgp_sample_y_batch(bgp_ctx* ctx, int B, const int* pidx, const double* h_kernel, int m, const double* Xq,
                        const double* z, double jitter, double* out, int* status);
 
+/*
+ * Generic kernel expression trees.  The reference accepts ANY skopt / scikit-learn kernel (bask/bayesgpr.py:148-159; priors by
+ * recursion over arbitrary Sum / Product trees, bask/utils.py:154-179) and evaluates it on the host: K = kernel_(X_train)
+ * (sklearn/_gpr.py:582).  For trees that have no canonical device form (two stationary terms, products of stationaries, general
+ * Matern nu, RationalQuadratic, ...) the host side does exactly that with the scikit-learn kernel object and hands the matrices
+ * over; the device does everything behind them -- diagonal add, factorisation, solves, log-likelihood, inverse, predictive
+ * products: the same kernels as the canonical path, no factorisation on the host.
+ *   K      B matrices of n*n doubles, row-major: kernel_(X_train) WITHOUT the alpha term; use_alpha != 0 adds the context's
+ *          alpha_diag on the device (sklearn/_gpr.py:585)
+ *   bgp_lml_batch_gram        as bgp_lml_batch        (sklearn/_gpr.py:537-613 via bask/bayesgpr.py:374)
+ *   bgp_posterior_batch_gram  as bgp_posterior_batch  (bask/bayesgpr.py:200-217); the posteriors stay resident
+ *   bgp_predict_batch_gram    as bgp_predict_batch for the B resident posteriors with host-evaluated cross covariances:
+ *          Ks B*m*n = kernel_(Xq, X_train), kss B*m = kernel_.diag(Xq), Kss B*m*m = kernel_(Xq) (read only when cov != NULL)
+ *          (bask/bayesgpr.py:622-635 -> skopt predict)
+ */
+int bgp_lml_batch_gram(bgp_ctx* ctx, int B, const double* K, int use_alpha, double* lml, int* status);
+int bgp_posterior_batch_gram(bgp_ctx* ctx, int B, const double* K, int use_alpha, double* L, double* alpha, double* K_inv,
+                             double* lml, int* status);
+int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const double* kss, const double* Kss, double* mean,
+                           double* var, double* cov);
+
 /* Number of walker groups (HIP streams) an LML batch is split over: one group's kernels fill the tail
  * of the other group's launches.  Default: automatic -- two groups for batches of >= 64 matrices (+3.7 % at
  * n = 2048 x 128 matrices on MI355X, results bit-identical), one group below that (every group's dependent
@@ -292,6 +313,9 @@ int bgp_comm_allgather(bgp_comm* comm, const double* send, size_t count, double*
 int bgp_comm_allreduce_max(bgp_comm* comm, double* inout, size_t count);
 int bgp_comm_broadcast(bgp_comm* comm, double* buf, size_t count, int root);
 int bgp_comm_barrier(bgp_comm* comm);
+/* This rank is going down outside a collective (interrupt, fatal error): ncclCommAbort, so that the peers' collectives fail at
+ * once (BGP_ERR_COMM on their side) instead of waiting BGP_COMM_TIMEOUT_S; every later call on the communicator answers BGP_ERR_COMM. */
+int bgp_comm_abort(bgp_comm* comm);
 /* ranks RCCL counts in the communicator (ncclCommCount) */
 int bgp_comm_nranks(bgp_comm* comm, int* nranks);
 /* Exact single-ensemble sharding of bask/bayesgpr.py:490-530 (ONE n_walkers ensemble, one RNG): every rank has

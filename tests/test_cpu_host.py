@@ -74,9 +74,18 @@ def test_kernel_analysis_and_canonical_mapping(bask):
     k4.set_params(k2=sk.WhiteKernel(noise_level=0.0))
     with np.errstate(divide="ignore"):
         assert K.analyse_kernel(k4).canonical(k4.theta, 2)[0, -1] == -np.inf
-    for bad in (sk.DotProduct(), sk.RBF(1.0) * sk.RBF(2.0), sk.Matern(nu=0.7), sk.RBF() + sk.RBF()):
+    # trees without a canonical device form: a GramPlan (host-evaluated kernel matrices, device arithmetic); strict refuses
+    for other in (sk.DotProduct(), sk.RBF(1.0) * sk.RBF(2.0), sk.Matern(nu=0.7), sk.RBF() + sk.RBF(),
+                  sk.Matern(nu=2.5) * sk.RBF() + sk.WhiteKernel(), sk.RationalQuadratic()):
+        plan = K.analyse_kernel(other)
+        assert isinstance(plan, K.GramPlan) and plan.generic and plan.n_theta == len(other.theta)
         with pytest.raises(NotImplementedError):
-            K.analyse_kernel(bad)
+            plan.canonical(other.theta, 2)
+        with pytest.raises(NotImplementedError):
+            K.analyse_kernel(other, strict=True)
+    assert not pl.generic
+    with pytest.raises(TypeError):
+        K.analyse_kernel("rbf")
     assert K.param_for_white_kernel_in_sum(k) == (True, "k2")
     assert K.param_for_white_kernel_in_sum(k3)[0] is False
 
