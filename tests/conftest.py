@@ -33,3 +33,18 @@ def synth(n, d, seed):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def assert_variance_close(var_dev, var_ref, selfdiff, rtol=1e-6, factor=4.0):
+    """The north star's tolerance on a predictive variance: 1e-6 RELATIVE -- except where the variance is the remainder of a
+    cancellation ``k_** - k_*^T K^-1 k_*`` that the reference itself only knows to ``selfdiff``, the difference between its own
+    two formulas (skopt's einsum with the explicit inverse vs scikit-learn's triangular solve; stored in the golden file or
+    computed by ``oracle.predict_variance_selfdiff``).  There the bound is ``factor`` times the reference's own uncertainty,
+    not a hand-picked number."""
+    var_dev, var_ref = np.asarray(var_dev), np.asarray(var_ref)
+    tol = np.maximum(rtol * np.abs(var_ref), factor * float(selfdiff))
+    err = np.abs(var_dev - var_ref)
+    worst = int(np.argmax(err - tol))
+    assert np.all(err <= tol), ("variance off by %.3e at %d (value %.3e, 1e-6 relative = %.3e, %g x reference self-difference "
+                                "= %.3e)" % (err[worst], worst, var_ref[worst], rtol * abs(var_ref[worst]), factor,
+                                             factor * float(selfdiff)))

@@ -220,7 +220,14 @@ def gen_predict(out):
             # noise_set_to_zero: swap the white kernel for WhiteKernel(0) WITHOUT refitting
             g.kernel_.set_params(k2=sk.WhiteKernel(noise_level=0.0))
             mean0, std0, cov0 = skopt_predict(g, K_inv, Xq, return_cov=True)
+            # the reference's own uncertainty about a predictive variance: skopt's formula (einsum with the explicit inverse,
+            # above) against scikit-learn's (triangular solve, sklearn/_gpr.py:470-489) on the same factor, with and without noise
+            K_trans = g.kernel_(Xq, g.X_train_)
+            V = solve_triangular(g.L_, K_trans.T, lower=True)
+            var0_sk = g.kernel_.diag(Xq) - np.einsum("ij,ij->j", V, V)
             pre = f"c{case}_"
+            rec[pre + "var0_selfdiff"] = np.array(np.abs(std0 ** 2 - np.maximum(var0_sk, 0.0)).max())
+            rec[pre + "var_selfdiff"] = np.array(np.abs(std ** 2 - s2 ** 2).max())
             rec[pre + "X"], rec[pre + "y"], rec[pre + "Xq"] = X, y, Xq
             rec[pre + "alpha_diag"] = np.broadcast_to(alpha, (n,)).copy()
             rec[pre + "theta"] = th

@@ -25,7 +25,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden, synth
+from conftest import ROOT, assert_variance_close, load_golden, synth
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-6
@@ -143,14 +143,16 @@ def test_dense_posterior_mean_and_variance(lib, tag):
     np.testing.assert_allclose(a[-16:], g[tag + "_alpha_tail"], rtol=RTOL, atol=RTOL * ascale)
     mean, var = ctx.predict(th, Xq)
     np.testing.assert_allclose(mean[0], g[tag + "_mean"], rtol=RTOL, atol=RTOL * np.abs(g[tag + "_mean"]).max())
-    prior_var = np.exp(th[0])
-    vtol = min(RTOL * prior_var, 200.0 * float(g[tag + "_var_selfdiff"]))
-    np.testing.assert_allclose(var[0], g[tag + "_std"] ** 2, rtol=0, atol=vtol)
+    # the variance itself: 1e-6 relative, or -- where it is the remainder of a cancellation at cond(K) up to 4e7 -- 8 x the
+    # difference between the reference's own two formulas (stored by the generator: 1.2e-10 / 1.3e-10), whichever is larger.
+    # (Both reference formulas share ONE LAPACK factor, so their difference understates what a second factorisation may differ
+    # by: measured 4.6 x at n = 4096; round 4 allowed 200 x.)
+    assert_variance_close(var[0], g[tag + "_std"] ** 2, g[tag + "_var_selfdiff"], factor=8.0)
     th0 = th.copy()
     th0[-1] = -np.inf
     mean0, var0 = ctx.predict(th0, Xq)
     np.testing.assert_array_equal(mean0, mean)
-    np.testing.assert_allclose(var0[0], g[tag + "_std0"] ** 2, rtol=0, atol=vtol)
+    assert_variance_close(var0[0], g[tag + "_std0"] ** 2, g[tag + "_var_selfdiff"], factor=8.0)
     ctx.close()
 
 

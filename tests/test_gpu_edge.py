@@ -326,3 +326,64 @@ def test_two_contexts_from_two_threads_and_a_wait_on_another_thread(lib, O):
     t.join()
     np.testing.assert_allclose(got["v"], ref, rtol=RTOL)
     ctx.close()
+
+
+def test_a_failing_call_on_one_thread_leaves_another_threads_downloads_alone(lib, O):
+    """The arena's bookkeeping is shared, a FAILED call must not be: thread A runs into the routine BGP_ERR_NOTPD of
+    bgp_sample_y (a singular predictive covariance, no jitter) over and over while thread B's chunked LML calls and predicts
+    have their downloads staged in the same arena.  Dropping "all pending downloads" on A's failure (rounds 3-4) left B's
+    results unpacked -- uninitialised caller buffers under BGP_OK; the drop is scoped to the failing thread now."""
+    import threading
+
+    rng = np.random.RandomState(4)
+    n, d = 300, 2
+    X = rng.uniform(size=(n, d))
+    y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n)
+    H = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]]) + 0.1 * rng.randn(12, d + 2)
+    ref = O.lml_batch(X, y, np.full(n, 1e-10), H)
+    Xq = rng.uniform(size=(40, d))
+    stop, errs, counts = threading.Event(), [], {"notpd": 0, "ok": 0}
+
+    def failing():
+        try:
+            ctx = lib.Context(X, y, 1e-10, max_batch=2)
+            ctx.posterior(H[:1])
+            hk = H[0].copy()
+            hk[-1] = -np.inf
+            Xdup = np.vstack([Xq[:8], Xq[:8]])  # duplicated points, no noise, no jitter: an exactly singular covariance
+            z = np.zeros((1, 16))
+            while not stop.is_set():
+                try:
+                    ctx.sample_y(0, hk, Xdup, z, jitter=0.0)
+                except lib.NotPositiveDefinite:
+                    counts["notpd"] += 1
+            ctx.close()
+        except Exception as exc:  # pragma: no cover
+            errs.append(exc)
+
+    def working():
+        try:
+            ctx = lib.Context(X, y, 1e-10, max_batch=4)  # 12 proposals in chunks of 4: downloads through the arena
+            ctx.posterior(H[:1])
+            m0, v0 = ctx.predict(H[:1], Xq)
+            for _ in range(150):
+                got = np.full(len(H), np.nan)
+                got[:] = ctx.lml(H)
+                np.testing.assert_allclose(got, ref, rtol=RTOL)
+                m1, v1 = ctx.predict(H[:1], Xq)
+                np.testing.assert_array_equal(m1, m0)
+                np.testing.assert_array_equal(v1, v0)
+                counts["ok"] += 1
+            ctx.close()
+        except Exception as exc:
+            errs.append(exc)
+        finally:
+            stop.set()
+
+    ta, tb = threading.Thread(target=failing), threading.Thread(target=working)
+    ta.start()
+    tb.start()
+    tb.join()
+    ta.join()
+    assert not errs, errs
+    assert counts["ok"] == 150 and counts["notpd"] > 0, counts

@@ -95,7 +95,10 @@ def test_bayesgpr_with_warping_end_to_end(O):
     mean, std = gp.predict(Xq, return_std=True)
     mo, so = O.predict(O.warp_inputs(X, w), y, np.full(n, 1e-10), gp.theta, O.warp_inputs(Xq, w))
     np.testing.assert_allclose(mean, mo, rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose(std, so, rtol=1e-5, atol=1e-7)
+    from conftest import assert_variance_close
+
+    assert_variance_close(std**2, so**2, O.predict_variance_selfdiff(O.warp_inputs(X, w), y, np.full(n, 1e-10), gp.theta,
+                                                                      O.warp_inputs(Xq, w)))
     with pytest.raises(ValueError):
         gp.predict(np.array([[1.5]]))
     np.testing.assert_allclose(gp.unwarp(gp.warp(Xq)), Xq, rtol=1e-8)
