@@ -283,8 +283,8 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_FUSED_GRAM", "BGP_KBUILD1", "BGP_PANELS",
-                                "BGP_PANEL_WIDTH", "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_NCRIT", "BGP_PS_PAIR", "BGP_PS_PSPLIT", "BGP_PS_STREAM", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_ROWQUAD_T", "BGP_SMALL_SPLIT", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_PANELS",
+                                "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -350,12 +350,6 @@ extern "C" int bgp_ctx_create(int device, int n, int d, const double* X, const d
     c->nstreams = ns;
     const char* envps = getenv("BGP_PERSIST");  // 0: never, 1: whenever the batch fits (<= 64 matrices, n > 128); unset: automatic
     c->persist = envps ? (atoi(envps) != 0 ? 1 : 0) : -1;
-    const char* envss = getenv("BGP_SMALL_SPLIT");  // 1: n <= 128 through the two-launch path (A/B of the fused kernel)
-    c->use_small_split = (envss && atoi(envss) != 0) ? 1 : 0;
-    const char* envk = getenv("BGP_KBUILD1");
-    c->use_kbuild1 = (envk && atoi(envk) != 0) ? 1 : 0;
-    const char* envf = getenv("BGP_FUSED_GRAM");
-    c->fused_gram = (envf && atoi(envf) != 0) ? 1 : 0;
     c->panels = 2;
     c->panels_auto = 1;
     const char* envp = getenv("BGP_PANELS");
@@ -583,11 +577,10 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
     else
       BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     int rc = BGP_OK;
-    const bool fused_small = c->nblk == 1 && !warp && !c->use_small_split;
-    const bool fused_gram = c->fused_gram && c->nblk >= 2 && !c->use_kbuild1;
+    const bool fused_small = c->nblk == 1 && !warp;
     // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
     // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-    const bool use_ps = !fused_small && !fused_gram && !c->timing && bgp_persist_fits(c, nb) &&
+    const bool use_ps = !fused_small && !c->timing && bgp_persist_fits(c, nb) &&
                         (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
     if (use_ps) c->ps_calls++;
     if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
@@ -601,20 +594,13 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
                                hipMemcpyHostToDevice, c->stream));
       rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
       if (rc) return rc;
-      if (fused_gram) {
-        S4Gen gen;
-        rc = bgp_launch_kbuild_col0(c, 0, nb, c->stream, 1, c->dXwB, nd, &gen);
-        if (rc) return rc;
-        rc = bgp_launch_cholesky_gen(c, 0, nb, c->stream, 0, &gen);
+      rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
+      if (rc) return rc;
+      if (use_ps) {
+        rc = bgp_launch_cholesky_persist(c, nb);
+        if (!rc) c->ps_inflight = 1;
       } else {
-        rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
-        if (rc) return rc;
-        if (use_ps) {
-          rc = bgp_launch_cholesky_persist(c, nb);
-          if (!rc) c->ps_inflight = 1;
-        } else {
-          rc = bgp_launch_cholesky(c, nb, 0);
-        }
+        rc = bgp_launch_cholesky(c, nb, 0);
       }
       if (rc) return rc;
     } else if (use_ps) {
@@ -625,16 +611,9 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       if (rc) return rc;
       c->ps_inflight = 1;
     } else if (ng == 1) {
-      if (fused_gram) {
-        S4Gen gen;
-        rc = bgp_launch_kbuild_col0(c, 0, nb, c->stream, 1, c->dXeff, 0, &gen);
-        if (rc) return rc;
-        rc = bgp_launch_cholesky_gen(c, 0, nb, c->stream, 0, &gen);
-      } else {
-        rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
-        if (rc) return rc;
-        rc = bgp_launch_cholesky(c, nb, 0);
-      }
+      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+      if (rc) return rc;
+      rc = bgp_launch_cholesky(c, nb, 0);
       if (rc) return rc;
     } else {
       BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
@@ -642,16 +621,9 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
         const int gb = std::min(gsz, nb - o);
         hipStream_t st = c->gstream[g];
         BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
-        if (fused_gram) {
-          S4Gen gen;
-          rc = bgp_launch_kbuild_col0(c, o, gb, st, 1, c->dXeff, 0, &gen);
-          if (rc) return rc;
-          rc = bgp_launch_cholesky_gen(c, o, gb, st, 0, &gen);
-        } else {
-          rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
-          if (rc) return rc;
-          rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
-        }
+        rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
+        if (rc) return rc;
+        rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
         if (rc) return rc;
         BGP_HIP(hipEventRecord(c->ev_done[g], st));
         BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));

@@ -13,7 +13,7 @@
 //   panel solve   X_i = A_ik W_kk^T  (fp64 MFMA),  y_i -= X_i z_k
 //   trailing upd. A_ij -= X_i X_j^T  (fp64 MFMA; the n^3/3 bulk -- the kernel the roofline fraction is quoted on)
 // Panel solve and trailing update are trsm4_kernel / syrk4_kernel on the LDS-DMA ring (bgp_syrk4.hip):
-//   * LML path (bgp_lml_batch; the MCMC hot loop): scheduled in groups of P block columns by bgp_launch_cholesky_gen;
+//   * LML path (bgp_lml_batch; the MCMC hot loop): scheduled in groups of P block columns by bgp_launch_cholesky_slice;
 //   * posterior builds on the augmented matrix (bgp_post.hip; once per sample(), per hyper-posterior draw of an
 //     acquisition and per gradient evaluation): the same kernels in single-panel mode with the active-row remap of
 //     bgp_rowblk (bgp_device.h);
@@ -199,16 +199,6 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   a.ystride = ld;
   a.mstride = (size_t)ld * ld;
   {
-    // P(I) -- the pre-update of block (I, I-1) that the chain waits for -- in 1, 2 or 4 column slices with a workgroup each
-    // (BGP_PS_PSPLIT; default 1, chain pairs 4: their cycle runs THROUGH this task)
-    static int psp = -1;
-    if (psp < 0) {
-      const char* e = getenv("BGP_PS_PSPLIT");
-      psp = (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) ? atoi(e) : 0;
-    }
-    a.psplit = psp;  // (0: decided below, once pair mode is known)
-  }
-  {
     // chain pairs (bgp_pf.h): two workgroups per matrix alternate over the block columns, the idle one preparing the next
     // diagonal block UNDER the other's factorisation; needs 2 * Bpad CUs and at least as many (and 32) left for the tile role.
     // BGP_PS_PAIR = 0 / 1 fixes it.
@@ -222,29 +212,22 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     const bool fits = nblk >= 3 && ncu - 2 * a.Bpad >= std::max(32, B);
     a.pair = (fits && (want == 1 || (want == -1 && bgp_pair_auto_rule(nblk, B)))) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
-    if (a.psplit == 0) a.psplit = a.pair ? 4 : 1;
+    // P(I) -- the pre-update of block (I, I-1) that the chain waits for -- as ONE task behind a single chain workgroup, in four
+    // 64 x 64 quadrants (and Dg(I) in three) behind chain pairs, whose cycle runs THROUGH this task (the
+    // two-slice and the mixed variants measured slower and left the library in round 5)
+    a.psplit = a.pair ? 4 : 1;
     a.dsplit = a.psplit == 4 ? 3 : 1;
     a.total = bgp_ps_total_tasks(B, nblk, a.psplit);
-    {
-      static int ns = -1;
-      if (ns < 0) {
-        const char* e = getenv("BGP_PS_STREAM");
-        ns = e ? atoi(e) : 3;  // (3: S(J+3, J) as well -- it feeds the quadrants ahead of the next column's critical solve)
-      }
-      a.ncrit_stream = ns;
-    }
+    // pair mode: the panel solves S(J+2, J) and S(J+3, J) follow pf_block(J) row block by row block (S(J+3, J) feeds the
+    // quadrants ahead of the next column's critical solve; streaming fewer measured slower)
+    a.ncrit_stream = 3;
   }
   const int tile_wgs = std::min(a.total, ncu - a.nchain);
   {
     // critical pool of the tile role: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
     // workgroups of their own, one per task of a column.  Measured in round 3: with up to ~10 block columns the chain waits less
     // (n = 1024 x 32: 0.63 -> 0.59 ms, 975 x 50: 0.93 -> 0.84); with more, these left-looking tasks are long and want the
-    // look-ahead the single list gives them (n = 2048 x 9: 1.20 -> 1.37 ms with the pool).  BGP_PS_NCRIT fixes the number.
-    static int ncf = -2;
-    if (ncf == -2) {
-      const char* e = getenv("BGP_PS_NCRIT");
-      ncf = e ? atoi(e) : -1;
-    }
+    // look-ahead the single list gives them (n = 2048 x 9: 1.20 -> 1.37 ms with the pool).
     // Chain pairs with more block columns: their 12 critical tasks per column and matrix are SHORT (quadrants that follow their
     // inputs) and numerous -- behind the long bulk solves of one list they start late: a pool of 48 (one matrix) / 96 workgroups
     // (n = 4096 x 1: 1.361 -> 1.330 ms, x 2: 2.022 -> 1.861; 1536 x 4: 0.588 -> 0.545, x 8: 0.666 -> 0.578, x 9: 0.847 -> 0.651)
@@ -253,8 +236,10 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     // 0.493, 1152 x 24: 0.580 -> 0.555, 975 x 25: 0.525 -> 0.508)
     const int auto_crit = nblk <= 10 ? ((a.pair || B > 32) ? std::min((a.psplit + 1 + a.dsplit + (a.psplit == 4 ? 4 : 0)) * B, tile_wgs / 2) : 0)
                                      : (a.pair && a.psplit == 4 ? std::min(B == 1 ? 48 : 96, tile_wgs / 2) : 0);
-    a.ncrit = ncf >= 0 ? ncf : auto_crit;
-    if (a.ncrit > tile_wgs) a.ncrit = tile_wgs;
+    a.ncrit = auto_crit;
+    // (at least one workgroup is left for the bulk list whenever it has tasks: critical tasks spin-wait on bulk solves of the
+    // previous column)
+    if (a.ncrit > tile_wgs - 1) a.ncrit = std::max(0, tile_wgs - 1);
   }
   a.spin_limit = limit;
   a.trace = nullptr;
@@ -288,7 +273,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
 
 // LDS-DMA pipelined trailing update and panel solve (bgp_syrk4.hip)
 void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
-                      int K, int jstart, int colmode, int B, const S4Gen* gen);
+                      int K, int jstart, int colmode, int B);
 void bgp_launch_trsm4(hipStream_t st, int B, double* dK, double* dW, double* dyw, int* dstatus, int ld, size_t mstride,
                       int ystride, int nblk, int k, int augmented);
 
@@ -322,12 +307,6 @@ int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
 }
 
 int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
-  return bgp_launch_cholesky_gen(ctx, off, B, st, augmented, nullptr);
-}
-
-// gen != nullptr (LML path only): the matrices hold block column 0 only (bgp_launch_kbuild_col0); the trailing updates
-// of the FIRST group of block columns -- the first launches to touch any other tile -- generate the Gram entries.
-int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -364,14 +343,14 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 5, st);
-          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, k == 0 ? gen : nullptr);
+          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
           bgp_tend(ctx, st);
         }
       }
       const int nt = nblk - (k + np);
       if (nt > 0) {
         bgp_tbegin(ctx, 3, st);
-        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B, k == 0 ? gen : nullptr);
+        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         bgp_tend(ctx, st);
       }
       k += np;
@@ -390,7 +369,7 @@ int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int au
     bgp_launch_trsm4(st, B, dK, dW, dyw, dstatus, ld, mstride, ystride, nblk, k, 1);
     bgp_tend(ctx, st);
     bgp_tbegin(ctx, 3, st);
-    bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128, 0, 2, B, nullptr);
+    bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128, 0, 2, B);
     bgp_tend(ctx, st);
   }
   BGP_HIP(hipGetLastError());

@@ -148,9 +148,6 @@ struct bgp_ctx {
   int has_warp = 0;
   double* dXs = nullptr;     // scaled inputs of the current batch, k-major: max_batch * dpad * npad (bgp_kbuild.hip)
   size_t cap_xs = 0;
-  int use_small_split = 0;   // env BGP_SMALL_SPLIT=1: no fused n <= 128 kernel (A/B measurements)
-  int use_kbuild1 = 0;       // env BGP_KBUILD1=1: the unpipelined Gram build (A/B measurements)
-  int fused_gram = 0;        // env BGP_FUSED_GRAM=1: Gram tiles generated inside the first trailing update that touches them
   double* dy = nullptr;      // npad (zero padded)
   double* dalpha = nullptr;  // npad
   size_t cap_n = 0;          // capacity (rows) of the three buffers above
@@ -290,7 +287,7 @@ struct PsArgs {
   int pair;           // 1: TWO chain workgroups per matrix that alternate over the block columns (bgp_pf.h, ps_chain_role)
   int Bpad;           // pair mode: chain workgroup p of matrix b is block p * Bpad + b (Bpad = B rounded up to 8: same XCD)
   int nchain;         // chain workgroups at the head of the grid (B, or 2 * Bpad)
-  int psplit;         // parts a pre-update task P(I) is dealt out in (1, 2 column slices or 4 quadrants): subrdy[I] counts to psplit
+  int psplit;         // parts a pre-update task P(I) is dealt out in (1, or 4 quadrants behind chain pairs): subrdy[I] counts to psplit
   int dsplit;         // parts of a diagonal block's task Dg(I) (3 quadrants with psplit == 4, else 1): diagrdy[I] counts to dsplit
   int ncrit_stream;   // pair mode: panel solves S(I, J) with I <= J + ncrit_stream follow pf_block(J) row block by row block
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
@@ -368,20 +365,7 @@ int bgp_gram_load(bgp_ctx* c, int nb, const double* K, int augmented, int use_al
 
 // ---- kernels launched across translation units ----
 // K-build: lower-triangular tiles of the jittered Gram matrix of walker b into dK[b] (npad x npad).
-// Gram generation inside the first trailing update that touches a tile (bgp_syrk4.hip): everything a tile needs to
-// produce its own K entries instead of loading them.  Xs = k-major scaled inputs of the batch slice (xscale_kernel).
-struct S4Gen {
-  const double* Xs = nullptr;     // B x dpad x npad
-  const double* alpha = nullptr;  // n diagonal terms (or nullptr)
-  const double* H = nullptr;      // B x (d + 2) canonical hyper-parameters
-  int n = 0, d = 0, npad = 0, dpad = 0;
-  int stat = 0, form = 0;         // kernel family (template dispatch)
-};
 int bgp_launch_kbuild(bgp_ctx* ctx, int B, int full_square, int augmented, int use_alpha);
-// scaled inputs + block column 0 of the Gram matrices only; fills `gen` for the trailing updates that generate the rest
-int bgp_launch_kbuild_col0(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha, const double* dXb, size_t xstride,
-                           S4Gen* gen);
-int bgp_launch_cholesky_gen(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, const S4Gen* gen);
 // same for the slice [off, off+B) of the current batch on an explicit stream
 int bgp_launch_kbuild_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_square, int augmented,
                             int use_alpha);

@@ -366,7 +366,7 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   bgp_tbegin(ctx, 0, st);
   // the pipelined build pays a second (tiny) launch and groups KB2_TPW tiles per workgroup: below ~2000 tiles the
   // plain kernel is faster (n = 1024 x 32 walkers: 0.069 vs 0.10 ms)
-  if (ctx->use_kbuild1 || B8 * ntiles < 2048) {
+  if (B8 * ntiles < 2048) {
     KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
                 hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(B8 * ntiles), dim3(256), 0, st, dXb, ctx->dalpha, dH,
                                    dKo, ctx->dy, dywo, ctx->n, d, npad, nblk, B, full_square, (int)ldm, use_alpha,
@@ -387,35 +387,6 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   }
   bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
-  return BGP_OK;
-}
-
-// LML path with Gram generation fused into the trailing updates: only block column 0 (what potrf(0) / trsm(0) read) is
-// built here; every other tile is produced by the first trailing update that touches it (bgp_syrk4.hip, S4Gen).
-int bgp_launch_kbuild_col0(bgp_ctx* ctx, int off, int B, hipStream_t st, int use_alpha, const double* dXb, size_t xstride,
-                           S4Gen* gen) {
-  const int nblk = ctx->nblk, npad = ctx->npad, d = ctx->d;
-  const int B8 = 8 * ((B + 7) / 8);
-  const int dpad = ((d + KB_DK - 1) / KB_DK) * KB_DK;
-  int rc = ensure_xs(ctx, dpad);
-  if (rc) return rc;
-  double* dKo = ctx->dK + (size_t)off * npad * npad;
-  const double* dH = ctx->dh + (size_t)off * (d + 2);
-  double* dywo = ctx->dyw + (size_t)off * npad;
-  double* dXs = ctx->dXs + (size_t)off * dpad * npad;
-  bgp_tbegin(ctx, 0, st);
-  hipLaunchKernelGGL(xscale_kernel, dim3(64, B), dim3(256), 0, st, dXb, xstride, dH, dXs, ctx->n, d, npad, dpad);
-  const int ngroups = (nblk + KB2_TPW - 1) / KB2_TPW;
-  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
-              hipLaunchKernelGGL((kbuild2_kernel<S, F>), dim3(B8 * ngroups), dim3(64 * KB2_WAVES), 0, st, dXs, ctx->dalpha,
-                                 dH, dKo, ctx->dy, dywo, ctx->n, d, npad, dpad, nblk, B, 2, npad, use_alpha));
-  bgp_tend(ctx, st);
-  BGP_HIP(hipGetLastError());
-  gen->Xs = dXs;
-  gen->alpha = use_alpha ? ctx->dalpha : nullptr;
-  gen->H = dH;
-  gen->n = ctx->n, gen->d = d, gen->npad = npad, gen->dpad = dpad;
-  gen->stat = ctx->ks.stationary, gen->form = ctx->ks.form;
   return BGP_OK;
 }
 

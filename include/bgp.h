@@ -237,12 +237,16 @@ int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const d
  * of the other group's launches.  Default: automatic -- two groups for batches of >= 64 matrices (+3.7 % at
  * n = 2048 x 128 matrices on MI355X, results bit-identical), one group below that (every group's dependent
  * chain is as long as the whole batch's, nothing to gain).  This call, or the environment variable
- * BGP_STREAMS read at context creation, forces a fixed group count.  Other environment switches read at
- * context creation: BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
- * (see bgp_set_persist) and the A/B switches BGP_KBUILD1=1 (unpipelined Gram build), BGP_SMALL_SPLIT=1 (n <= 128 through
- * the two-launch path), BGP_FUSED_GRAM=1 (Gram tiles generated inside the first trailing update); process-wide:
- * BGP_PANEL_WIDTH, BGP_ROWQUAD_T, BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_NCRIT, BGP_PS_TRACE,
- * BGP_PS_PAIR, BGP_PS_PSPLIT, BGP_PS_STREAM, BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  A BGP_* variable the library does not read is reported once on stderr. */
+ * BGP_STREAMS read at context creation, forces a fixed group count.
+ *
+ * Environment switches the library reads (a BGP_* variable it does not read is reported once on stderr).  Schedule switches --
+ * each selects between code paths whose results are bit-identical (tests/test_gpu_edge.py, tests/test_gpu_persist.py):
+ *   BGP_STREAMS (this call), BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
+ *   (bgp_set_persist), BGP_PS_PAIR (0 / 1: one or two chain workgroups per matrix on the launch-free path; default by shape).
+ * Waits and diagnostics (no effect on results): BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_TRACE,
+ *   BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  The A/B switches of earlier rounds (BGP_FUSED_GRAM, BGP_KBUILD1,
+ *   BGP_SMALL_SPLIT, BGP_PS_NCRIT / _PSPLIT / _STREAM, BGP_PANEL_WIDTH, BGP_ROWQUAD_T) left the library in round 5 with the
+ *   measured-slower variants they selected. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
 
 /* hipDeviceSynchronize on `device` (timing brackets in bench.py). */

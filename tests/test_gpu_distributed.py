@@ -222,3 +222,52 @@ def test_collective_error_path_through_rccl():
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["sound1"] == [True, [0], True] and res.stderr.count("timed out") >= 1
+
+
+_SOAK_WORKER = r"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, %r)
+import bayes_skopt_amd as bask
+from bayes_skopt_amd import _lib, distributed
+rank, local_rank, ws = distributed.init_process_group()
+comm = distributed._state["comm"]
+rng = np.random.RandomState(0)
+n, d, B = 2048, 16, 16     # the per-GPU share of BASELINE config C at N = 8: 16 matrices of n = 2048 (launch-free by the automatic rule)
+X = rng.uniform(size=(n, d)); y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(n); y = (y - y.mean()) / y.std()
+ctx = _lib.Context(X, y, 1e-10, max_batch=B)
+base = np.concatenate([[0.0], np.full(d, np.log(0.3)), [np.log(0.01)]])
+blocks = [base + 1e-2 * rng.randn(B, d + 2) for _ in range(4)]
+ctx.set_persist(0)
+refs = [ctx.lml(H) for H in blocks]
+ctx.set_persist(-1)        # automatic: what a rank of the sharded ensemble runs with
+t0 = time.perf_counter()
+bad = 0
+for it in range(2000):
+    H = blocks[it %% 4]
+    assert ctx.lml_submit(H)
+    vals, errs = ctx.lml_wait_allgather(comm, B)
+    bad += int(not np.array_equal(vals[0], refs[it %% 4])) + int(np.any(errs != 0))
+stats = ctx.persist_stats()
+print(json.dumps({"bad": bad, "stats": [stats["calls"], stats["timeouts"], int(stats["disabled"])], "ms_per_half_step": (time.perf_counter() - t0) / 2000 * 1e3}))
+ctx.close()
+distributed.destroy_process_group()
+"""
+
+
+def test_launch_free_shard_beside_a_live_rccl_communicator_2000_half_steps():
+    """The 16-matrix shard of the sharded ensemble takes the launch-free factorisation by the automatic rule; include/bgp.h tells
+    contexts that share their device with collectives to switch it off.  They do not have to: the per-half-step all-gather waits
+    for the context's stream through an event and the next batch is submitted after the host has the gathered values, so
+    ps_kernel and the RCCL kernel are never on the device together.  2000 half-steps of exactly that shape through a live RCCL
+    communicator (one rank: the box has one GPU): every value bit-identical to the launch schedule, every status word 0, zero
+    time-outs."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), BGP_DIST_FORCE="1",
+               BGP_DIST_BACKEND="rccl", HSA_ENABLE_IPC_MODE_LEGACY="0", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    env.pop("BGP_PERSIST", None)
+    res = subprocess.run([sys.executable, "-c", _SOAK_WORKER % ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    print(d)
+    assert d["bad"] == 0
+    assert d["stats"][0] == 2000 and d["stats"][1] == 0 and d["stats"][2] == 0, d  # 2000 launch-free calls, no time-out

@@ -59,18 +59,17 @@ def _run(env, shapes=SHAPES):
     return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:]), res.stderr
 
 
-@pytest.mark.parametrize("ncrit", ["auto", "0", "24", "pair"])
-def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit):
-    """ncrit = workgroups of the tile kernel's critical pool (automatic: one per critical task of a column up to ten block
-    columns, none beyond; 0: one ticket list; 24: fewer than the critical tasks of a column -- they queue); "pair": chain
-    PAIRS (BGP_PS_PAIR=1: two chain workgroups per matrix alternate over the block columns, the idle one preparing the next
-    diagonal block under the other's factorisation from the rows of W as they are published)."""
+@pytest.mark.parametrize("chains", ["auto", "single", "pair"])
+def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(chains):
+    """"single": ONE chain workgroup per matrix (BGP_PS_PAIR=0); "pair": chain PAIRS (BGP_PS_PAIR=1: two chain workgroups per
+    matrix alternate over the block columns, the idle one preparing the next diagonal block under the other's factorisation
+    from the rows of W as they are published; the critical pre-updates in quadrants on a pool of their own); "auto": whichever
+    bgp_pair_auto_rule picks per shape.  BGP_PS_PAIR is the only schedule switch the launch-free path still reads (round 5
+    removed BGP_PS_NCRIT / BGP_PS_PSPLIT / BGP_PS_STREAM with the variants they selected)."""
     ref, _ = _run({"BGP_PERSIST": "0"})
     env = {"BGP_PERSIST": "1"}
-    if ncrit == "pair":
-        env["BGP_PS_PAIR"] = "1"
-    elif ncrit != "auto":
-        env["BGP_PS_NCRIT"] = ncrit
+    if chains != "auto":
+        env["BGP_PS_PAIR"] = "1" if chains == "pair" else "0"
     got, err = _run(env)
     assert "timed out" not in err, err[-1500:]
     for k in ref:
@@ -85,20 +84,12 @@ def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(ncrit
     assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
 
 
-@pytest.mark.parametrize("switches", [
-    {"BGP_PS_PAIR": "1", "BGP_PS_STREAM": "0"},   # chain pairs, no panel solve follows the factorisation row block by row block
-    {"BGP_PS_PAIR": "1", "BGP_PS_STREAM": "2"},   # ... only the column's critical one
-    {"BGP_PS_PAIR": "1", "BGP_PS_PSPLIT": "2"},   # the critical pre-update in two column slices (no quadrants, no Q tasks)
-    {"BGP_PS_PAIR": "1", "BGP_PS_PSPLIT": "1"},   # ... whole
-    {"BGP_PS_PAIR": "0", "BGP_PS_PSPLIT": "4"},   # quadrant tasks behind ONE chain workgroup per matrix
-    {"BGP_PS_PAIR": "1", "BGP_PS_NCRIT": "5"},    # fewer pool workgroups than critical tasks of a column
-], ids=lambda d: ",".join(f"{k[7:]}={v}" for k, v in d.items()))
-def test_the_documented_switches_of_the_launch_free_path_keep_the_bits(switches):
-    """INTEGRATION.md lists BGP_PS_PAIR / BGP_PS_PSPLIT / BGP_PS_STREAM / BGP_PS_NCRIT: whatever they are set to, the factors,
-    statuses and log-likelihoods are those of the launch schedule (failing matrices included)."""
+@pytest.mark.parametrize("pair", ["0", "1"])
+def test_both_chain_schemes_keep_the_bits_on_further_shapes(pair):
+    """The shapes the automatic rule sends to the OTHER scheme too: few and many matrices, 5 to 16 block columns, a ragged n."""
     shapes = [(1024, 8, 5), (2048, 16, 2), (640, 5, 3), (1536, 4, 9)]
     ref, _ = _run({"BGP_PERSIST": "0"}, shapes)
-    got, err = _run(dict({"BGP_PERSIST": "1"}, **switches), shapes)
+    got, err = _run({"BGP_PERSIST": "1", "BGP_PS_PAIR": pair}, shapes)
     assert "timed out" not in err, err[-1500:]
     for k in ref:
         assert got[k]["lml"] == ref[k]["lml"] and got[k]["status"] == ref[k]["status"], k
