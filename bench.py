@@ -80,6 +80,30 @@ def trailing_flops_split(n, nb=NB):
     return col, total - col
 
 
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s (6.29 TB/s measured streaming copy)
+HBM_COPY_MEASURED_GBS = 6290.0
+PIVOT_CHAIN_NS = 81.0      # measured latency of one pivot of the in-register 16 x 16 micro-Cholesky (tools/potrf_bench, PF_TRACE)
+
+
+def hot_path_bytes(n, d, nb=NB):
+    """Algorithmic HBM bytes per matrix and half-step of the launch schedule's HBM-side kernels:
+    Gram build: every lower 128 x 128 tile written once; panel solve: the sub-diagonal block column read and written once per
+    block column; look-ahead column launches: block column c read and written once + its K = 128 (j+1) panel rows read once."""
+    nblk = n // nb
+    kbuild = nblk * (nblk + 1) // 2 * nb * nb * 8.0
+    trsm = sum(2.0 * 8.0 * nb * (n - (k + 1) * nb) for k in range(nblk - 1))
+    P = 4 if nblk >= 12 else 2
+    col, k = 0.0, 0
+    while k < nblk:
+        np_ = min(P, nblk - k)
+        for j in range(np_ - 1):
+            c = k + j + 1
+            m_c = n - c * nb
+            col += 16.0 * (nb * m_c - nb * (nb - 1) / 2.0) + 8.0 * m_c * nb * (j + 1)
+        k += np_
+    return {"kbuild": kbuild, "trsm": trsm, "syrk_columns": col}
+
+
 def _PROFILER_ENV(k):
     return k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTX_")) or k in ("LD_PRELOAD", "HSA_TOOLS_LIB")
 
@@ -418,17 +442,45 @@ def launch_free_fresh_process(device, peak, timeout_s=240):
     return None
 
 
-def config_b(bask, device, steps=150):
-    """BASELINE config B (n = 1024, d = 8, Matern-5/2, 64 walkers; the configuration runs 500 steps, this leg times
-    `steps` of them after the start ensemble): MCMC LML-evaluations/s, ms per half-step (32 proposals) and the
-    per-kernel split of one half-step (HIP events, one stream)."""
-    n, d, W = 1024, 8, 64
-    X, y = synth(n, d, seed=0)
-    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device,
-                       max_batch=W // 2)
+def _host_sampler_cpu(X, y, priors, theta0, W, steps, seed=1):
+    """The reference's sampling loop on the host: the package's ensemble sampler driving scikit-learn's
+    log_marginal_likelihood one walker at a time (bask/bayesgpr.py:510-530, :351-379), at one BLAS thread.  Returns
+    (wall seconds, evaluations)."""
+    from threadpoolctl import threadpool_limits
+
+    from bayes_skopt_amd.sampler import EnsembleSampler
+
+    gpr = _sklearn_gpr(X, y)
+    n_eval = [0]
+
+    def log_prob(Theta, priors=None):
+        out = np.empty(len(Theta))
+        for i, th in enumerate(Theta):
+            lp = sum(float(pr(t)) for pr, t in zip(priors, th))
+            out[i] = lp + gpr.log_marginal_likelihood(th) if np.isfinite(lp) else -np.inf
+            n_eval[0] += 1
+        return out
+
+    p = len(theta0)
+    pos = theta0 + 1e-2 * np.random.RandomState(0).randn(W, p)
+    smp = EnsembleSampler(W, p, log_prob, kwargs=dict(priors=priors))
+    smp.random_state = np.random.RandomState(seed).get_state()
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        smp.run_mcmc(pos, steps)
+        dt = time.perf_counter() - t0
+    return dt, int(n_eval[0])
+
+
+def _device_sampler(bask, device, n, d, W, steps, warm=2):
+    """The device side of a BASELINE configuration's MCMC: BayesGPR in the state right after the MAP fit, the default priors,
+    the reference's start ball; `steps` timed ensemble steps behind `warm` untimed ones.  Returns (gp, sampler, state, seconds)."""
     from bayes_skopt_amd.bayesgpr import _AsyncLogProb
     from bayes_skopt_amd.kernels import WhiteKernel
 
+    X, y = synth(n, d, seed=0)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device,
+                       max_batch=W // 2)
     gp.kernel_ = gp.kernel + WhiteKernel(noise_level=0.01)
     gp.noise_ = 0.01
     gp.X_train_, gp.y_train_ = X, y
@@ -439,10 +491,48 @@ def config_b(bask, device, steps=150):
     pos = theta0 + 1e-2 * gp.random_state.randn(W, d + 2)
     smp = bask.sampler.EnsembleSampler(W, d + 2, _AsyncLogProb(gp), kwargs=dict(priors=priors))
     smp.random_state = np.random.RandomState(1).get_state()
-    st = smp.run_mcmc(pos, 5)
+    st = smp.run_mcmc(pos, warm)
     t0 = time.perf_counter()
     st = smp.run_mcmc(st.coords, steps, log_prob0=st.log_prob, skip_initial_state_check=True)
     dt = time.perf_counter() - t0
+    return gp, smp, st, dt, (X, y, priors, theta0)
+
+
+def config_a(bask, device, with_cpu=True):
+    """BASELINE config A as stated: n = 128, d = 2, Matern-5/2, W = 100 walkers (the reference's default), 100 MCMC steps =
+    10 100 log-likelihood evaluations.  Device: ONE fused launch per half-step (Gram generation + factorisation + LML in the
+    walker's workgroup).  CPU: the same 100 steps of the host loop (scikit-learn's log_marginal_likelihood per walker, one
+    BLAS thread), run IN FULL -- no extrapolation."""
+    n, d, W, steps = 128, 2, 100, 100
+    gp, smp, st, dt, (X, y, priors, theta0) = _device_sampler(bask, device, n, d, W, steps)
+    gp._ctx.close()
+    tf0 = time.perf_counter()
+    gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device)
+    gp2.fit(X, y, n_desired_samples=W * steps, n_burnin=0, n_walkers_per_thread=W, progress=False)
+    fit_ms = (time.perf_counter() - tf0) * 1e3
+    out = {"workload": f"n={n}, d={d}, {W} walkers x {steps} steps ({W * (steps + 1)} evaluations incl. the start ensemble)",
+           "evals_per_s": W * steps / dt, "ms_per_half_step": dt / (2 * steps) * 1e3, "sample_ms": dt * 1e3,
+           "fit_plus_sample_ms": fit_ms, "fit_plus_sample_evals": int(gp2._sampler.n_log_prob_evals),
+           "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
+    del gp2
+    if with_cpu:
+        cdt, cev = _host_sampler_cpu(X, y, priors, theta0, W, steps)
+        out["cpu_baseline"] = {"value": cev / cdt, "unit": "LML-evals/s", "cores": 1, "kind": "reference",
+                               "sample": f"the WHOLE configuration on the host: {W} walkers x {steps} steps = {cev} sequential "
+                               "sklearn log_marginal_likelihood calls + priors, host ensemble sampler, one BLAS thread",
+                               "sample_ms": cdt * 1e3, "ms_per_eval": cdt * 1e3 / cev}
+        out["speedup_vs_cpu"] = (W * steps / dt) / (cev / cdt)
+    return out
+
+
+def config_b(bask, device, steps=500, with_cpu=True, peak_tflops=None):
+    """BASELINE config B as stated (n = 1024, d = 8, Matern-5/2, 64 walkers x 500 steps = 32 064 evaluations): MCMC
+    LML-evaluations/s over all 500 steps, ms per half-step (32 proposals), the wall clock of a whole BayesGPR.fit() at that
+    size, the per-kernel split of one half-step on the launch schedule (HIP events, one stream), and the CPU baseline: the
+    reference's per-walker call timed on >= 32 walker positions."""
+    n, d, W = 1024, 8, 64
+    gp, smp, st, dt, (X, y, priors, theta0) = _device_sampler(bask, device, n, d, W, steps, warm=5)
+    ps = gp._ctx.persist_stats()
     H = gp._canonical(st.coords[: W // 2])
     gp._ctx.set_streams(1)
     gp._ctx.set_timing(True)
@@ -456,10 +546,91 @@ def config_b(bask, device, steps=150):
         dev += tm["device_total_ms"] / 5
     gp._ctx.set_timing(False)
     gp._ctx.close()
-    return {"workload": f"n={n}, d={d}, {W} walkers, {steps} timed MCMC steps (32 proposals per half-step)",
-            "evals_per_s": W * steps / dt, "ms_per_half_step": dt / (2 * steps) * 1e3,
-            "kernel_ms_per_half_step": split, "device_ms_per_half_step_instrumented": dev,
-            "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
+    tf0 = time.perf_counter()
+    gp2 = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=0, device=device)
+    gp2.fit(X, y, n_desired_samples=W * steps, n_burnin=0, n_walkers_per_thread=W, progress=False)
+    fit_ms = (time.perf_counter() - tf0) * 1e3
+    evals_fit = int(gp2._sampler.n_log_prob_evals)
+    del gp2
+    rate = W * steps / dt
+    out = {"workload": f"n={n}, d={d}, {W} walkers, {steps} timed MCMC steps (32 proposals per half-step)",
+           "evals_per_s": rate, "ms_per_half_step": dt / (2 * steps) * 1e3,
+           "fit_plus_sample_ms": fit_ms, "fit_plus_sample_evals": evals_fit,
+           "fit_plus_sample_config": f"BayesGPR.fit: MAP start (L-BFGS-B on the device LML + gradient) + {W} walkers x {steps} steps",
+           "launch_free_calls": ps["calls"], "launch_free_timeouts": ps["timeouts"],
+           "kernel_ms_per_half_step_launch_schedule": split, "device_ms_per_half_step_instrumented": dev,
+           "acceptance_fraction": float(np.mean(smp.acceptance_fraction))}
+    if peak_tflops:
+        out["end_to_end"] = {"flops_per_eval": lml_flops(n, d), "tflops": lml_flops(n, d) * rate / 1e12,
+                             "frac": lml_flops(n, d) * rate / 1e12 / peak_tflops}
+    if with_cpu:
+        from threadpoolctl import threadpool_limits
+
+        gpr = _sklearn_gpr(X, y)
+        runs = {}
+        for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+            with threadpool_limits(limits=nthreads):
+                t = _timed_evals(lambda th: gpr.log_marginal_likelihood(th), st.coords, budget_s=3.0, min_evals=32)
+            runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                           "evals_per_s": float(1.0 / np.median(t))}
+        best = max(runs, key=lambda k: runs[k]["evals_per_s"])
+        out["cpu_baseline"] = {"value": runs[best]["evals_per_s"], "unit": "LML-evals/s", "cores": runs[best]["threads"],
+                               "kind": "reference", "runs": runs,
+                               "sample": f">= 32 sequential sklearn log_marginal_likelihood calls (n={n}, d={d}) on walker "
+                               "positions of the timed chain, at 1 BLAS thread and at all of them; value = the faster setting"}
+        out["speedup_vs_cpu"] = rate / out["cpu_baseline"]["value"]
+        out["cpu_fit_plus_sample_ms_extrapolated"] = evals_fit / out["cpu_baseline"]["value"] * 1e3
+    return out
+
+
+def config_e_cpu(n=1000, d=8, m=10000, n_thompson=10, mcmc_evals=1300, svd_m=1500):
+    """The CPU side of ONE config-E PVRS tell, timed PIECEWISE on bounded samples and EXTRAPOLATED (a full CPU tell is
+    minutes): (i) the MCMC's log-likelihood calls (sklearn, n ~ 1000), (ii) the PVRS loop's bordered (n+1) Cholesky + solve per
+    candidate (bask/acquisition.py:328-338), (iii) the Thompson draw's SVD multivariate normal over the m candidates
+    (sklearn/_gpr.py:522-526), timed at `svd_m` points and scaled by (m / svd_m)^3."""
+    from scipy.linalg import cho_solve, cholesky
+    from threadpoolctl import threadpool_limits
+
+    X, y = synth(n, d, seed=0)
+    gpr = _sklearn_gpr(X, y)
+    k = gpr.kernel_
+    rng = np.random.RandomState(0)
+    th = k.theta
+    out = {}
+    best = None
+    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+        with threadpool_limits(limits=nthreads):
+            t = _timed_evals(lambda t_: gpr.log_marginal_likelihood(t_), th + 0.01 * rng.randn(24, len(th)), budget_s=1.5, min_evals=12)
+            lml_ms = float(np.median(t) * 1e3)
+            T = rng.uniform(size=(n_thompson, d))
+            cand = rng.uniform(size=(12, d))
+            ts = []
+            for x in cand:
+                t0 = time.perf_counter()
+                Xa = np.vstack([X, x[None, :]])
+                L = cholesky(k(Xa), lower=True)
+                kt = k(Xa, T)
+                float(np.sum(kt * cho_solve((L, True), kt)))
+                ts.append(time.perf_counter() - t0)
+            pvrs_ms = float(np.median(ts[2:]) * 1e3)
+            Xq = rng.uniform(size=(svd_m, d))
+            mean, cov = gpr.predict(Xq, return_cov=True)
+            t0 = time.perf_counter()
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                np.random.RandomState(1).multivariate_normal(mean, cov, n_thompson)
+            svd_ms = (time.perf_counter() - t0) * 1e3
+        tell_ms = lml_ms * mcmc_evals + pvrs_ms * m + svd_ms * (m / svd_m) ** 3
+        out[label] = {"threads": int(nthreads), "lml_ms_per_eval": lml_ms, "pvrs_ms_per_candidate": pvrs_ms,
+                      "svd_mvn_ms_at_m%d" % svd_m: svd_ms, "extrapolated_ms_per_tell": tell_ms}
+        if best is None or tell_ms < out[best]["extrapolated_ms_per_tell"]:
+            best = label
+    return {"value": out[best]["extrapolated_ms_per_tell"], "unit": "ms per PVRS tell (EXTRAPOLATED)", "cores": out[best]["threads"],
+            "kind": "reference", "runs": out,
+            "sample": f"timed pieces of one tell at n={n}: >= 12 sklearn LML calls x {mcmc_evals} (100 walkers x 13 steps), 10 bordered "
+            f"(n+1)-Cholesky + solve iterations of the PVRS loop x {m} candidates, one numpy SVD multivariate normal at m={svd_m} "
+            f"x ({m}/{svd_m})^3; EXTRAPOLATED, not run in full (a CPU tell is minutes)"}
 
 
 def config_e(bask, device, n_iters=50, n0=974, m=10000, d=8):
@@ -574,7 +745,7 @@ def main():
                     "rocprofv3 passes of tools/profile_round.sh run, so that their per-kernel numbers are config C's alone")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect roofline.traffic with two rocprofv3 --pmc child passes (~25 s); use the "
-                    "committed profiles/r03_pmc_traffic.json instead")
+                    "newest committed profiles/rNN[_vK]_pmc_traffic.json instead")
     ap.add_argument("--shard", choices=("ensemble", "chains"), default="ensemble",
                     help="N > 1 only.  ensemble (default; BASELINE config C as stated, the reference's semantics): ONE "
                     "256-walker ensemble, each half-step's 128 proposals split over the GPUs + a device-to-device "
@@ -727,7 +898,13 @@ def main():
                               "(%d launches; FETCH_SIZE %.0f KiB raw x 2 + WRITE_SIZE %.0f KiB)"
                               % (live["launches_averaged"], live["fetch_size_kb_raw"], live["write_size_kb_raw"]))
     if traffic is None:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):  # the committed PMC passes of tools/profile_round.sh
+        import glob
+        import re
+
+        # the NEWEST committed PMC passes of tools/profile_round.sh (config C's: rNN_pmc_traffic.json / rNN_vK_pmc_traffic.json)
+        names = [os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))]
+        names = [f for f in names if re.fullmatch(r"r\d+(_v\d+)?_pmc_traffic\.json", f)]
+        for name in sorted(names, key=lambda f: [int(v) for v in re.findall(r"\d+", f)], reverse=True):
             try:
                 traffic = json.load(open(os.path.join(ROOT, "profiles", name)))["traffic_bytes_per_launch"]
                 traffic_source = f"profiles/{name} (committed passes of tools/profile_round.sh)"
@@ -749,6 +926,21 @@ def main():
         }
         for v in by_kind.values():
             v["frac_of_peak"] = v["tflops"] / peak
+        by_kind["bulk"]["bound"] = "mfma"
+        # the K = 128 / 256 / 384 launches on ONE block column sit at the ridge: 16 B per element of the column read + written plus
+        # the panel rows once against 2 K flops per element -- 10.7 / 21 / 32 flop per byte, the ridge is peak / 8 TB/s = 9.6
+        cb = hot_path_bytes(n, d)["syrk_columns"] * B * n_calls
+        ck = by_kind["look_ahead_columns"]
+        ck["algorithmic_gb_per_half_step"] = cb / n_calls / 1e9
+        ck["tb_per_s"] = cb / (col_ms * 1e-3) / 1e12
+        ck["hbm_frac"] = ck["tb_per_s"] * 1e3 / HBM_PEAK_GBS
+        ck["flop_per_byte"] = f_col * B * n_calls / cb
+        ck["roof_tflops"] = min(peak, ck["flop_per_byte"] * HBM_PEAK_GBS / 1e3)
+        ck["frac_of_roof"] = ck["tflops"] / ck["roof_tflops"]
+        ck["ridge_flop_per_byte"] = peak / (HBM_PEAK_GBS / 1e3)
+        # (above the ridge the MFMA roof is the lower one: these launches are NOT HBM-bound on algorithmic traffic -- they move
+        # hbm_frac of the HBM peak -- they are short: 12 launches of 0.15 ms, a C round trip per 128 .. 384 columns of k)
+        ck["bound"] = "mfma" if ck["flop_per_byte"] >= ck["ridge_flop_per_byte"] else "hbm"
     roofline = {
         "bound": "mfma",
         "kernel": "syrk4_kernel<64> (blocked-Cholesky trailing update, four-panel groups K = 128..512, LDS-DMA ring, fp64 "
@@ -771,6 +963,35 @@ def main():
         "MI355X_MICROARCH.md has no fp64 row; traffic = HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
         "+ WRITE_SIZE, separate passes; see traffic_source)",
     }
+
+    # every kernel of the half-step against the roof that bounds it (per half-step of this rank: B matrices)
+    hb = hot_path_bytes(n, d)
+    kms = {k: v[0] / max(n_calls, 1) for k, v in acc.items()}
+    roofline_kernels = [dict(kernel="syrk4_kernel<64> (trailing update)", bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
+                             frac=achieved / peak, ms_per_half_step=kms["syrk"])]
+    if kms["trsm"] > 0:
+        gbs = hb["trsm"] * B / (kms["trsm"] * 1e-3) / 1e9
+        roofline_kernels.append(dict(kernel="trsm4_kernel (panel solve + fused forward substitution)", bound="hbm", achieved=gbs,
+                                     peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, frac_of_measured_copy=gbs / HBM_COPY_MEASURED_GBS,
+                                     algorithmic_gb_per_half_step=hb["trsm"] * B / 1e9, ms_per_half_step=kms["trsm"]))
+    if kms["kbuild"] > 0:
+        gbs = hb["kbuild"] * B / (kms["kbuild"] * 1e-3) / 1e9
+        fk = n * n / 2.0 * (3 * d + 14) * B
+        roofline_kernels.append(dict(kernel="xscale_kernel + kbuild2_kernel (Gram build)", bound="hbm (written once) / fp64 VALU",
+                                     achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
+                                     algorithmic_gb_per_half_step=hb["kbuild"] * B / 1e9, ms_per_half_step=kms["kbuild"],
+                                     valu={"algorithmic_tflops": fk / (kms["kbuild"] * 1e-3) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+                                           "frac": fk / (kms["kbuild"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                           "note": "(3d+14) flop per pair (SURVEY 8d) against the fp64 vector peak; the kernel executes 78 "
+                                           "VALU lane-instructions per pair: VALUBusy 84 % (profiles/r03_kbuild_counters.txt)"}))
+    if kms["potrf"] > 0 and acc["potrf"][1] > 0:
+        us = acc["potrf"][0] / acc["potrf"][1] * 1e3
+        floor = NB * PIVOT_CHAIN_NS * 1e-3
+        roofline_kernels.append(dict(kernel="potrf_kernel (128 x 128 diagonal block, one workgroup per matrix)", bound="latency",
+                                     achieved=us, peak=floor, unit="us per launch (lower is better)", frac=floor / us,
+                                     ms_per_half_step=kms["potrf"],
+                                     note="peak = 128 dependent pivots x %.0f ns (the in-register pivot chain alone, tools/potrf_bench); "
+                                     "frac = that floor / the measured launch" % PIVOT_CHAIN_NS))
 
     evals = W * args.steps * (1 if (ensemble or ws == 1) else ws)
     value = evals / dt
@@ -800,6 +1021,7 @@ def main():
             "parallelism": f"ensemble_sharded{ws}" if ensemble else f"chains{ws}",
         },
         "roofline": roofline,
+        "roofline_kernels": roofline_kernels,
         "end_to_end": {
             "what": "the WHOLE hot path against the same peak: algorithmic flops of one log-likelihood evaluation (Gram build "
             "(3d+14) flop per pair of the lower triangle + n^3/3 + n^2) x value / peak -- Gram build, diagonal blocks, panel "
@@ -868,11 +1090,28 @@ def main():
             line["launch_free"] = launch_free_fresh_process(device, peak) or launch_free(_lib, device, peak)
         except Exception as exc:
             line["launch_free"] = {"error": repr(exc)}
-        for key, fn in (("config_B", config_b), ("config_E", config_e)):
+        with_cpu = not args.no_cpu_baseline
+        for key, fn in (("config_A", lambda: config_a(bask, device, with_cpu)),
+                        ("config_B", lambda: config_b(bask, device, 500, with_cpu, peak)),
+                        ("config_E", lambda: config_e(bask, device))):
             try:
-                line[key] = fn(bask, device)
+                line[key] = fn()
             except Exception as exc:  # reported, never fatal for the bench line
                 line[key] = {"error": repr(exc)}
+        if with_cpu and isinstance(line.get("config_E"), dict) and "pvrs" in line["config_E"]:
+            try:
+                ce = config_e_cpu()
+                line["config_E"]["cpu_baseline"] = ce
+                line["config_E"]["pvrs"]["speedup_vs_cpu_extrapolated"] = ce["value"] / line["config_E"]["pvrs"]["median_ms_per_tell"]
+            except Exception as exc:
+                line["config_E"]["cpu_baseline"] = {"error": repr(exc)}
+        # the launch-free kernel against the MFMA roof, at config B's own half-step shape (whole call: Gram build + factorisation)
+        lf = line.get("launch_free") or {}
+        if isinstance(lf.get("n1024_B32"), dict) and "launch_free_tflops" in lf["n1024_B32"]:
+            r = lf["n1024_B32"]
+            line["roofline_kernels"].append(dict(kernel="ps_kernel (launch-free factorisation, n = 1024 x 32: config B's half-step; whole call)",
+                                                 bound="mfma", achieved=r["launch_free_tflops"], peak=peak, unit="TFLOP/s",
+                                                 frac=r["launch_free_tflops"] / peak, ms_per_call=r["launch_free_ms"]))
     if rank == 0:
         if not args.no_cpu_baseline and ws == 1:  # (the CPU legs run at N = 1 only: the N > 1 runs time the GPUs)
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])

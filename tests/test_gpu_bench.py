@@ -32,8 +32,8 @@ def _line(res):
 
 
 def test_bench_single_gpu_line():
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=1500)
     d = _line(res)
     assert KEYS <= set(d)
     assert d["metric"] == "mcmc_lml_evals_per_s_n2048" and d["n_gpus"] == 1 and d["dtype"] == "f64"
@@ -67,11 +67,33 @@ def test_bench_single_gpu_line():
     e2e = d["end_to_end"]  # the whole hot path against the same peak: below the trailing update's own fraction
     assert 0.2 < e2e["frac"] < r["frac"] and abs(e2e["tflops"] - e2e["flops_per_eval"] * d["value"] / 1e12) < 1e-9
     assert d["launch_free_calls_in_timed_path"]["timeouts"] == 0
-    cb = d["config_B"]
-    assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9
+    # SURVEY 8d in the ONE driver line: every BASELINE configuration with its CPU side, every kernel with its roof
+    ca = d["config_A"]  # n = 128, W = 100, 100 steps: the CPU loop runs IN FULL (10 100 evaluations), nothing extrapolated
+    assert "10100 evaluations" in ca["workload"] and ca["fit_plus_sample_evals"] == 10100 and ca["evals_per_s"] > 1.0e5
+    assert ca["cpu_baseline"]["kind"] == "reference" and ca["cpu_baseline"]["cores"] == 1 and "10100" in ca["cpu_baseline"]["sample"]
+    assert ca["speedup_vs_cpu"] > 1.0 and ca["cpu_baseline"]["sample_ms"] > ca["sample_ms"]
+    cb = d["config_B"]  # as stated: 500 steps, with the wall clock of a whole fit() and the reference's per-walker call beside it
+    assert "500 timed MCMC steps" in cb["workload"] and cb["fit_plus_sample_evals"] == 64 * 501
+    assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9 and cb["fit_plus_sample_ms"] > 0
+    assert all(r_["evals"] >= 32 for r_ in cb["cpu_baseline"]["runs"].values()) and cb["speedup_vs_cpu"] > 50
+    assert 0.05 < cb["end_to_end"]["frac"] < 1.0 and cb["launch_free_timeouts"] == 0
     ce = d["config_E"]
     assert ce["n_iters"] == 50 and ce["pvrs"]["n_final"] == 1024 and ce["ei128"]["n_final"] == 1024
     assert 0 < ce["pvrs"]["median_ms_per_tell"] < 500 and 0 < ce["ei128"]["median_ms_per_tell"] < 500
+    assert "EXTRAPOLATED" in ce["cpu_baseline"]["unit"] and "EXTRAPOLATED" in ce["cpu_baseline"]["sample"]
+    assert ce["cpu_baseline"]["value"] > 1e3 and ce["pvrs"]["speedup_vs_cpu_extrapolated"] > 50
+    rk = {k_["kernel"].split(" ")[0]: k_ for k_ in d["roofline_kernels"]}
+    assert {"syrk4_kernel<64>", "trsm4_kernel", "xscale_kernel", "potrf_kernel", "ps_kernel"} <= set(rk)
+    assert rk["trsm4_kernel"]["bound"] == "hbm" and rk["trsm4_kernel"]["unit"] == "GB/s" and 0.2 < rk["trsm4_kernel"]["frac"] < 1.0
+    assert rk["xscale_kernel"]["bound"].startswith("hbm") and 0.1 < rk["xscale_kernel"]["frac"] < 1.0 and 0 < rk["xscale_kernel"]["valu"]["frac"] < 1
+    assert rk["potrf_kernel"]["bound"] == "latency" and 0.1 < rk["potrf_kernel"]["frac"] < 1.0
+    assert rk["ps_kernel"]["bound"] == "mfma" and 0.1 < rk["ps_kernel"]["frac"] < 1.0
+    for k_ in d["roofline_kernels"]:
+        assert {"kernel", "bound", "achieved", "peak", "unit", "frac"} <= set(k_)
+    assert bk["bulk"]["bound"] == "mfma" and bk["look_ahead_columns"]["bound"] in ("mfma", "hbm")
+    assert (bk["look_ahead_columns"]["bound"] == "mfma") == (bk["look_ahead_columns"]["flop_per_byte"] >= bk["look_ahead_columns"]["ridge_flop_per_byte"])
+    assert 0.2 < bk["look_ahead_columns"]["hbm_frac"] < 1.0 and 0.4 < bk["look_ahead_columns"]["frac_of_roof"] <= 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
 
 
 def test_bench_spawns_its_own_ranks_without_a_launcher():
