@@ -73,7 +73,10 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
                                                      int ld, size_t mstride, int ystride, int nblk, int k, PfGen gen) {
   const int b = blockIdx.x;
   if (!GEN && status[b] != 0) return;
-  (void)pf_block<GEN, STAT, FORM>(b, Kbuf, Wbuf, yw, accb, lml, status, n, ld, mstride, ystride, nblk, k, gen);
+  PfPre nopre;  // (launch schedule: nothing to request ahead)
+  nopre.state = 0;
+  (void)pf_block<GEN, STAT, FORM, 0>(b, Kbuf, Wbuf, yw, accb, lml, status, n, ld, mstride, ystride, nblk, k, gen, false, nullptr,
+                                     PsArgs(), nopre);
 }
 
 // Debugging aid / accuracy test: the pivot root of the diagonal-block factorisation (pf_pivot_root) on n arguments.

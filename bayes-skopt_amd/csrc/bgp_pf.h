@@ -272,16 +272,39 @@ static __device__ __forceinline__ PfLds pf_lds() {
   return l;
 }
 
+// Operands of the chain's OWN share of block column J (pf_chain_next: the solve of block (J+1, J)), requested EARLY.  Measured
+// (tools/persist_trace.py, n = 1024 x 32): of the 29 us the chain spends behind pf_block(J), 8-9 are the 128 KB of block (J+1, J)
+// reaching ONE workgroup at ~15 GB/s with the solve's MFMAs waiting behind their A fragments (an L2 warm-up by the idle wave
+// changed nothing: it is this CU's own miss queue, not where the lines sit).  The block is usually final well before pf_block(J)
+// ends (its pre-update only needs the panels 0 .. J-1): wave 4 -- idle in pf_block -- looks at the two flags once per 16-pivot
+// step, requested in one step and examined in the next, never waiting, and acquires when both are up; behind pf_block(J) -- its
+// stores drained, its registers free -- every wave issues its A-fragment loads (16 x 16 B per lane) at once, under the release and
+// the flag store that publish W_JJ, instead of behind pf_chain_next's own poll + acquire + barrier (2-4 us per column).  (Issued
+// inside pf_block's tail they would be waited for by the drain of its stores.)  Same values in the same registers, only earlier.
+struct PfPre {
+  double af[32];  // rows 16 w + lr of block (J+1, J): 32 contiguous bytes per lane and k-group (pf_afrag_issue's image: NOT yet transposed)
+  int state;      // 0: not requested, 2: loads issued (pf_chain_next skips its wait and its loads)
+};
+static __device__ __forceinline__ void pf_afrag_issue(const double* __restrict__ rowp, int lk, double (&af)[32]);
+static __device__ __forceinline__ void pf_pre_issue(const PsArgs& a, int b, int J, int w, int lr, int lk, PfPre& pre) {
+  const int I = J + 1, ld = a.ld;
+  const double* const Ab = a.K + (size_t)b * a.mstride + (size_t)I * 128 * ld + (size_t)J * 128;
+  pf_afrag_issue(Ab + (size_t)(16 * w + lr) * ld, lk, pre.af);
+  pre.state = 2;
+}
+
 // One diagonal block of one walker (the whole workgroup).  Returns 0, or the 1-based pivot index inside the block at
 // which the factorisation failed (status / lml of the walker are set here either way).  Called once per launch by
 // potrf_kernel and once per block column by the persistent chain kernel (ps_chain_kernel): the LDS tile is free again
 // when the function returns through its trailing barrier.
-template <int GEN, int STAT, int FORM>
+template <int GEN, int STAT, int FORM, int PRE>
 static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf, double* __restrict__ Wbuf,
                                                double* __restrict__ yw, double* __restrict__ accb,
                                                double* __restrict__ lml, int* __restrict__ status, int n, int ld,
                                                size_t mstride, int ystride, int nblk, int k, const PfGen& gen,
-                                               bool inlds = false, unsigned* wrow = nullptr) {
+                                               bool inlds, unsigned* wrow, const PsArgs& pa, PfPre& pre) {
+  // PRE (the single chain workgroup of the launch-free factorisation): request the operands of pf_chain_next(k) behind the
+  // last step when the tile workers have handed them over by then (struct PfPre)
   // inlds (chain kernel, k > 0): the block and its right-hand side are in LDS already (pf_chain_next left them there)
   // wrow (chain pairs): the 16-row blocks of W go out to the partner workgroup AS THEY ARE FORMED -- row block p is complete
   // in memory at the end of step p + 1; the otherwise idle wave 4 releases it and raises *wrow to the number of complete
@@ -326,6 +349,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   double ld_prev = 0.0, zz_prev = 0.0;  // running log-det and z^T z of the earlier diagonal blocks
   if (tid == 0) {
     fail_lds = 0;
+    if (PRE) lds.fail[1] = 0;  // 1: wave 4 has seen the pre-updated block (k+1, k) final (and acquired)
     if (k > 0) {
       ld_prev = accb[b * 4 + 0];
       zz_prev = accb[b * 4 + 1];
@@ -342,9 +366,21 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   // update waves: 1-3 and 5-7 (two per SIMD so that one's LDS latency hides behind the other's MFMAs); wave 4
   // shares the panel wave's SIMD and stays idle (every VALU / MFMA issue there would delay the pivot chain)
   const int u6 = (w < 4) ? w - 1 : w - 2;  // 0..5 for the update waves
+  unsigned pre_fs = 0, pre_fd = 0;
+  int pre_seen = (PRE && k + 1 < nblk) ? 0 : 1;
 #pragma unroll 1
   for (int sb = 0; sb < 8; sb++) {
     PF_TW(2 * sb);
+    if (PRE && w == 4 && lane == 0 && !pre_seen) {
+      if (k == 0 || (sb > 0 && pre_fs >= (unsigned)pa.psplit && pre_fd >= (unsigned)pa.dsplit)) {
+        if (k > 0) ps_acquire();
+        lds.fail[1] = 1;
+        pre_seen = 1;
+      } else {
+        pre_fd = ps_ld(pa.flags + PS_HDR + (size_t)pa.B * nblk + (size_t)b * nblk + (k + 1));                  // diagrdy[k + 1]
+        pre_fs = ps_ld(pa.flags + PS_HDR + (size_t)pa.B * nblk * (2 + nblk) + (size_t)b * nblk + (k + 1));   // subrdy[k + 1]
+      }
+    }
     if (w == 0) {
       if (sb > 1) {  // pending panel block of the previous row
 #pragma unroll
@@ -657,7 +693,7 @@ static __device__ __forceinline__ void pf_load_afrag(const double* __restrict__ 
 //      in steps of 4, A-negate: the arithmetic of syrk4_kernel), and the result IS the next LDS tile of pf_block: no
 //      flag, no L2 round trip and no other workgroup between two factorisations.
 // Returns 0, or -1 when a wait was abandoned.
-static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr) {
+static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int J, int* ok_lds, unsigned long long* tr, PfPre& pre) {
   const PfLds lds = pf_lds();
   double* const s = lds.s;
   const double* const Minv = lds.Minv;
@@ -674,7 +710,8 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   double* const Mb = a.K + (size_t)b * a.mstride;
   double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
   const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
-  if (J > 0) {
+  const bool early = pre.state == 2;  // (uniform) requested behind pf_block(J)'s last step: flags seen, acquired, loads issued
+  if (J > 0 && !early) {
     if (tid == 0) {
       const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
       const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
@@ -687,16 +724,16 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   }
   if (tr && tid == 0) tr[J * 8 + 2] = wall_clock64();
   // ---- operands: A fragments (k = 4 t + lk of row 16 w + lr), this lane's rows of y, the D tiles of this wave
-  double af[32];
-  {
-    pf_load_afrag(Ab + (size_t)(16 * w + lr) * ld, lk, af);
-  }
+  if (!early) pf_pre_issue(a, b, J, w, lr, lk, pre);
+  pre.state = 0;
+  double (&af)[32] = pre.af;
   double yv[4];
   {
     const double* const yi = a.yw + (size_t)b * a.ystride + I * 128;
 #pragma unroll
     for (int r = 0; r < 4; r++) yv[r] = yi[16 * w + lk + 4 * r];
   }
+  pf_afrag_transpose(af);
   // lower 16 x 16 tiles t = w, w + 8, ... < 36 in row-major order of the triangle (waves 0-3: five, 4-7: four; nine per SIMD)
   d4 dt[5];
   int offa[5], offb[5], offc[5], offd[5];
@@ -1266,6 +1303,8 @@ static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int
   unsigned* const wready = flags + PS_HDR + (size_t)b * a.nblk;
   unsigned* const wrow = flags + PS_HDR + (size_t)a.B * a.nblk * (3 + a.nblk) + (size_t)b * a.nblk;
   unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
+  PfPre pre;
+  pre.state = 0;
   for (int J = 0; J < a.nblk; J++) {
     if (PAIR && (J & 1) != p) {  // the partner factorises column J: prepare block (J+1, J+1) under it
       if (J + 1 < a.nblk && pf_pair_helper(a, b, J, &ps_ok, &ps_peek, tr) < 0) return;
@@ -1273,10 +1312,16 @@ static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int
     }
     if (tr && tid == 0) tr[J * 8 + 0] = wall_clock64();
     // (J > 0: the block and its right-hand side are in LDS, pf_chain_next / pf_pair_helper left them there)
-    const int failed = pf_block<0, 0, 0>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
-                                         a.nblk, J, PfGen(), J > 0, PAIR ? wrow + J : nullptr);
+    const int failed = pf_block<0, 0, 0, PAIR ? 0 : 1>(b, a.K, a.W, a.yw, a.acc, a.lml, a.status, a.n, a.ld, a.mstride, a.ystride,
+                                                       a.nblk, J, PfGen(), J > 0, PAIR ? wrow + J : nullptr, a, pre);
     if (tr && tid == 0) tr[J * 8 + 1] = wall_clock64();
     ps_publish_barrier();
+    // (single chain) wave 4 saw block (J+1, J) handed over while pf_block(J) ran: its A fragments are requested NOW, behind the
+    // drain of this block's stores and under the release + flag store below -- by wave 0, whose release waits for its own
+    // memory operations, behind them -- instead of after pf_chain_next's poll and acquire
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool early = !PAIR && !failed && J + 1 < a.nblk && pf_lds().fail[1] != 0;
+    if (early && wv != 0) pf_pre_issue(a, b, J, wv, tid & 15, (tid & 63) >> 4, pre);
     if (tid == 0) {
       ps_release();
       // a failed matrix (status set above) releases every later column at once -- and the panel blocks this workgroup owes
@@ -1290,7 +1335,8 @@ static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int
       }
     }
     if (failed) return;
-    if (!PAIR && J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr) < 0) return;  // (abandoned: the host redoes the batch)
+    if (early && wv == 0) pf_pre_issue(a, b, J, wv, tid & 15, (tid & 63) >> 4, pre);
+    if (!PAIR && J + 1 < a.nblk && pf_chain_next(a, b, J, &ps_ok, tr, pre) < 0) return;  // (abandoned: the host redoes the batch)
   }
 }
 
