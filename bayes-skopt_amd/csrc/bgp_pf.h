@@ -60,13 +60,15 @@ static __device__ __forceinline__ void pf_pivot_root(double x, double& dj, doubl
   inv = fma(y1, e, y1);
 }
 
+// (No validity test inside the chain: a non-positive, NaN or overflowed pivot makes its own root and everything behind it NaN /
+// Inf, so the FIRST diagonal entry of the finished block that is not a positive finite number is the failing pivot -- looked for
+// by the idle wave, one step behind and off the wave that runs the 16 dependent pivots: pf_check_diag.  The test cost that wave
+// five instructions per pivot of ~35.)
 template <int J>
-static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr,
-                                                      int& bad) {
+static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&macc)[16], double (&mrow)[16], int lr) {
   if constexpr (J < 16) {
     asm volatile("s_nop 1");  // a[J] was last written by the inline-asm updates above: DPP read hazard (2 wait states)
     const double djj = bc16<J>(a[J]);
-    bad = (!(djj > 0.0 && djj < INFINITY) && bad == 0) ? J + 1 : bad;  // non-positive, NaN or overflowed pivot
     double dj, inv;  // sqrt(djj), 1 / sqrt(djj)
     pf_pivot_root(djj, dj, inv);
     a[J] = (lr == J) ? dj : a[J] * inv;
@@ -75,8 +77,18 @@ static __device__ __forceinline__ void micro_chol_inv(double (&a)[16], double (&
     mrow[J] = mj;
     if constexpr (J < 15) asm volatile("s_nop 1" ::"v"(a[J]), "v"(naj), "v"(mj));  // VALU write -> DPP read
     micro_cols<J, J + 1>(a, macc, naj, mj);
-    micro_chol_inv<J + 1>(a, macc, mrow, lr, bad);
+    micro_chol_inv<J + 1>(a, macc, mrow, lr);
   }
+}
+
+// The validity test of the 16 pivots of diagonal sub-block `blk`, off the pivot chain: lanes 0 .. 15 of the calling wave (the idle
+// wave 4) look at the block's diagonal in the LDS tile; the first entry that is not a positive finite number is the failing pivot
+// (everything behind a failed pivot is NaN).  *fail = its 1-based index inside the 128 x 128 block, if none was recorded before.
+static __device__ __forceinline__ void pf_check_diag(const double* __restrict__ s, int blk, int lane, int* fail, int ldt) {
+  const int i = blk * 16 + (lane & 15);
+  const double v = s[i * ldt + i];
+  const unsigned long long m = __ballot(!(v > 0.0 && v < INFINITY)) & 0xffffull;
+  if (m != 0 && lane == 0 && *fail == 0) *fail = blk * 16 + __ffsll((long long)m);
 }
 
 // acc (+/-)= sum_{t < nt} A_t B_t^T for 16x16 blocks whose operands sit in LDS rows `pa` / `pb` (pointers
@@ -381,6 +393,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
         pre_fs = ps_ld(pa.flags + PS_HDR + (size_t)pa.B * nblk * (2 + nblk) + (size_t)b * nblk + (k + 1));   // subrdy[k + 1]
       }
     }
+    if (w == 4 && sb > 0) pf_check_diag(s, sb - 1, lane, lds.fail, PF_LD);  // (seen by everybody behind this step's barrier)
     if (w == 0) {
       if (sb > 1) {  // pending panel block of the previous row
 #pragma unroll
@@ -412,20 +425,16 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
         a[c] = s[(sb * 16 + lr) * PF_LD + sb * 16 + c];
         macc[c] = 0.0;
       }
-      int bad = 0;
 #ifdef PF_TRACE
       asm volatile("s_nop 0" ::"v"(a[0]), "v"(a[15]));
 #endif
       PF_T(3 + sb * 3);
-      micro_chol_inv<0>(a, macc, mrow, lr, bad);
+      micro_chol_inv<0>(a, macc, mrow, lr);
 #ifdef PF_TRACE
       asm volatile("s_nop 0" ::"v"(a[15]), "v"(mrow[15]), "v"(mrow[14]));
 #endif
       PF_T(4 + sb * 3);
-      const int bad_u = __builtin_amdgcn_readfirstlane(bad);
-      if (bad_u) {
-        if (lane == 0) fail_lds = sb * 16 + bad_u;
-      } else if (lane < 16) {
+      if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 16; j++) Minv[sb * 16 * PF_MLD + j * PF_MLD + lr] = mrow[j];
 #pragma unroll
@@ -508,6 +517,7 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
       ps_st(wrow, (unsigned)sb);
     }
   }
+  if (!failed && w == 4) pf_check_diag(s, 7, lane, lds.fail, PF_LD);  // the last sub-block: read behind the next barrier
   if (failed) {
     if (tid == 0) {
       status[b] = k * 128 + failed;  // 1-based index of the failing pivot
@@ -546,6 +556,14 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   for (int o = 32; o > 0; o >>= 1) ldv += __shfl_xor(ldv, o);
   if (lane == 0) red[w] = ldv;
   __syncthreads();
+  failed = fail_lds;  // (a failure inside the last 16 pivots)
+  if (failed) {
+    if (tid == 0) {
+      status[b] = k * 128 + failed;
+      lml[b] = -INFINITY;
+    }
+    return failed;
+  }
   PF_T(27);
   // ---- z = W y from the LDS copy of W (transposed in the upper triangle, diagonal blocks in Minv); four
   // threads per row, fixed summation order (bitwise reproducible)
