@@ -198,3 +198,60 @@ static __device__ __forceinline__ double kb_stationary(double r2) {
     }                                                                        \
   } while (0)
 
+// ---- A-operand fragments straight from global memory (the chain role of the launch-free factorisation, bgp_pf.h; the panel
+// solve trsm5_kernel, bgp_syrk4.hip) ----
+// A-operand fragments of 16 rows x 128 columns for the f64 16x16x4 MFMA: lane (lr, lk) wants A[row lr][4 t + lk], t = 0 .. 31 -- as
+// 8-byte loads that is 32 B per row per instruction.  Loaded instead as 32 contiguous bytes per lane (two 16-byte loads, a whole
+// 128-B line per row per pair of instructions) and transposed 4 x 4 across the four 16-lane rows with the gfx950 lane-swap
+// instructions (v_permlane32_swap: rows 2, 3 of one register <-> rows 0, 1 of another; v_permlane16_swap: odd rows <-> even rows):
+// the same values in the same registers, half the memory instructions and full lines (handed-off blocks arrive at 60-120 GB/s per
+// workgroup, MI355X_MICROARCH.md "handoff-payload": the 128 KB block is most of a chain step's entry).
+static __device__ __forceinline__ void pf_swap_rows32(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+static __device__ __forceinline__ void pf_swap_rows16(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  x = __hiloint2double((int)hi[0], (int)lo[0]);
+  y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// (the two halves, for callers that put other work between the loads and the first use)
+static __device__ __forceinline__ void pf_afrag_issue(const double* __restrict__ rowp, int lk, double (&af)[32]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v* const q = reinterpret_cast<const d2v*>(rowp + 4 * lk);
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const d2v u = q[8 * g], v = q[8 * g + 1];
+    af[4 * g] = u[0];
+    af[4 * g + 1] = u[1];
+    af[4 * g + 2] = v[0];
+    af[4 * g + 3] = v[1];
+  }
+}
+static __device__ __forceinline__ void pf_afrag_transpose(double (&af)[32]) {
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    pf_swap_rows32(af[4 * g], af[4 * g + 2]);
+    pf_swap_rows32(af[4 * g + 1], af[4 * g + 3]);
+    pf_swap_rows16(af[4 * g], af[4 * g + 1]);
+    pf_swap_rows16(af[4 * g + 2], af[4 * g + 3]);
+  }
+}
+// rowp = &A[this lane's row][0] (32-byte aligned), lk = lane >> 4
+static __device__ __forceinline__ void pf_load_afrag(const double* __restrict__ rowp, int lk, double (&af)[32]) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v* const q = reinterpret_cast<const d2v*>(rowp + 4 * lk);
+#pragma unroll
+  for (int g = 0; g < 8; g++) {
+    const d2v u = q[8 * g], v = q[8 * g + 1];
+    af[4 * g] = u[0];
+    af[4 * g + 1] = u[1];
+    af[4 * g + 2] = v[0];
+    af[4 * g + 3] = v[1];
+  }
+  pf_afrag_transpose(af);
+}
+
