@@ -186,7 +186,9 @@ def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
 
-        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        # the BLAS pools only: an OpenMP pool (scikit-learn's) reports every core of the host, and raising OpenBLAS above the
+        # thread count it was initialised with (OPENBLAS_NUM_THREADS in the environment, as tests/conftest.py sets) crashes dpotrf
+        return max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
         return os.cpu_count() or 1
 
