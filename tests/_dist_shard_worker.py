@@ -1,7 +1,9 @@
 """Worker for the exact single-ensemble sharding test (SURVEY.md 8(e) option 1): every rank drives the
 same sampler RNG, evaluates only its rows of each proposal block and all-gathers the log-probabilities.
 argv: out_dir mode [W]  (mode "toy": CPU toy target with W walkers (default 14); "fail": the same, rank 3's share raises in
-its 6th call -- every rank must stop with ShardedEvaluationError; mode "gpu": the device LML, ranks share GPU 0)."""
+its 6th call -- every rank must stop with ShardedEvaluationError; mode "gpu": the device LML, ranks share GPU 0; mode "gpu_generic":
+the same with a kernel tree that has no canonical device form -- Matern() + Matern(): host-evaluated kernel matrices, device
+factorisation -- whose finished values are gathered from the host)."""
 import json
 import os
 import sys
@@ -48,13 +50,20 @@ def main():
         rng = np.random.RandomState(0)
         X = rng.uniform(size=(96, 2))
         y = np.sin(3.0 * X.sum(axis=1)) + 0.1 * rng.randn(96)
-        gp = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1]), random_state=3, device=0, normalize_y=True,
-                           shard_ensemble=True)
+        def kernel():
+            if mode == "gpu_generic":
+                from sklearn.gaussian_process import kernels as sk
+
+                return sk.Matern(length_scale=0.5, nu=2.5) + sk.Matern(length_scale=2.0, nu=1.5)
+            return bask.construct_default_kernel([0, 1])
+
+        gp = bask.BayesGPR(kernel=kernel(), random_state=3, device=0, normalize_y=True, shard_ensemble=True)
         gp.fit(X, y, n_desired_samples=60, n_burnin=4, n_walkers_per_thread=20, progress=False)
+        assert gp._generic == (mode == "gpu_generic")
         chain = gp.chain_
         lp = np.array([gp.log_marginal_likelihood_value_])
         # the same fit without sharding, in this very process (same libraries / thread settings)
-        gp1 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1]), random_state=3, device=0, normalize_y=True)
+        gp1 = bask.BayesGPR(kernel=kernel(), random_state=3, device=0, normalize_y=True)
         gp1.fit(X, y, n_desired_samples=60, n_burnin=4, n_walkers_per_thread=20, progress=False)
         np.save(os.path.join(out_dir, f"chain_unsharded{rank}.npy"), gp1.chain_)
     np.save(os.path.join(out_dir, f"chain{rank}.npy"), chain)

@@ -48,6 +48,23 @@ def test_two_rank_sharded_fit_equals_single_process(tmp_path):
     assert np.isclose(r0["lp_sum"], gp.log_marginal_likelihood_value_, rtol=1e-12)
 
 
+def test_two_rank_sharded_fit_with_a_generic_kernel_tree(tmp_path):
+    """The sharded ensemble with a kernel tree that has no canonical device form (host-evaluated kernel matrices, device
+    factorisation): every rank evaluates its rows and the finished values are gathered from the host; the chain is the same on
+    both ranks and equals the unsharded chain of the same process bit for bit."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", BGP_DIST_BACKEND="gloo",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_shard_worker.py"),
+           str(tmp_path), "gpu_generic"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    c0, c1 = np.load(tmp_path / "chain0.npy"), np.load(tmp_path / "chain1.npy")
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_array_equal(c0, np.load(tmp_path / "chain_unsharded0.npy"))
+    assert c0.shape == (60, 3)  # the two length scales and the WhiteKernel fit() appends
+
+
 _RCCL_WORKER = r"""
 import json, os, sys
 import numpy as np
