@@ -97,12 +97,21 @@ class KernelPlan:
         self.const, self.ell, self.white = const, ell, white
         self.n_theta = n_theta
         self.ard = ard
+        # theta IS the canonical vector already (every component free, anisotropic length scales, theta order = h order: the
+        # reference's default kernel, bask/utils.py:144-150 + WhiteKernel): the sampler's per-half-step mapping is a no-op
+        self._identity_d = None
+        if const[0] == "free" and white[0] == "free" and ell[0] == "free" and len(ell[1]) > 1:
+            idx = [const[1]] + list(ell[1]) + [white[1]]
+            if idx == list(range(n_theta)):
+                self._identity_d = len(ell[1])
 
     def canonical(self, theta, d):
         """(B, p) or (p,) theta -> (B, d+2) canonical vectors."""
         T = np.atleast_2d(np.asarray(theta, dtype=np.float64))
         if T.shape[1] != self.n_theta:
             raise ValueError(f"theta has {T.shape[1]} entries, kernel has {self.n_theta} free hyper-parameters")
+        if self._identity_d == d:
+            return np.ascontiguousarray(T)
         B = T.shape[0]
         H = np.empty((B, d + 2))
         kind, v = self.const
