@@ -183,3 +183,34 @@ def test_optimizer_runs_on_a_generic_tree(bask):
     # a kernel the reference's own guess_priors refuses (bask/utils.py:178-179) is refused alike -- with explicit priors it runs
     with pytest.raises(NotImplementedError):
         bask.guess_priors(sk.RationalQuadratic())
+
+
+def test_generic_tree_with_input_warping(bask):
+    """warp_inputs=True on a tree without a canonical form: every walker's kernel matrix is evaluated on the host from ITS warped
+    inputs (the device's Beta-CDF warp), the chain carries the 2d warp parameters, predictions warp the query points; the LML of a
+    chain row equals scikit-learn's on the row's warped design."""
+    from oracle import gp_oracle as O
+
+    n, d = 90, 1
+    rng = np.random.RandomState(3)
+    X = rng.uniform(size=(n, d))
+    y = np.sin(6.0 * X[:, 0] ** 2) + 0.05 * rng.randn(n)
+    kernel = sk.Matern(length_scale=0.4, nu=2.5) + sk.Matern(length_scale=1.5, nu=1.5)
+    gp = bask.BayesGPR(kernel=kernel, random_state=2, warp_inputs=True)
+    gp.fit(X, y, n_desired_samples=40, n_burnin=2, n_walkers_per_thread=20, progress=False)
+    assert gp._generic and gp.chain_.shape == (40, 3 + 2 * d)
+    row = gp.chain_[7]
+    th, w = row[:3], row[3:]
+    Xw = O.warp_inputs(X, w)
+    g = GaussianProcessRegressor(kernel=gp.kernel_, optimizer=None, alpha=1e-10).fit(Xw, gp.y_train_)
+    got = gp._gram_lml(th[None, :], w[None, :])[0]
+    np.testing.assert_allclose(got, g.log_marginal_likelihood(th), rtol=1e-6)
+    Xq = np.linspace(0.02, 0.98, 15)[:, None]
+    mean, std = gp.predict(Xq, return_std=True)
+    wm = np.concatenate([gp.warp_alphas_, gp.warp_betas_])
+    gm = GaussianProcessRegressor(kernel=gp.kernel_, optimizer=None, alpha=1e-10).fit(O.warp_inputs(X, wm), gp.y_train_)
+    mu, sd = gm.predict(O.warp_inputs(Xq, wm), return_std=True)
+    np.testing.assert_allclose(mean, mu * gp.y_train_std_ + gp.y_train_mean_, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(std, sd * gp.y_train_std_, rtol=1e-6, atol=1e-8)
+    acq = bask.acquisition.evaluate_acquisitions(Xq, gp, [bask.acquisition.ExpectedImprovement()], n_samples=3, random_state=0)
+    assert acq.shape == (1, 15) and np.all(np.isfinite(acq))
