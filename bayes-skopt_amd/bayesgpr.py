@@ -52,11 +52,11 @@ class BayesGPR(RegressorMixin, BaseEstimator):
       reference's own variates;
     * ``"cholesky"``: ``mean + chol(cov + jitter I) z`` entirely on the device (same distribution, other
       variates; the only practical choice for thousands of query points, where the SVD takes minutes);
-    * ``"auto"`` (default): ``"reference"`` up to ``MVN_REFERENCE_MAX_POINTS`` (256) query points,
+    * ``"auto"`` (default): ``"reference"`` up to ``MVN_REFERENCE_MAX_POINTS`` (512) query points,
       ``"cholesky"`` beyond.  The generator is consumed identically in both modes.
     """
 
-    MVN_REFERENCE_MAX_POINTS = 256
+    MVN_REFERENCE_MAX_POINTS = 512
 
     def __init__(
         self,

@@ -107,7 +107,7 @@ def fitted_minimal_gp(bask):
 # geometric median, the hyper-sample selection and -- ThompsonSampling, and the Thompson points of PVRS --
 # numpy's legacy SVD multivariate normal behind sample_y: reproducing ALL EIGHT exactly pins this build's
 # restatement of the ensemble sampler (emcee itself is absent from the image) and its reference-variate
-# function draws (BayesGPR(mvn="auto"): device mean / covariance, host SVD draw up to 256 query points)
+# function draws (BayesGPR(mvn="auto"): device mean / covariance, host SVD draw up to 512 query points)
 # against the reference's own test vectors.
 ACQ_CASES = [
     ("VarianceReduction", 0, 50),

@@ -191,7 +191,7 @@ def test_sample_y_reference_variates_equal_sklearns_seeded_draws():
     """Row a8 with the reference's OWN variates (SURVEY 8c golden (8), tests/golden/mvn.npz): BayesGPR.sample_y(mvn="reference")
     -- mean and covariance from the device (bgp_predict_batch with cov), numpy's legacy SVD multivariate normal on the host,
     as sklearn/_gpr.py:522-526 behind bask/bayesgpr.py:669-678 -- returns scikit-learn's seeded draws: 1e-9 absolute at 6,
-    24 and 64 query points, noise off (the reference's default) and on.  "auto" takes this mode up to 256 query points."""
+    24 and 64 query points, noise off (the reference's default) and on.  "auto" takes this mode up to 512 query points."""
     g = load_golden("mvn.npz")
     gp = _mvn_gp(g)
     for m in (6, 24, 64):
