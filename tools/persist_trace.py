@@ -68,6 +68,7 @@ if total:
         if nm.startswith("S"):
             stat(f"{nm}: stored (or ticket) -> W ready", ((tl[:, 4] - tl[:, 3]) / 100.0)[sel])
             stat(f"{nm}: W ready -> solved", ((tl[:, 5] - tl[:, 4]) / 100.0)[sel])
+        stat(f"{nm}: computed -> drained, released, flag set", ((tl[:, 6] - (tl[:, 5] if nm.startswith("S") else tl[:, 3])) / 100.0)[sel])
         stat(f"{nm}: whole task", ((tl[:, 6] - tl[:, 0]) / 100.0)[sel])
     # slack of the two hand-overs to the chain, matrix 0: published this long before pf_block(I-1) ended (the chain asks then)
     for nm, k in (("P", 1), ("Dg", 2)):
@@ -76,3 +77,10 @@ if total:
             sel = sel[np.argsort(I[sel])]
             slack = (ch[0, I[sel] - 1, 1] - tl[sel, 6]) / 100.0
             print(f"  {nm}(I) of matrix 0 published this long before the chain asked (us, I = {I[sel][0]} ..):", " ".join(f"{v:.0f}" for v in slack))
+    # how much of the time the tile workgroups hold a task is arithmetic: the factorisation's n^3 / 3 flop per matrix at one compute
+    # unit's fp64 MFMA rate (0.307 TF) against the sum of the tasks' durations (ticket -> published) and against workers x call
+    held = float(((tl[:, 6] - tl[:, 0])[done]).sum()) / 100.0
+    floor_us = B * (n ** 3 / 3.0) / 0.307e12 * 1e6
+    span = us(max(tl[:, 6].max(), ch[:, -1, 1].max()))
+    print("  tile side: tasks hold workgroups for %.0f CU-us in all; the factorisations' flops are %.0f CU-us at the single-CU MFMA rate "
+          "(%.0f %% of the held time); call span %.0f us" % (held, floor_us, 100.0 * floor_us / held, span))
