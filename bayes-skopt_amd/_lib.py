@@ -67,6 +67,8 @@ SIGNATURES = {
     "bgp_posterior_batch_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "bgp_predict_batch_gram": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "bgp_comm_abort": (C.c_int, [_vp]),
+    "bgp_mcmc_run": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp,
+                               _dp, C.POINTER(C.c_longlong), _ip]),
     "bgp_comm_available": (C.c_int, []),
     "bgp_comm_unique_id": (C.c_int, [_vp]),
     "bgp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
@@ -228,6 +230,38 @@ class Context:
         _check(self._lib.bgp_lml_batch_submit(self._h, H.shape[0], _p(H)), "bgp_lml_batch_submit")
         self._pending, self._pending_H = H.shape[0], H  # (H stays alive until the upload has certainly happened)
         return True
+
+    def mcmc_run(self, coords, logp, plan, h_src, h_fixed, prior_kind, prior_par):
+        """``bgp_mcmc_run``: the whole run of the ensemble sampler on the device.  ``plan`` = (movers, partners, zz, factors,
+        logu), each (2 * nsteps, W / 2).  Returns chain (nsteps, W, p), logp (nsteps, W), final coords, final logp, accept
+        counts (W,) and the two info words (non-finite proposal seen; run redone on the launch schedule)."""
+        coords = _c(np.asarray(coords, dtype=np.float64))
+        W, p = coords.shape
+        movers, partners, zz, factors, logu = plan
+        movers = np.ascontiguousarray(movers, dtype=np.int32)
+        partners = np.ascontiguousarray(partners, dtype=np.int32)
+        zz, factors, logu = (_c(np.asarray(a, dtype=np.float64)) for a in (zz, factors, logu))
+        nhalf = movers.shape[0]
+        if nhalf % 2 or any(a.shape != (nhalf, W // 2) for a in (movers, partners, zz, factors, logu)):
+            raise ValueError("the plan must hold (2 * nsteps, W / 2) rows of every array")
+        nsteps = nhalf // 2
+        logp = _c(np.asarray(logp, dtype=np.float64))
+        h_src = np.ascontiguousarray(h_src, dtype=np.int32)
+        h_fixed = _c(np.asarray(h_fixed, dtype=np.float64))
+        prior_kind = np.ascontiguousarray(prior_kind, dtype=np.int32)
+        prior_par = _c(np.asarray(prior_par, dtype=np.float64))
+        if h_src.shape != (self.d + 2,) or h_fixed.shape != (self.d + 2,) or prior_kind.shape != (p,) or prior_par.shape != (p, 5):
+            raise ValueError("canonical map / prior tables have the wrong shape")
+        chain = np.empty((nsteps, W, p))
+        lps = np.empty((nsteps, W))
+        cout, lout = np.empty((W, p)), np.empty(W)
+        nacc = np.zeros(W, dtype=np.int64)
+        info = np.zeros(2, dtype=np.int32)
+        _check(self._lib.bgp_mcmc_run(self._h, W, p, nsteps, _p(h_src), _p(h_fixed), _p(prior_kind), _p(prior_par), _p(coords),
+                                      _p(logp), _p(movers), _p(partners), _p(zz), _p(factors), _p(logu), _p(chain), _p(lps),
+                                      _p(cout), _p(lout), nacc.ctypes.data_as(C.POINTER(C.c_longlong)), _p(info)),
+               "bgp_mcmc_run")
+        return chain, lps, cout, lout, nacc, info
 
     def lml_warped_submit(self, H, W):
         """Asynchronous ``lml_warped``: False when the batch cannot go asynchronously (see ``lml_submit``)."""

@@ -54,6 +54,12 @@ class BayesGPR(RegressorMixin, BaseEstimator):
       variates; the only practical choice for thousands of query points, where the SVD takes minutes);
     * ``"auto"`` (default): ``"reference"`` up to ``MVN_REFERENCE_MAX_POINTS`` (512) query points,
       ``"cholesky"`` beyond.  The generator is consumed identically in both modes.
+
+    ``resident_sampler`` (default True): ``sample`` / ``fit`` run the ensemble sampler with its walkers, proposals,
+    log-priors, accept tests and chain resident on the device (``bgp_mcmc_run``: no transfer between the first and the
+    last half-step) whenever the priors are ``guess_priors``' two families, the kernel has a canonical device form, the
+    inputs are not warped and the ensemble is not sharded; the same moves as the host-driven loop, log-probabilities
+    equal to ~1e-15 relative (the device's exp / pow in the priors instead of numpy's).
     """
 
     MVN_REFERENCE_MAX_POINTS = 512
@@ -73,6 +79,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         max_batch=None,
         shard_ensemble=False,
         mvn="auto",
+        resident_sampler=True,
     ):
         self._kernel = None if kernel is None else kernel.clone_with_theta(kernel.theta)
         self.kernel = kernel
@@ -93,6 +100,9 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         if mvn not in ("auto", "reference", "cholesky"):
             raise ValueError("mvn must be 'auto', 'reference' or 'cholesky', got %r" % (mvn,))
         self.mvn = mvn
+        # the ensemble sampler's whole run on the device (bgp_mcmc_run) where the priors and the kernel allow it; False: the
+        # host-driven loop (one LML batch per half-step), whose priors are numpy's to the last bit
+        self.resident_sampler = bool(resident_sampler)
         self._sampler = None
         self.chain_ = None
         self.pos_ = None
@@ -1212,6 +1222,36 @@ class _AsyncLogProb:
 
     def finish(self, token):
         return self._gp._log_prob_finish(token)
+
+    def resident(self, n_walkers, n_dim, priors=None, warp_priors=None):
+        """The sampler asks: can the whole run stay on the device (``bgp_mcmc_run``)?  A callable taking (coords,
+        log_prob, plan) when it can -- an even number of walkers, a kernel with a canonical device form, no input warp,
+        every prior one of the two families ``guess_priors`` hands out -- else None (the host-driven loop runs)."""
+        gp = self._gp
+        if not getattr(gp, "resident_sampler", True) or gp.warp_inputs or gp._generic or n_walkers % 2 or n_walkers // 2 > gp._ctx.max_batch:
+            return None
+        if callable(priors) or priors is None or gp._ctx._timing:  # (per-launch timing synchronises inside every batch)
+            return None
+        priors = list(priors)
+        if len(priors) != n_dim or any(getattr(f, "_bgp_device", None) is None for f in priors):
+            return None
+        d = gp._X_train_.shape[1]
+        try:  # the canonical map as an index table: probe it with the positions themselves
+            probe = gp._canonical(np.arange(n_dim, dtype=np.float64)[None, :] + 0.25)[0]
+            fixed = gp._canonical(np.arange(n_dim, dtype=np.float64)[None, :] + 0.75)[0]
+        except Exception:
+            return None
+        src = np.where(probe != fixed, np.floor(probe).astype(np.int64), -1)
+        if probe.shape != (d + 2,) or np.any(src >= n_dim):
+            return None
+        kind = np.array([f._bgp_device[0] for f in priors], dtype=np.int32)
+        par = np.array([f._bgp_device[1] for f in priors], dtype=np.float64)
+        ctx = gp._ctx
+
+        def run(coords, log_prob, plan):
+            return ctx.mcmc_run(coords, log_prob, plan, src, np.where(src < 0, probe, 0.0), kind, par)
+
+        return run
 
 
 def _vec_call(fn, col):

@@ -537,6 +537,74 @@ extern "C" int bgp_lml_batch_warped(bgp_ctx* c, int B, const double* h, const do
   return lml_batch_impl(c, B, h, warp, lml, status);
 }
 
+// Everything of an LML batch that runs on the device, enqueued on the context's stream(s): the nb canonical hyper-parameter
+// vectors are in c->dh (and, warped, the per-walker warp parameters in c->dwarpB) already; Gram build, factorisation and the
+// LML reduction leave c->dlml / c->dstatus.  No upload, no download, no synchronisation: bgp_lml_batch* wrap it with their
+// transfers, the device-resident ensemble sampler (bgp_mcmc.hip) calls it between its own kernels.
+int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
+  const size_t nd = (size_t)c->n * c->d;
+  // walker groups on separate streams (sizes are multiples of 8: one matrix slot per XCD)
+  int ng = (c->streams_auto && nb < 64) ? 1 : c->nstreams;
+  int gsz = ((nb + ng - 1) / ng + 7) / 8 * 8;
+  if (ng == 1 || nb < 16 || warped) {
+  ng = 1;
+  gsz = nb;
+  }
+  const bool warp = warped != 0;
+  int rc = BGP_OK;
+  const bool fused_small = c->nblk == 1 && !warp;
+  // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
+  // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
+  const bool use_ps = !fused_small && !c->timing && bgp_persist_fits(c, nb) &&
+                      (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
+  if (use_ps) c->ps_calls++;
+  if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
+  if (fused_small) {
+    // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
+    rc = bgp_launch_lml_small(c, 0, nb, c->stream);
+    if (rc) return rc;
+  } else if (warp) {
+    // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
+    rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
+    if (rc) return rc;
+    rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
+    if (rc) return rc;
+    if (use_ps) {
+      rc = bgp_launch_cholesky_persist(c, nb);
+      if (!rc) c->ps_inflight = 1;
+    } else {
+      rc = bgp_launch_cholesky(c, nb, 0);
+    }
+    if (rc) return rc;
+  } else if (use_ps) {
+    // small batch: K-build on this stream, then ONE chain / tile kernel pair instead of ~3 launches per block column
+    rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+    if (rc) return rc;
+    rc = bgp_launch_cholesky_persist(c, nb);
+    if (rc) return rc;
+    c->ps_inflight = 1;
+  } else if (ng == 1) {
+    rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+    if (rc) return rc;
+    rc = bgp_launch_cholesky(c, nb, 0);
+    if (rc) return rc;
+  } else {
+    BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
+    for (int g = 0, o = 0; o < nb; g++, o += gsz) {
+      const int gb = std::min(gsz, nb - o);
+      hipStream_t st = c->gstream[g];
+      BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
+      rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
+      if (rc) return rc;
+      rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
+      if (rc) return rc;
+      BGP_HIP(hipEventRecord(c->ev_done[g], st));
+      BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));
+    }
+  }
+  return BGP_OK;
+}
+
 static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status,
                          hipEvent_t& e0, hipEvent_t& e1, int defer_sync = 0) {
   if (B == 0) return BGP_OK;
@@ -563,71 +631,18 @@ static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp,
       (void)hipEventCreate(&e1);
       (void)hipEventRecord(e0, c->stream);
     }
-    // walker groups on separate streams (sizes are multiples of 8: one matrix slot per XCD)
-    int ng = (c->streams_auto && nb < 64) ? 1 : c->nstreams;
-    int gsz = ((nb + ng - 1) / ng + 7) / 8 * 8;
-    if (ng == 1 || nb < 16 || warp) {
-      ng = 1;
-      gsz = nb;
-    }
     // (the submit path hands over the context's own pinned blocks; a caller's pageable block goes through the arena)
     const bool own = (h == c->hh);
     if (own)
       BGP_HIP(hipMemcpyAsync(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
     else
       BGP_HIP(bgp_memcpy_async(c->dh, h + (size_t)off * p, nb * p * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    int rc = BGP_OK;
-    const bool fused_small = c->nblk == 1 && !warp;
-    // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
-    // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-    const bool use_ps = !fused_small && !c->timing && bgp_persist_fits(c, nb) &&
-                        (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
-    if (use_ps) c->ps_calls++;
-    if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
-    if (fused_small) {
-      // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
-      rc = bgp_launch_lml_small(c, 0, nb, c->stream);
-      if (rc) return rc;
-    } else if (warp) {
-      // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
+    if (warp)
       BGP_HIP(bgp_memcpy_async(c->dwarpB, warp + (size_t)off * 2 * c->d, (size_t)nb * 2 * c->d * sizeof(double),
                                hipMemcpyHostToDevice, c->stream));
-      rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
+    {
+      const int rc = bgp_lml_enqueue_dev(c, nb, warp ? 1 : 0);
       if (rc) return rc;
-      rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
-      if (rc) return rc;
-      if (use_ps) {
-        rc = bgp_launch_cholesky_persist(c, nb);
-        if (!rc) c->ps_inflight = 1;
-      } else {
-        rc = bgp_launch_cholesky(c, nb, 0);
-      }
-      if (rc) return rc;
-    } else if (use_ps) {
-      // small batch: K-build on this stream, then ONE chain / tile kernel pair instead of ~3 launches per block column
-      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
-      if (rc) return rc;
-      rc = bgp_launch_cholesky_persist(c, nb);
-      if (rc) return rc;
-      c->ps_inflight = 1;
-    } else if (ng == 1) {
-      rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
-      if (rc) return rc;
-      rc = bgp_launch_cholesky(c, nb, 0);
-      if (rc) return rc;
-    } else {
-      BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
-      for (int g = 0, o = 0; o < nb; g++, o += gsz) {
-        const int gb = std::min(gsz, nb - o);
-        hipStream_t st = c->gstream[g];
-        BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
-        rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
-        if (rc) return rc;
-        rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
-        if (rc) return rc;
-        BGP_HIP(hipEventRecord(c->ev_done[g], st));
-        BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));
-      }
     }
     if (own) {
       BGP_HIP(hipMemcpyAsync(lml + off, c->dlml, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -269,7 +269,8 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     }
   }
   bgp_launch_ps(c->stream, a, a.nchain + tile_wgs);
-  BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+  if (!c->ps_resident)
+    BGP_HIP(hipMemcpyAsync(c->ps_herr, c->ps_flags + PS_ERROR, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
   BGP_HIP(hipGetLastError());
   return BGP_OK;
 }

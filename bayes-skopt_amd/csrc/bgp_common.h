@@ -197,6 +197,7 @@ struct bgp_ctx {
   long long ps_calls = 0;       // launch-free calls enqueued by this context (bgp_persist_stats)
   long long ps_timeouts = 0;    // ... of which timed out and were redone by launches
   int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
+  int ps_resident = 0;          // the device-resident sampler is enqueuing: no per-call copy of the error word (its kernels read it)
   unsigned long long* ps_trace = nullptr;  // BGP_PS_TRACE=1: device buffer of in-kernel time stamps (bgp_debug_ps_trace)
   size_t cap_pstrace = 0;
   int ps_trace_B = 0, ps_trace_nblk = 0, ps_trace_total = 0;
@@ -345,6 +346,7 @@ static inline bool bgp_ps_allowed(bgp_ctx* c) {
 }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
+int bgp_lml_enqueue_dev(bgp_ctx* ctx, int nb, int warped);  // bgp_api.hip: Gram build + factorisation + LML of c->dh[0 .. nb), on the device only
 // the launch-free call of a batch whose results are discarded anyway: forget it (no time-out is counted, nothing is redone)
 static inline void bgp_ps_clear_inflight(bgp_ctx* c) {
   c->ps_inflight = 0;

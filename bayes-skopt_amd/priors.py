@@ -40,6 +40,7 @@ def make_roundflat(
         out = shape(x) - log_norm
         return float(out) if np.ndim(out) == 0 else out
 
+    prior._bgp_roundflat = (lo, hi, p_lo, p_hi, log_norm)  # (the device-resident sampler evaluates the same expression)
     return prior
 
 
@@ -70,4 +71,5 @@ def halfnorm_logpdf_logspace(scale):
             out = c - 0.5 * np.exp(t) / (scale * scale) + 0.5 * t
         return float(out) if np.ndim(out) == 0 else out
 
+    prior._bgp_device = (1, (c, scale * scale, 0.0, 0.0, 0.0))  # include/bgp.h bgp_mcmc_run, prior_kind 1
     return prior

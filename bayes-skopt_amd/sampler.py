@@ -140,6 +140,13 @@ class EnsembleSampler:
             raise ValueError("The initial log_prob was NaN")
 
         nsteps = int(nsteps)
+        # a log_prob_fn that can describe itself to the device (BayesGPR with its default prior families, no warp, no
+        # sharding) runs the whole loop there: proposals, priors, LML batches, accept tests and the chain stay in HBM
+        resident = getattr(self.log_prob_fn, "resident", None) if (self.vectorize and not progress and nsteps > 0) else None
+        if resident is not None:
+            run = resident(self.nwalkers, self.ndim, *self.args, **self.kwargs)
+            if run is not None:
+                return self._run_resident(run, coords, log_prob, nsteps)
         chain = np.empty((nsteps, self.nwalkers, self.ndim))
         lps = np.empty((nsteps, self.nwalkers))
         rng = self._random
@@ -181,6 +188,30 @@ class EnsembleSampler:
         self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
         self._log_prob = lps if self._log_prob is None else np.concatenate([self._log_prob, lps])
         self.iteration += nsteps
+        return State(coords, log_prob, rng.get_state())
+
+    def _run_resident(self, run, coords, log_prob, nsteps):
+        """The same run with the state on the device (``bgp_mcmc_run``): every draw of the generator is made here, up
+        front, in the order ``run_mcmc``'s loop makes them -- a half-step's stretch factors and partners, its accept
+        draws, the next half-step's -- so the generator ends in the same state and the device replays the same moves."""
+        rng, Ns = self._random, self.nwalkers // 2
+        nhalf = 2 * nsteps
+        movers = np.empty((nhalf, Ns), dtype=np.int32)
+        partners = np.empty((nhalf, Ns), dtype=np.int32)
+        zz, factors, logu = np.empty((nhalf, Ns)), np.empty((nhalf, Ns)), np.empty((nhalf, Ns))
+        for h, (mv, pt, z, f) in enumerate(self._half_step_plans(nsteps)):
+            movers[h], partners[h], zz[h], factors[h] = mv, pt, z[:, 0], f
+            with np.errstate(divide="ignore"):
+                logu[h] = np.log(rng.rand(Ns))
+        chain, lps, coords, log_prob, nacc, info = run(coords, log_prob, (movers, partners, zz, factors, logu))
+        if info[0]:
+            raise ValueError("At least one parameter value was infinite")
+        self.n_log_prob_evals += nhalf * Ns
+        self.naccepted += nacc
+        self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
+        self._log_prob = lps if self._log_prob is None else np.concatenate([self._log_prob, lps])
+        self.iteration += nsteps
+        self.resident_runs = getattr(self, "resident_runs", 0) + 1
         return State(coords, log_prob, rng.get_state())
 
     @property

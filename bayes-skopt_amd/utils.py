@@ -74,6 +74,7 @@ def _collect_priors(kernel, out):
                     out_ = _rf(np.exp(t)) + t
                 return float(out_) if np.ndim(out_) == 0 else out_
 
+            ls_prior._bgp_device = (2, roundflat._bgp_roundflat)  # include/bgp.h bgp_mcmc_run, prior_kind 2
             out.extend([ls_prior] * count)
         else:
             raise NotImplementedError(f"Unable to guess priors for this kernel: {kernel}.")

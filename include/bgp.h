@@ -337,6 +337,26 @@ int bgp_comm_nranks(bgp_comm* comm, int* nranks);
 int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, int local_error, double* lml_all,
                                  int* errors_out);
 
+/* ---- the ensemble sampler with its state resident in HBM ------------------------------------------------------------
+ * Replaces the per-half-step traffic of emcee's loop (bask/bayesgpr.py:510-530 -> emcee 3.1.6 EnsembleSampler.sample with
+ * one StretchMove: propose, compute_log_prob, accept, for each half of the ensemble): nsteps steps of W walkers (W even) with p
+ * entries each run on the device without a transfer or a synchronisation in between.  The caller draws every random number of
+ * the run in emcee's stream order (none depends on a log-probability) and passes them as the plan, 2 * nsteps half-steps of
+ * Ns = W / 2 rows: movers / partners (walker indices), zz (the stretch factors z), factors ((p - 1) log z) and logu (log of
+ * the accept draws).  A proposal is q = c - (c - s) z (s = coords[mover], c = coords[partner]); its canonical hyper-parameters
+ * are h[j] = h_src[j] >= 0 ? q[h_src[j]] : h_fixed[j] (j < d + 2); its log-prior is the sum over the p entries, in order, of
+ *   prior_kind 1:  par[0] - 0.5 exp(t) / par[1] + 0.5 t                      (half-Normal on sqrt(exp t), bask/utils.py:95-99)
+ *   prior_kind 2:  (-2 ((e^t / par[0])^par[2] + (e^t / par[1])^par[3]) - par[4]) + t   (round-flat on exp t, bask/priors.py:7-57)
+ * (prior_par: p x 5); log-probability = log-prior + LML, non-finite -> -inf (bask/bayesgpr.py:351-379); accept iff
+ * factors + lp_new - lp_old > logu.  Outputs: chain (nsteps x W x p) and logp (nsteps x W) after every step, the final
+ * ensemble (coords_out, logp_out), accept counts, info[0] != 0 when a proposal had a non-finite coordinate (emcee raises
+ * ValueError there: the caller should), info[1] = 1 when a launch-free factorisation gave up its waits and the WHOLE run was
+ * redone on the launch schedule (same bits).  Needs W / 2 <= max_batch, no pending batch, per-launch timing off. */
+int bgp_mcmc_run(bgp_ctx* ctx, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
+                 const double* prior_par, const double* coords0, const double* logp0, const int* movers, const int* partners,
+                 const double* zz, const double* factors, const double* logu, double* chain, double* logp, double* coords_out,
+                 double* logp_out, long long* naccepted, int* info);
+
 #ifdef __cplusplus
 }
 #endif
