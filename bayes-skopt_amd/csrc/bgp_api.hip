@@ -558,7 +558,8 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
   const bool use_ps = !fused_small && !c->timing && bgp_persist_fits(c, nb) &&
                       (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
   if (use_ps) c->ps_calls++;
-  if (!fused_small) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
+  // (ps_resident: the sampler's step kernel has reset the statuses in front of this batch)
+  if (!fused_small && !c->ps_resident) BGP_HIP(hipMemsetAsync(c->dstatus, 0, nb * sizeof(int), c->stream));
   if (fused_small) {
     // n <= 128: Gram generation, factorisation and LML fused into one launch (status is reset in the kernel)
     rc = bgp_launch_lml_small(c, 0, nb, c->stream);

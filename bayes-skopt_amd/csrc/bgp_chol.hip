@@ -158,6 +158,19 @@ int bgp_persist_fits(bgp_ctx* c, int B) {
 // this enqueues ONE kernel behind them -- B chain workgroups + one tile workgroup for every other CU -- and the copy of
 // the error word to pinned memory (ctx->ps_herr): != 0 after the synchronisation means a wait timed out and the caller
 // redoes the batch on the multi-launch path.
+// the flag block of a launch-free call with B matrices exists (grown with 50 % head room; contents undefined)
+int bgp_ps_ensure_flags(bgp_ctx* c, int B) {
+  const size_t words = ps_flag_words(B, c->nblk);
+  if (words > c->cap_psflags) {
+    if (c->ps_flags) (void)hipFree(c->ps_flags);
+    c->ps_flags = nullptr;
+    c->cap_psflags = 0;
+    BGP_HIP(hipMalloc(&c->ps_flags, (words + words / 2) * sizeof(unsigned)));
+    c->cap_psflags = words + words / 2;
+  }
+  return BGP_OK;
+}
+
 int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
   const int nblk = c->nblk, ld = c->npad;
   if (!bgp_persist_fits(c, B)) {
@@ -170,14 +183,12 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     *c->ps_herr = 0;
   }
   const size_t words = ps_flag_words(B, nblk);
-  if (words > c->cap_psflags) {
-    if (c->ps_flags) (void)hipFree(c->ps_flags);
-    c->ps_flags = nullptr;
-    c->cap_psflags = 0;
-    BGP_HIP(hipMalloc(&c->ps_flags, (words + words / 2) * sizeof(unsigned)));
-    c->cap_psflags = words + words / 2;
+  {
+    const int rcf = bgp_ps_ensure_flags(c, B);
+    if (rcf) return rcf;
   }
-  BGP_HIP(hipMemsetAsync(c->ps_flags, 0, words * sizeof(unsigned), c->stream));
+  // (the device-resident sampler's step kernel has zeroed the block in front of this call: one dispatch less per half-step)
+  if (!c->ps_resident) BGP_HIP(hipMemsetAsync(c->ps_flags, 0, words * sizeof(unsigned), c->stream));
   static unsigned long long limit = 0;
   if (!limit) {
     const char* e = getenv("BGP_PS_TIMEOUT_MS");

@@ -353,6 +353,7 @@ static inline void bgp_ps_clear_inflight(bgp_ctx* c) {
   if (c->ps_herr) *c->ps_herr = 0;
 }
 int bgp_persist_fits(bgp_ctx* ctx, int B);
+int bgp_ps_ensure_flags(bgp_ctx* ctx, int B);
 
 int bgp_ensure_scratch(bgp_ctx* ctx, size_t doubles);
 void bgp_free_child(bgp_ctx* ctx);

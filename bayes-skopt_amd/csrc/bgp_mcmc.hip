@@ -21,6 +21,10 @@ struct McmcArgs {
   long long* nacc;        // W
   double* q;              // Ns x p: proposals of the half-step in flight
   double* prior;          // Ns
+  double* pterm;          // Ns x p: the log-prior terms of the proposals, summed in theta order by one thread per proposal
+  int* status;            // Ns: statuses of the LML batch (reset here, in front of it)
+  unsigned* ps_flags;     // flag block of the launch-free factorisation (reset here) or nullptr
+  int ps_words;
   double* dh;             // Ns x hp: canonical hyper-parameters of the proposals (the LML batch reads them)
   const double* lml;      // Ns: the LML batch's results
   const int* h_src;       // hp: index into a walker, or -1: h_fixed
@@ -51,50 +55,62 @@ static __device__ __forceinline__ double mcmc_prior(int kind, const double* par,
 }
 
 // ONE workgroup.  h = index of the half-step to PROPOSE (0 .. nhalf); the accept phase closes half-step h - 1.
-__global__ void __launch_bounds__(256) mcmc_step_kernel(McmcArgs a, int h) {
+__global__ void __launch_bounds__(1024) mcmc_step_kernel(McmcArgs a, int h) {
 #pragma clang fp contract(off)
-  const int tid = threadIdx.x, p = a.p, Ns = a.Ns;
+  const int tid = threadIdx.x, nt = blockDim.x, p = a.p, Ns = a.Ns;
   if (h > 0) {
     const int g = h - 1;
     const int* mv = a.movers + (size_t)g * Ns;
     if (tid == 0 && a.ps_err && *a.ps_err != 0) a.info[1] = 1u;
-    for (int i = tid; i < Ns; i += blockDim.x) {
+    for (int i = tid; i < Ns; i += nt) {
       double lp = a.prior[i] + a.lml[i];
       if (!(lp > -INFINITY && lp < INFINITY)) lp = -INFINITY;  // (NaN included, as _log_prob_finish)
       const int m = mv[i];
       const bool acc = a.factors[(size_t)g * Ns + i] + lp - a.logp[m] > a.logu[(size_t)g * Ns + i];
+      a.status[i] = acc ? -1 : 0;  // (the batch is over: its status words carry the accept flags to the copy below)
       if (acc) {
-        for (int k = 0; k < p; k++) a.coords[(size_t)m * p + k] = a.q[(size_t)i * p + k];
         a.logp[m] = lp;
         a.nacc[m] += 1;
       }
     }
     __syncthreads();
+    for (int e = tid; e < Ns * p; e += nt) {
+      const int i = e / p;
+      if (a.status[i]) a.coords[(size_t)mv[i] * p + (e - i * p)] = a.q[e];
+    }
+    __syncthreads();
     if (g & 1) {  // second half of step g / 2: the ensemble goes into the chain
       const int step = g >> 1;
-      for (int e = tid; e < a.W * p; e += blockDim.x) a.chain[(size_t)step * a.W * p + e] = a.coords[e];
-      for (int e = tid; e < a.W; e += blockDim.x) a.lps[(size_t)step * a.W + e] = a.logp[e];
+      for (int e = tid; e < a.W * p; e += nt) a.chain[(size_t)step * a.W * p + e] = a.coords[e];
+      for (int e = tid; e < a.W; e += nt) a.lps[(size_t)step * a.W + e] = a.logp[e];
     }
   }
   if (h >= a.nhalf) return;
+  // the resets the LML batch would otherwise enqueue as dispatches of their own (the previous batch, and with it every reader
+  // of these words, is over: this kernel runs behind it on the stream)
+  for (int e = tid; e < Ns; e += nt) a.status[e] = 0;
+  if (a.ps_flags)
+    for (int e = tid; e < a.ps_words; e += nt) a.ps_flags[e] = 0u;
   const int* mv = a.movers + (size_t)h * Ns;
   const int* pr = a.partners + (size_t)h * Ns;
-  for (int i = tid; i < Ns; i += blockDim.x) {
+  for (int e = tid; e < Ns * p; e += nt) {
+    const int i = e / p, k = e - i * p;
     const double z = a.zz[(size_t)h * Ns + i];
-    const double* s = a.coords + (size_t)mv[i] * p;
-    const double* c = a.coords + (size_t)pr[i] * p;
-    double* q = a.q + (size_t)i * p;
+    const double s = a.coords[(size_t)mv[i] * p + k], c = a.coords[(size_t)pr[i] * p + k];
+    const double v = c - (c - s) * z;
+    a.q[e] = v;
+    if (!(v > -INFINITY && v < INFINITY)) a.info[0] = 1u;
+    a.pterm[e] = mcmc_prior(a.prior_kind[k], a.prior_par + 5 * k, v);
+  }
+  __syncthreads();
+  for (int i = tid; i < Ns; i += nt) {
     double lp = 0.0;
-    bool bad = false;
-    for (int k = 0; k < p; k++) {
-      const double v = c[k] - (c[k] - s[k]) * z;
-      q[k] = v;
-      bad = bad || !(v > -INFINITY && v < INFINITY);
-      lp += mcmc_prior(a.prior_kind[k], a.prior_par + 5 * k, v);
-    }
+    for (int k = 0; k < p; k++) lp += a.pterm[(size_t)i * p + k];
     a.prior[i] = lp;
-    if (bad) a.info[0] = 1u;
-    for (int j = 0; j < a.hp; j++) a.dh[(size_t)i * a.hp + j] = a.h_src[j] >= 0 ? q[a.h_src[j]] : a.h_fixed[j];
+  }
+  for (int e = tid; e < Ns * a.hp; e += nt) {
+    const int i = e / a.hp, j = e - i * a.hp;
+    a.dh[e] = a.h_src[j] >= 0 ? a.q[(size_t)i * p + a.h_src[j]] : a.h_fixed[j];
   }
 }
 
@@ -155,6 +171,7 @@ extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_s
     a.nacc = blk.take<long long>(W);
     a.q = blk.take<double>((size_t)Ns * p);
     a.prior = blk.take<double>(Ns);
+    a.pterm = blk.take<double>((size_t)Ns * p);
     a.h_src = blk.take<int>(hp);
     a.h_fixed = blk.take<double>(hp);
     a.prior_kind = blk.take<int>(p);
@@ -179,6 +196,16 @@ extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_s
   a.nhalf = nhalf;
   a.dh = c->dh;
   a.lml = c->dlml;
+  a.status = c->dstatus;
+  a.ps_flags = nullptr;
+  a.ps_words = 0;
+  if (c->nblk > 1 && bgp_persist_fits(c, Ns)) {  // a launch-free call may follow: its flag block is reset by the step kernel
+    const int rcf = bgp_ps_ensure_flags(c, Ns);
+    if (rcf) return rcf;
+    a.ps_flags = c->ps_flags;
+    a.ps_words = (int)ps_flag_words(Ns, c->nblk);
+  }
+  const int threads = (Ns * p > 512) ? 1024 : 256;
   hipStream_t st = c->stream;
   auto up = [&](const void* dst, const void* src, size_t bytes) {
     return bgp_memcpy_async(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, st);
@@ -203,7 +230,7 @@ extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_s
     c->ps_resident = 1;
     a.ps_err = nullptr;
     for (int h = 0; h <= nhalf && rc == BGP_OK; h++) {
-      hipLaunchKernelGGL(mcmc_step_kernel, dim3(1), dim3(256), 0, st, a, h);
+      hipLaunchKernelGGL(mcmc_step_kernel, dim3(1), dim3(threads), 0, st, a, h);
       if (h == nhalf) break;
       c->ps_inflight = 0;
       rc = bgp_lml_enqueue_dev(c, Ns, 0);
