@@ -284,7 +284,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_PANELS",
-                                "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
+                                "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_GEN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -571,17 +571,15 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
     rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
     if (rc) return rc;
     if (use_ps) {
-      rc = bgp_launch_cholesky_persist(c, nb);
+      rc = bgp_launch_cholesky_persist(c, nb, 0);
       if (!rc) c->ps_inflight = 1;
     } else {
       rc = bgp_launch_cholesky(c, nb, 0);
     }
     if (rc) return rc;
   } else if (use_ps) {
-    // small batch: K-build on this stream, then ONE chain / tile kernel pair instead of ~3 launches per block column
-    rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
-    if (rc) return rc;
-    rc = bgp_launch_cholesky_persist(c, nb);
+    // small batch: ONE launch-free kernel instead of ~3 launches per block column, the Gram build inside it or in front of it
+    rc = bgp_launch_cholesky_persist(c, nb, 1);
     if (rc) return rc;
     c->ps_inflight = 1;
   } else if (ng == 1) {

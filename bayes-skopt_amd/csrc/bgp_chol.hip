@@ -130,7 +130,7 @@ extern "C" int bgp_debug_pivot_root(int device, int n, const double* x, double* 
 // the batch on the multi-launch path.  Arithmetic, operand order and summation order are those of the multi-launch path:
 // the log-likelihoods are bit-identical (tests/test_gpu_persist.py).
 // ------------------------------------------------------------------------------------------
-int bgp_ps_total_tasks(int B, int nblk, int np);
+int bgp_ps_total_tasks(int B, int nblk, int np, int gen);
 void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg);
 
 // BGP_PS_TRACE=1: the time stamps of the last launch-free call (100 MHz wall clock): dims = {B, nblk, total tasks};
@@ -171,7 +171,7 @@ int bgp_ps_ensure_flags(bgp_ctx* c, int B) {
   return BGP_OK;
 }
 
-int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
+int bgp_launch_cholesky_persist(bgp_ctx* c, int B, int build_gram) {
   const int nblk = c->nblk, ld = c->npad;
   if (!bgp_persist_fits(c, B)) {
     bgp_set_error("bgp_launch_cholesky_persist: B = %d, nblk = %d outside the persistent path's range", B, nblk);
@@ -231,12 +231,12 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     // two-slice and the mixed variants measured slower and left the library in round 5)
     a.psplit = a.pair ? 4 : 1;
     a.dsplit = a.psplit == 4 ? 3 : 1;
-    a.total = bgp_ps_total_tasks(B, nblk, a.psplit);
+    a.total = bgp_ps_total_tasks(B, nblk, a.psplit, 0);
     // pair mode: the panel solves S(J+2, J) and S(J+3, J) follow pf_block(J) row block by row block (S(J+3, J) feeds the
     // quadrants ahead of the next column's critical solve; streaming fewer measured slower)
     a.ncrit_stream = 3;
   }
-  const int tile_wgs = std::min(a.total, ncu - a.nchain);
+  int tile_wgs = std::min(a.total, ncu - a.nchain);
   {
     // critical pool of the tile role: the three tasks at the head of a block column -- S(J+2, J), P(J+2), Dg(J+2) -- get
     // workgroups of their own, one per task of a column.  Measured in round 3: with up to ~10 block columns the chain waits less
@@ -255,6 +255,32 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B) {
     // previous column)
     if (a.ncrit > tile_wgs - 1) a.ncrit = std::max(0, tile_wgs - 1);
   }
+  // build_gram: the caller has NOT built the Gram matrices (plain LML batch: unwarped inputs, c->dh, diagonal additions).  With one
+  // chain workgroup per matrix, one ticket list and the default kernel form the tile workers generate them block by block at the
+  // head of that list -- the chain starts on block (0, 0) ~10 us into the launch instead of behind a whole Gram kernel and a kernel
+  // boundary (n = 1024 x 32: 63 + ~15 us) -- else the Gram kernel goes in front as before.  BGP_PS_GEN = 0 / 1 fixes it.
+  a.gen = 0;
+  if (build_gram) {
+    static int want = -2;
+    if (want == -2) {
+      const char* e = getenv("BGP_PS_GEN");
+      want = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+    }
+    const bool can = !a.pair && a.ncrit == 0 && a.total > 0 && c->ks.stationary == BGP_MATERN52 && c->ks.form == BGP_FORM_PRODUCT;
+    if (can && (want == 1 || (want == -1 && bgp_ps_gen_auto_rule(nblk, B)))) {
+      a.gen = 1;
+      a.total = bgp_ps_total_tasks(B, nblk, a.psplit, 1);
+    } else {
+      const int rck = bgp_launch_kbuild(c, B, 0, 0, 1);
+      if (rck) return rck;
+    }
+  }
+  a.d = c->d;
+  a.X = c->dXeff;
+  a.alpha = c->dalpha;
+  a.H = c->dh;
+  a.y = c->dy;
+  tile_wgs = std::min(a.total, ncu - a.nchain);  // (gen adds tasks)
   a.spin_limit = limit;
   a.trace = nullptr;
   {

@@ -293,8 +293,24 @@ struct PsArgs {
   int ncrit_stream;   // pair mode: panel solves S(I, J) with I <= J + ncrit_stream follow pf_block(J) row block by row block
   unsigned long long spin_limit;  // wall_clock64 ticks (100 MHz) a single wait may last before the call is abandoned
   unsigned long long* trace;      // debugging (BGP_PS_TRACE=1): wall-clock stamps, chain: 8 per (b, J), tile: 8 per task
+  // gen = 1: the Gram matrices are generated INSIDE this launch -- the first B nblk (nblk + 1) / 2 tickets of the tile list are one
+  // 128 x 128 block each (kb_gram_tile512; block (I, 0) also sets up row block I of the right-hand side), genrdy[b][I][J] tells
+  // its consumer -- instead of by a Gram kernel in front of it (Matern-5/2 product form, one chain workgroup per matrix, one list)
+  int gen, d;
+  const double* X;      // n x d training inputs
+  const double* alpha;  // n diagonal additions
+  const double* H;      // B x (d + 2) canonical hyper-parameters
+  const double* y;      // n
 };
-static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (8 + nblk); }
+//   genrdy[(b * nblk + I) * nblk + J]   gen = 1: block (I, J) of matrix b has been generated (behind s2rdy)
+#define PS_GEN(B, nblk) (PS_HDR + (size_t)(B) * (nblk) * (8 + (nblk)))
+// Shapes at which the tile workers generate the Gram blocks inside the launch-free kernel (PsArgs::gen) instead of a Gram kernel in
+// front of it: where the chain is the bound and the tile side has the slack to take the extra work (measured: bgp_chol.hip)
+// (tools/gen_probe.py, ms per LML call without -> with: 1024 x 24 0.488 -> 0.464, x 16 0.476 -> 0.456, x 8 0.460 -> 0.449; 768 x 32
+// 0.383 -> 0.362; 1536 x 16 0.729 -> 0.719; 2048 x 8 0.927 -> 0.884; 512 x 32 0.260 -> 0.250; but 1024 x 32 0.522 -> 0.527, 2048 x 16
+// 1.308 -> 1.357 and 3072 x 8 1.921 -> 1.936: there the tile side is the bound already and the blocks are extra work for it)
+static inline bool bgp_ps_gen_auto_rule(int nblk, int B) { return nblk >= 4 && nblk <= 16 && B <= 32 && B * nblk <= 192; }
+static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (8 + 2 * (size_t)nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
 // DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
 //   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11
@@ -344,7 +360,7 @@ static inline bool bgp_ps_allowed(bgp_ctx* c) {
   if (c->ps_cooldown > 0 && --c->ps_cooldown == 0) c->ps_disabled = 0;
   return false;
 }
-int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B);
+int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B, int build_gram);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
 int bgp_lml_enqueue_dev(bgp_ctx* ctx, int nb, int warped);  // bgp_api.hip: Gram build + factorisation + LML of c->dh[0 .. nb), on the device only
 // the launch-free call of a batch whose results are discarded anyway: forget it (no time-out is counted, nothing is redone)

@@ -12,76 +12,7 @@
 #include "bgp_common.h"
 #include "bgp_device.h"
 #include "bgp_ring.h"
-
-#define KB_DK 16  // input dimensions staged per pass
-
-// Epilogue of a 128 x 128 tile whose squared scaled distances sit in acc[r][c] (rows ty + 16 r, columns tx + 16 c):
-// stationary kernel, constant, exact diagonal / identity padding (GRAM) or zero padding (cross matrices).
-// R = rows per thread (8: 256 threads, rows ty + 16 r; 4: 512 threads, rows ty + 32 r).
-template <int GRAM, int STAT, int FORM, int R = 8>
-static __device__ __forceinline__ void kb_epilogue(double (&acc)[R][8], int na, int nb, int d,
-                                                   const double* __restrict__ h, const double* __restrict__ alpha,
-                                                   int i0, int j0, double* __restrict__ out, size_t ldo, int out_rows,
-                                                   int out_cols, int tx, int ty) {
-#pragma clang fp contract(off)
-  const double cst = exp(h[0]);
-  const bool interior = (i0 + 128 <= na) && (j0 + 128 <= nb) && (i0 + 128 <= out_rows) && (j0 + 128 <= out_cols) &&
-                        !(GRAM && i0 == j0);
-  if (interior) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      double* orow = out + (size_t)(i0 + ty + (128 / R) * r) * ldo + j0 + tx;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const double s = kb_stationary<STAT>(acc[r][c]);
-        const double v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
-        orow[16 * c] = v;
-        if (!GRAM) acc[r][c] = v;  // (cross builds: the caller may go on with the values, see kbuild_cross_kernel)
-      }
-    }
-    return;
-  }
-  const double s2 = exp(h[d + 1]);
-#pragma unroll
-  for (int r = 0; r < R; r++) {
-    const int gi = i0 + ty + (128 / R) * r;
-    if (!GRAM) {
-      // cross matrices are consumed by 128-tiled GEMMs: the tile's padding (rows >= out_rows, columns >= out_cols,
-      // inside the 128-padded buffer) is written as zeros here, so no memset pass over the buffer is needed
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const int gj = j0 + tx + 16 * c;
-        double v = 0.0;
-        if (gi < out_rows && gj < out_cols) {
-          const double sv = kb_stationary<STAT>(acc[r][c]);
-          v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
-        }
-        out[(size_t)gi * ldo + gj] = v;
-        acc[r][c] = v;
-      }
-      continue;
-    }
-    if (gi >= out_rows) continue;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const int gj = j0 + tx + 16 * c;
-      if (gj >= out_cols) continue;
-      double v;
-      if (GRAM && (gi >= na || gj >= nb)) {
-        v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
-      } else if (GRAM && gi == gj) {
-        // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
-        const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
-        v = (base + s2);
-        if (alpha) v += alpha[gi];
-      } else {
-        const double s = kb_stationary<STAT>(acc[r][c]);
-        v = (FORM == BGP_FORM_PRODUCT) ? cst * s : cst + s;
-      }
-      out[(size_t)gi * ldo + gj] = v;
-    }
-  }
-}
+#include "bgp_kb.h"
 
 // Generic tile body: out[(i0+..)][(j0+..)] = k(A_i, B_j); A is (na x d), Bm is (nb x d), row-major.
 // GRAM != 0: A == Bm is the training set, diagonal gets c(+1) + s2 + alpha_i, padding gets identity.

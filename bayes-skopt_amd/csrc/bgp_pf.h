@@ -383,10 +383,18 @@ static __device__ __forceinline__ int pf_block(int b, double* __restrict__ Kbuf,
   for (int sb = 0; sb < 8; sb++) {
     PF_TW(2 * sb);
     if (PRE && w == 4 && lane == 0 && !pre_seen) {
-      if (k == 0 || (sb > 0 && pre_fs >= (unsigned)pa.psplit && pre_fd >= (unsigned)pa.dsplit)) {
-        if (k > 0) ps_acquire();
+      // (column 0 has no pre-update tasks: its two blocks are final as generated -- by the Gram kernel in front of this launch,
+      // or, pa.gen, by two tile workers of this launch: genrdy)
+      const bool gen0 = k == 0 && pa.gen;
+      const unsigned want_s = gen0 ? 1u : (unsigned)pa.psplit, want_d = gen0 ? 1u : (unsigned)pa.dsplit;
+      if ((k == 0 && !pa.gen) || (sb > 0 && pre_fs >= want_s && pre_fd >= want_d)) {
+        if (k > 0 || pa.gen) ps_acquire();
         lds.fail[1] = 1;
         pre_seen = 1;
+      } else if (gen0) {
+        const unsigned* const g1 = pa.flags + PS_GEN(pa.B, nblk) + ((size_t)b * nblk + 1) * nblk;
+        pre_fs = ps_ld(g1 + 0);  // genrdy[1][0]
+        pre_fd = ps_ld(g1 + 1);  // genrdy[1][1]
       } else {
         pre_fd = ps_ld(pa.flags + PS_HDR + (size_t)pa.B * nblk + (size_t)b * nblk + (k + 1));                  // diagrdy[k + 1]
         pre_fs = ps_ld(pa.flags + PS_HDR + (size_t)pa.B * nblk * (2 + nblk) + (size_t)b * nblk + (k + 1));   // subrdy[k + 1]
@@ -673,11 +681,13 @@ static __device__ __forceinline__ int pf_chain_next(const PsArgs& a, int b, int 
   double* const Ab = Mb + (size_t)I * 128 * ld + (size_t)J * 128;
   const double* const Db = Mb + (size_t)I * 128 * ld + (size_t)I * 128;
   const bool early = pre.state == 2;  // (uniform) requested behind pf_block(J)'s last step: flags seen, acquired, loads issued
-  if (J > 0 && !early) {
+  if ((J > 0 || a.gen) && !early) {
     if (tid == 0) {
       const unsigned* const diagrdy = flags + PS_HDR + (size_t)a.B * nblk + (size_t)b * nblk;
       const unsigned* const subrdy = flags + PS_HDR + (size_t)a.B * nblk * (2 + nblk) + (size_t)b * nblk;
-      const bool ok = ps_wait_ge2(subrdy + I, (unsigned)a.psplit, diagrdy + I, (unsigned)a.dsplit, err, a.spin_limit);
+      const unsigned* const g1 = flags + PS_GEN(a.B, nblk) + ((size_t)b * nblk + 1) * nblk;  // genrdy[1][.]
+      const bool ok = J > 0 ? ps_wait_ge2(subrdy + I, (unsigned)a.psplit, diagrdy + I, (unsigned)a.dsplit, err, a.spin_limit)
+                            : ps_wait_ge2(g1 + 0, 1u, g1 + 1, 1u, err, a.spin_limit);
       ps_acquire();
       *ok_lds = ok ? 1 : 0;
     }
@@ -1267,6 +1277,16 @@ static __device__ __forceinline__ void ps_chain_role(const PsArgs& a, int b, int
   unsigned long long* const tr = a.trace ? a.trace + (size_t)b * a.nblk * 8 : nullptr;
   PfPre pre;
   pre.state = 0;
+  if (!PAIR && a.gen) {  // block (0, 0) and the first 128 entries of the right-hand side come from a tile worker of this launch
+    if (tid == 0) {
+      const bool ok = ps_wait_ge(flags + PS_GEN(a.B, a.nblk) + (size_t)b * a.nblk * a.nblk, 1u, flags + PS_ERROR, a.spin_limit);
+      ps_acquire();
+      ps_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!ps_ok) return;
+    __syncthreads();
+  }
   for (int J = 0; J < a.nblk; J++) {
     if (PAIR && (J & 1) != p) {  // the partner factorises column J: prepare block (J+1, J+1) under it
       if (J + 1 < a.nblk && pf_pair_helper(a, b, J, &ps_ok, &ps_peek, tr) < 0) return;

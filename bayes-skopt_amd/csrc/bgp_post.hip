@@ -1097,7 +1097,7 @@ extern "C" int bgp_sample_y(bgp_ctx* c, int b, const double* h_kernel, int m, co
       if (ps) {
         c->ps_calls++;
         w->persist = 1;
-        if ((rc = bgp_launch_cholesky_persist(w, 1))) break;
+        if ((rc = bgp_launch_cholesky_persist(w, 1, 0))) break;
       } else if ((rc = bgp_launch_cholesky(w, 1, 0))) {
         break;
       }

@@ -4,6 +4,7 @@
 // the launch schedule (potrf_kernel / trsm4_kernel / syrk4_kernel): bit-identical factors and log-likelihoods.
 // Replaces nothing in the reference: a scheduling choice behind cholesky() of sklearn/_gpr.py:587.
 #include "bgp_s4.h"
+#include "bgp_kb.h"
 #include "bgp_pf.h"
 
 // ------------------------------------------------------------------------------------------
@@ -369,6 +370,22 @@ static __device__ __forceinline__ int ps_ll_update_quad(const PsArgs& a, const d
   return 0;
 }
 
+// PsArgs::gen: one Gram block (I, J) of matrix b, generated where the Gram kernel in front of the launch would have written it
+// (same arithmetic per element: kb_gram_tile512); block (I, 0) also copies row block I of y into the working right-hand side.
+static __device__ __forceinline__ void ps_gen_task(const PsArgs& a, int b, int I, int J) {
+  const int tid = threadIdx.x;
+  double* const lds = reinterpret_cast<double*>(pf_lds_raw());
+  double* const xi = lds;
+  double* const xj = xi + KB_DK * BGP_TILE_LD;
+  double* const ell = xj + KB_DK * BGP_TILE_LD;
+  if (J == 0 && tid < 128) a.yw[(size_t)b * a.ystride + I * 128 + tid] = a.y[I * 128 + tid];
+  kb_gram_tile512<BGP_MATERN52, BGP_FORM_PRODUCT>(a.X, a.n, a.d, a.H + (size_t)b * (a.d + 2), a.alpha, I * 128, J * 128,
+                                                 a.K + (size_t)b * a.mstride, (size_t)a.ld, a.ld, xi, xj, ell);
+  ps_publish_barrier();
+  if (tid == 0) ps_signal_add(a.flags + PS_GEN(a.B, a.nblk) + ((size_t)b * a.nblk + I) * a.nblk + J);
+  __syncthreads();
+}
+
 // wg = this workgroup's index among the tile workgroups of the launch
 template <int PAIR>
 static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
@@ -396,7 +413,8 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     const int Bx = (B - x + 7) / 8;  // matrices b = x, x + 8, ... < B
     // parts of a P task, of a Dg task, quadrants Q ahead of the critical solve; critical tasks per column and matrix
     const int NP = a.psplit, ND = PS_ND(NP), NQ = PS_NQ(NP), NK = NQ + 1 + NP + ND;
-    const int per_matrix = !pools ? ps_tasks_per_matrix(nblk, NP) : (pool == 0 ? ps_crit_per_matrix(nblk, NP) : ps_bulk_per_matrix(nblk));
+    const int ngen = a.gen ? nblk * (nblk + 1) / 2 : 0;  // (gen: one list, the Gram blocks lead it)
+    const int per_matrix = !pools ? ngen + ps_tasks_per_matrix(nblk, NP) : (pool == 0 ? ps_crit_per_matrix(nblk, NP) : ps_bulk_per_matrix(nblk));
     if (tid == 0) {
       int tt = -1;
       if (Bx > 0 && per_matrix > 0) {
@@ -422,6 +440,40 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
     // 3: Q(I), quadrant `part` of block (I, J) with I = J + 2.  Order inside a column's critical group: Q, S, P, Dg -- a task only
     // ever waits for tasks with EARLIER tickets (or for the chain): Q for the bulk solves of column J - 1, S(J+2, J) for its Q.
     int J = 0, kq = NQ, I;
+    if (ngen) {
+      // one list: G0 G1 G2 T0 G3 T1 G4 T2 ... -- G_j = the nblk - j blocks of block column j, T_J = the tasks of column J, which touch
+      // blocks of the columns J (solves), J + 1 (P) and J + 2 (Dg): still topological, and only three columns of blocks (not the
+      // whole triangle) stand between the start of the launch and the first solves
+      int Jg = 0;
+      bool hit = false;
+      for (; Jg < 3 && Jg < nblk; Jg++) {
+        const int cg = (nblk - Jg) * Bx;
+        if (t < cg) {
+          hit = true;
+          break;
+        }
+        t -= cg;
+      }
+      if (!hit)
+        for (;; J++) {
+          const int c = (NK + nblk - J - 3) * Bx;
+          if (t < c) break;
+          t -= c;
+          if (J + 3 < nblk) {
+            const int cg = (nblk - J - 3) * Bx;
+            if (t < cg) {
+              hit = true;
+              Jg = J + 3;
+              break;
+            }
+            t -= cg;
+          }
+        }
+      if (hit) {
+        ps_gen_task(a, x + 8 * (t % Bx), Jg + t / Bx, Jg);
+        continue;
+      }
+    }
     if (pools && pool == 0) {  // NK critical tasks per column and matrix
       J = t / (NK * Bx);
       t -= J * NK * Bx;
@@ -429,12 +481,13 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       I = J + 2;
     } else {
       const int head = pools ? 0 : NK;  // (one list: the critical tasks lead their column)
-      for (;;) {
-        const int c = (head + nblk - J - 3) * Bx;
-        if (t < c) break;
-        t -= c;
-        J++;
-      }
+      if (!ngen)  // (gen: J and the position inside the column were found above)
+        for (;;) {
+          const int c = (head + nblk - J - 3) * Bx;
+          if (t < c) break;
+          t -= c;
+          J++;
+        }
       const int q0 = t / Bx;
       kq = q0 < head ? q0 : NQ;  // (a bulk task is a solve)
       I = q0 < head ? J + 2 : J + 3 + (q0 - head);
@@ -463,8 +516,16 @@ static __device__ __forceinline__ void ps_tile_role(const PsArgs& a, int wg) {
       tr[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | ((unsigned long long)kind << 28) |
               ((unsigned long long)Jc << 20) | ((unsigned long long)I << 12) | (unsigned long long)b;
     }
-    if (tid == 0) sh_q = (__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0;
+    if (tid == 0) {
+      bool ok = true;
+      if (a.gen) {  // the task's own block comes from a tile worker of this launch
+        ok = ps_wait_ge(flags + PS_GEN(B, nblk) + ((size_t)b * nblk + I) * nblk + Jc, 1u, err, a.spin_limit);
+        ps_acquire();
+      }
+      sh_q = !ok ? -1 : ((__hip_atomic_load(stat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? 1 : 0);
+    }
     __syncthreads();
+    if (sh_q < 0) return;   // abandoned
     bool dead = sh_q != 0;  // the matrix has failed: nothing to compute, the task only passes its flag on
     __syncthreads();
     if (qpre) {
@@ -682,5 +743,5 @@ void bgp_launch_ps(hipStream_t st, const PsArgs& a, int nwg) {
   else
     hipLaunchKernelGGL(ps_kernel<0>, dim3(nwg), dim3(512), 0, st, a);
 }
-int bgp_ps_total_tasks(int B, int nblk, int np) { return B * ps_tasks_per_matrix(nblk, np); }
+int bgp_ps_total_tasks(int B, int nblk, int np, int gen) { return B * (ps_tasks_per_matrix(nblk, np) + (gen ? nblk * (nblk + 1) / 2 : 0)); }
 

@@ -242,7 +242,9 @@ int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const d
  * Environment switches the library reads (a BGP_* variable it does not read is reported once on stderr).  Schedule switches --
  * each selects between code paths whose results are bit-identical (tests/test_gpu_edge.py, tests/test_gpu_persist.py):
  *   BGP_STREAMS (this call), BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
- *   (bgp_set_persist), BGP_PS_PAIR (0 / 1: one or two chain workgroups per matrix on the launch-free path; default by shape).
+ *   (bgp_set_persist), BGP_PS_PAIR (0 / 1: one or two chain workgroups per matrix on the launch-free path; default by shape),
+ *   BGP_PS_GEN (0 / 1: the Gram blocks of a launch-free LML batch are built by a kernel in front of it / by its own tile workers
+ *   at the head of their ticket list; default by shape).
  * Waits and diagnostics (no effect on results): BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_TRACE,
  *   BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  The A/B switches of earlier rounds (BGP_FUSED_GRAM, BGP_KBUILD1,
  *   BGP_SMALL_SPLIT, BGP_PS_NCRIT / _PSPLIT / _STREAM, BGP_PANEL_WIDTH, BGP_ROWQUAD_T) left the library in round 5 with the

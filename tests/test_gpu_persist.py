@@ -84,6 +84,21 @@ def test_launch_free_factorisation_is_bit_identical_to_the_launch_schedule(chain
     assert got["1024_8_32"]["lml"][0][2] == float("-inf").hex()
 
 
+@pytest.mark.parametrize("gen", ["0", "1"])
+def test_gram_blocks_built_inside_the_launch_free_kernel_keep_the_bits(gen):
+    """BGP_PS_GEN=1: the tile workers generate the Gram blocks (and the working right-hand side) at the head of their ticket list
+    instead of a Gram kernel in front of the launch; =0: the kernel in front, whatever the shape.  Shapes with failing matrices
+    (a NaN walker, a pivot that fails in block column 1), ragged n, one matrix, a context-level diagonal vector."""
+    shapes = [(300, 3, 8), (1024, 8, 32), (975, 8, 13), (640, 5, 1), (2048, 16, 9), (1100, 6, 24), (520, 2, 32)]
+    ref, _ = _run({"BGP_PERSIST": "0"}, shapes)
+    got, err = _run({"BGP_PERSIST": "1", "BGP_PS_PAIR": "0", "BGP_PS_GEN": gen}, shapes)
+    assert "timed out" not in err and "not one this library reads" not in err, err[-1500:]
+    for k in ref:
+        assert got[k]["lml"] == ref[k]["lml"] and got[k]["status"] == ref[k]["status"], k
+        assert got[k]["lml"][0] == got[k]["lml"][2], k
+        assert got[k]["Lsum"] == ref[k]["Lsum"] and got[k]["zsum"] == ref[k]["zsum"], k
+
+
 @pytest.mark.parametrize("pair", ["0", "1"])
 def test_both_chain_schemes_keep_the_bits_on_further_shapes(pair):
     """The shapes the automatic rule sends to the OTHER scheme too: few and many matrices, 5 to 16 block columns, a ragged n."""
