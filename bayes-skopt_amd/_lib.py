@@ -67,6 +67,9 @@ SIGNATURES = {
     "bgp_posterior_batch_gram": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, _dp, _ip]),
     "bgp_predict_batch_gram": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "bgp_comm_abort": (C.c_int, [_vp]),
+    "bgp_mcmc_begin": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp]),
+    "bgp_mcmc_steps": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp, _dp, _dp]),
+    "bgp_mcmc_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.POINTER(C.c_longlong), _ip]),
     "bgp_mcmc_run": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp,
                                _dp, C.POINTER(C.c_longlong), _ip]),
     "bgp_comm_available": (C.c_int, []),
@@ -231,20 +234,11 @@ class Context:
         self._pending, self._pending_H = H.shape[0], H  # (H stays alive until the upload has certainly happened)
         return True
 
-    def mcmc_run(self, coords, logp, plan, h_src, h_fixed, prior_kind, prior_par):
-        """``bgp_mcmc_run``: the whole run of the ensemble sampler on the device.  ``plan`` = (movers, partners, zz, factors,
-        logu), each (2 * nsteps, W / 2).  Returns chain (nsteps, W, p), logp (nsteps, W), final coords, final logp, accept
-        counts (W,) and the two info words (non-finite proposal seen; run redone on the launch schedule)."""
+    def mcmc_begin(self, coords, logp, nsteps, h_src, h_fixed, prior_kind, prior_par):
+        """``bgp_mcmc_begin``: open a device-resident run of the ensemble sampler (``nsteps`` steps of the (W, p) ensemble
+        ``coords`` with log-probabilities ``logp``); the plan follows in segments through ``mcmc_steps``, ``mcmc_end`` collects."""
         coords = _c(np.asarray(coords, dtype=np.float64))
         W, p = coords.shape
-        movers, partners, zz, factors, logu = plan
-        movers = np.ascontiguousarray(movers, dtype=np.int32)
-        partners = np.ascontiguousarray(partners, dtype=np.int32)
-        zz, factors, logu = (_c(np.asarray(a, dtype=np.float64)) for a in (zz, factors, logu))
-        nhalf = movers.shape[0]
-        if nhalf % 2 or any(a.shape != (nhalf, W // 2) for a in (movers, partners, zz, factors, logu)):
-            raise ValueError("the plan must hold (2 * nsteps, W / 2) rows of every array")
-        nsteps = nhalf // 2
         logp = _c(np.asarray(logp, dtype=np.float64))
         h_src = np.ascontiguousarray(h_src, dtype=np.int32)
         h_fixed = _c(np.asarray(h_fixed, dtype=np.float64))
@@ -252,16 +246,54 @@ class Context:
         prior_par = _c(np.asarray(prior_par, dtype=np.float64))
         if h_src.shape != (self.d + 2,) or h_fixed.shape != (self.d + 2,) or prior_kind.shape != (p,) or prior_par.shape != (p, 5):
             raise ValueError("canonical map / prior tables have the wrong shape")
+        _check(self._lib.bgp_mcmc_begin(self._h, W, p, int(nsteps), _p(h_src), _p(h_fixed), _p(prior_kind), _p(prior_par), _p(coords),
+                                        _p(logp)), "bgp_mcmc_begin")
+        self._mcmc = (W, p, int(nsteps))
+
+    def mcmc_steps(self, plan):
+        """``bgp_mcmc_steps``: hand over the next segment of the plan -- (movers, partners, zz, factors, logu), each
+        (2 * nseg, W / 2) -- and return at once; the device works through it while the caller draws the next segment."""
+        W, p, _ = self._mcmc
+        movers, partners, zz, factors, logu = plan
+        movers = np.ascontiguousarray(movers, dtype=np.int32)
+        partners = np.ascontiguousarray(partners, dtype=np.int32)
+        zz, factors, logu = (_c(np.asarray(a, dtype=np.float64)) for a in (zz, factors, logu))
+        nhalf = movers.shape[0]
+        if nhalf % 2 or any(a.shape != (nhalf, W // 2) for a in (movers, partners, zz, factors, logu)):
+            raise ValueError("a plan segment must hold (2 * nseg, W / 2) rows of every array")
+        try:
+            _check(self._lib.bgp_mcmc_steps(self._h, nhalf // 2, _p(movers), _p(partners), _p(zz), _p(factors), _p(logu)), "bgp_mcmc_steps")
+        except BaseException:
+            self.mcmc_abandon()
+            raise
+
+    def mcmc_abandon(self):
+        """Drop an open run (an exception between ``mcmc_begin`` and ``mcmc_end``): ``bgp_mcmc_end`` with nothing to
+        collect closes it on the C side."""
+        if getattr(self, "_mcmc", None) is not None:
+            self._mcmc = None
+            self._lib.bgp_mcmc_end(self._h, None, None, None, None, None, None)
+
+    def mcmc_end(self):
+        """``bgp_mcmc_end``: wait for the run and collect chain (nsteps, W, p), logp (nsteps, W), the final ensemble and its
+        log-probabilities, accept counts (W,) and the two info words (non-finite proposal seen; run redone on the launch
+        schedule)."""
+        W, p, nsteps = self._mcmc
+        self._mcmc = None
         chain = np.empty((nsteps, W, p))
         lps = np.empty((nsteps, W))
         cout, lout = np.empty((W, p)), np.empty(W)
         nacc = np.zeros(W, dtype=np.int64)
         info = np.zeros(2, dtype=np.int32)
-        _check(self._lib.bgp_mcmc_run(self._h, W, p, nsteps, _p(h_src), _p(h_fixed), _p(prior_kind), _p(prior_par), _p(coords),
-                                      _p(logp), _p(movers), _p(partners), _p(zz), _p(factors), _p(logu), _p(chain), _p(lps),
-                                      _p(cout), _p(lout), nacc.ctypes.data_as(C.POINTER(C.c_longlong)), _p(info)),
-               "bgp_mcmc_run")
+        _check(self._lib.bgp_mcmc_end(self._h, _p(chain), _p(lps), _p(cout), _p(lout), nacc.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                      _p(info)), "bgp_mcmc_end")
         return chain, lps, cout, lout, nacc, info
+
+    def mcmc_run(self, coords, logp, plan, h_src, h_fixed, prior_kind, prior_par):
+        """``bgp_mcmc_run``: the same run with the whole plan handed over at once."""
+        self.mcmc_begin(coords, logp, np.asarray(plan[0]).shape[0] // 2, h_src, h_fixed, prior_kind, prior_par)
+        self.mcmc_steps(plan)
+        return self.mcmc_end()
 
     def lml_warped_submit(self, H, W):
         """Asynchronous ``lml_warped``: False when the batch cannot go asynchronously (see ``lml_submit``)."""

@@ -1224,8 +1224,8 @@ class _AsyncLogProb:
         return self._gp._log_prob_finish(token)
 
     def resident(self, n_walkers, n_dim, priors=None, warp_priors=None):
-        """The sampler asks: can the whole run stay on the device (``bgp_mcmc_run``)?  A callable taking (coords,
-        log_prob, plan) when it can -- an even number of walkers, a kernel with a canonical device form, no input warp,
+        """The sampler asks: can the whole run stay on the device (``bgp_mcmc_begin`` / ``_steps`` / ``_end``)?  An object
+        with begin(coords, log_prob, nsteps) / steps(plan segment) / end() / abandon() when it can -- an even number of walkers, a kernel with a canonical device form, no input warp,
         every prior one of the two families ``guess_priors`` hands out -- else None (the host-driven loop runs)."""
         gp = self._gp
         if not getattr(gp, "resident_sampler", True) or gp.warp_inputs or gp._generic or n_walkers % 2 or n_walkers // 2 > gp._ctx.max_batch:
@@ -1247,11 +1247,18 @@ class _AsyncLogProb:
         kind = np.array([f._bgp_device[0] for f in priors], dtype=np.int32)
         par = np.array([f._bgp_device[1] for f in priors], dtype=np.float64)
         ctx = gp._ctx
+        h_fixed = np.where(src < 0, probe, 0.0)
 
-        def run(coords, log_prob, plan):
-            return ctx.mcmc_run(coords, log_prob, plan, src, np.where(src < 0, probe, 0.0), kind, par)
+        class _Run:  # (the sampler hands the plan over in segments and draws the next one while the device works)
+            @staticmethod
+            def begin(coords, log_prob, nsteps):
+                ctx.mcmc_begin(coords, log_prob, nsteps, src, h_fixed, kind, par)
 
-        return run
+            steps = staticmethod(ctx.mcmc_steps)
+            end = staticmethod(ctx.mcmc_end)
+            abandon = staticmethod(ctx.mcmc_abandon)
+
+        return _Run
 
 
 def _vec_call(fn, col):

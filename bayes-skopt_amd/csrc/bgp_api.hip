@@ -397,6 +397,7 @@ extern "C" int bgp_ctx_update_data(bgp_ctx* c, int n, const double* X, const dou
 extern "C" void bgp_ctx_destroy(bgp_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  bgp_mcmc_abandon(c);  // (a sampler run left open: its work is drained, its block freed)
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   bgp_free_child(c);
   free_dev(c->dX);
@@ -762,7 +763,7 @@ extern "C" int bgp_lml_batch_wait(bgp_ctx* c, double* lml, int* status) {
     bgp_set_error("bgp_lml_batch_wait: bad argument");
     return BGP_ERR_INVALID;
   }
-  if (c->pending_B == 0) {
+  if (c->pending_B <= 0) {  // (< 0: a device-resident sampler run is open, not a submitted batch)
     bgp_set_error("bgp_lml_batch_wait: nothing submitted");
     return BGP_ERR_STATE;
   }

@@ -65,6 +65,7 @@ extern "C" int bgp_debug_potrf_trace_w(unsigned long long* out) {
 #define PF_TW(i)
 #endif
 #include "bgp_pf.h"
+#include "bgp_mcmc.h"
 
 template <int GEN, int STAT, int FORM>
 __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ Kbuf, double* __restrict__ Wbuf,
@@ -77,6 +78,77 @@ __global__ void __launch_bounds__(PF_THREADS) potrf_kernel(double* __restrict__ 
   nopre.state = 0;
   (void)pf_block<GEN, STAT, FORM, 0>(b, Kbuf, Wbuf, yw, accb, lml, status, n, ld, mstride, ystride, nblk, k, gen, false, nullptr,
                                      PsArgs(), nopre);
+}
+
+// Device-resident ensemble sampler, n <= 128 (bgp_mcmc.hip): half-step h in ONE launch.  Workgroup i = proposal i of the half-step:
+// q = c - (c - s) z from the ensemble in HBM, its log-prior (terms summed in theta order) and canonical hyper-parameters; the Gram
+// block, its factorisation and the log-likelihood exactly as potrf_kernel<1, ...> (pf_block); then the accept test of ITS walker --
+// the only writer of that walker's row, and nobody reads a mover's row in the half-step in which it moves (partners come from the
+// other half) -- and the walker's row of the chain (a walker moves once per step: its row of step h / 2 is final here).
+template <int STAT, int FORM>
+__global__ void __launch_bounds__(PF_THREADS) mcmc_small_kernel(McmcArgs a, int h, double* __restrict__ lml, int* __restrict__ status,
+                                                               int n, PfGen gen) {
+#pragma clang fp contract(off)
+  __shared__ double sh_qv[64], sh_pt[64];
+  __shared__ double sh_prior;
+  __shared__ int sh_acc;
+  const int i = blockIdx.x, tid = threadIdx.x, p = a.p;
+  const int m = a.movers[(size_t)h * a.Ns + i], pr = a.partners[(size_t)h * a.Ns + i];
+  if (tid < p) {
+    const double z = a.zz[(size_t)h * a.Ns + i];
+    const double s = a.coords[(size_t)m * p + tid], c = a.coords[(size_t)pr * p + tid];
+    const double v = c - (c - s) * z;
+    sh_qv[tid] = v;
+    if (!(v > -INFINITY && v < INFINITY)) a.info[0] = 1u;
+    sh_pt[tid] = mcmc_prior(a.prior_kind[tid], a.prior_par + 5 * tid, v);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double lp = 0.0;
+    for (int k = 0; k < p; k++) lp += sh_pt[k];
+    sh_prior = lp;
+  }
+  if (tid < a.hp) a.dh[(size_t)i * a.hp + tid] = a.h_src[tid] >= 0 ? sh_qv[a.h_src[tid]] : a.h_fixed[tid];
+  __syncthreads();  // (the hyper-parameters are read back from memory by this workgroup only)
+  PfPre nopre;
+  nopre.state = 0;
+  (void)pf_block<1, STAT, FORM, 0>(i, nullptr, nullptr, nullptr, nullptr, lml, status, n, 128, (size_t)0, 0, 1, 0, gen, false, nullptr,
+                                   PsArgs(), nopre);
+  __syncthreads();
+  if (tid == 0) {
+    double lp = sh_prior + lml[i];
+    if (!(lp > -INFINITY && lp < INFINITY)) lp = -INFINITY;
+    const bool acc = a.factors[(size_t)h * a.Ns + i] + lp - a.logp[m] > a.logu[(size_t)h * a.Ns + i];
+    if (acc) {
+      a.logp[m] = lp;
+      a.nacc[m] += 1;
+    }
+    sh_acc = acc ? 1 : 0;
+    a.lps[(size_t)(h >> 1) * a.W + m] = acc ? lp : a.logp[m];
+  }
+  __syncthreads();
+  if (tid < p) {
+    const double v = sh_acc ? sh_qv[tid] : a.coords[(size_t)m * p + tid];
+    if (sh_acc) a.coords[(size_t)m * p + tid] = v;
+    a.chain[((size_t)(h >> 1) * a.W + m) * p + tid] = v;
+  }
+}
+
+int bgp_launch_mcmc_small(bgp_ctx* ctx, hipStream_t st, const McmcArgs& a, int h) {
+  if (a.p > 64 || a.hp > 64) {
+    bgp_set_error("bgp_launch_mcmc_small: more than 64 entries per walker");
+    return BGP_ERR_INVALID;
+  }
+  PfGen g;
+  g.X = ctx->dXeff;
+  g.alpha = ctx->dalpha;
+  g.H = ctx->dh;
+  g.y = ctx->dy;
+  g.d = ctx->d;
+  KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
+              hipLaunchKernelGGL((mcmc_small_kernel<S, F>), dim3(a.Ns), dim3(PF_THREADS), 0, st, a, h, ctx->dlml, ctx->dstatus, ctx->n, g));
+  BGP_HIP(hipGetLastError());
+  return BGP_OK;
 }
 
 // Debugging aid / accuracy test: the pivot root of the diagonal-block factorisation (pf_pivot_root) on n arguments.

@@ -350,6 +350,10 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
     return BGP_ERR_INVALID;
   }
   BGP_COMM_LIVE(c, "bgp_lml_batch_wait_allgather");
+  if (ctx->pending_B < 0) {
+    bgp_set_error("bgp_lml_batch_wait_allgather: a device-resident sampler run is open on this context");
+    return BGP_ERR_STATE;
+  }
   const int Bp = ctx->pending_B;
   ctx->pending_B = 0;  // the pending batch is consumed here whatever happens (a rank without rows has nothing pending)
   if (per_rank > ctx->max_batch || Bp > per_rank || ctx->device != c->device) {

@@ -11,48 +11,10 @@
 // prior + LML, non-finite -> -inf; accept iff (p - 1) log z + lp_new - lp_old > log u), except that exp / pow of the two
 // default prior families come from the device's libm instead of numpy's: log-probabilities agree to ~1e-15 relative, the
 // walkers' positions are identical unless an accept test is decided by that last bit.  gfx950 only.
+#include <memory>
+#include <vector>
 #include "bgp_common.h"
-
-struct McmcArgs {
-  int W, p, Ns, hp;       // walkers, entries of a walker, proposals per half-step, d + 2
-  int nhalf;              // half-steps of the run (2 x steps)
-  double* coords;         // W x p
-  double* logp;           // W
-  long long* nacc;        // W
-  double* q;              // Ns x p: proposals of the half-step in flight
-  double* prior;          // Ns
-  double* pterm;          // Ns x p: the log-prior terms of the proposals, summed in theta order by one thread per proposal
-  int* status;            // Ns: statuses of the LML batch (reset here, in front of it)
-  unsigned* ps_flags;     // flag block of the launch-free factorisation (reset here) or nullptr
-  int ps_words;
-  double* dh;             // Ns x hp: canonical hyper-parameters of the proposals (the LML batch reads them)
-  const double* lml;      // Ns: the LML batch's results
-  const int* h_src;       // hp: index into a walker, or -1: h_fixed
-  const double* h_fixed;  // hp
-  const int* prior_kind;  // p: 1 half-Normal on sqrt(exp(t)), 2 round-flat on exp(t) (both with the log-space Jacobian)
-  const double* prior_par;  // p x 5
-  const int* movers;      // nhalf x Ns   (the plan of the whole run)
-  const int* partners;    // nhalf x Ns
-  const double* zz;       // nhalf x Ns
-  const double* factors;  // nhalf x Ns
-  const double* logu;     // nhalf x Ns
-  double* chain;          // steps x W x p
-  double* lps;            // steps x W
-  unsigned* info;         // [0] a proposal had a non-finite coordinate, [1] a launch-free factorisation abandoned its waits
-  const unsigned* ps_err; // error word of the launch-free kernel of the half-step just finished, or nullptr
-};
-
-static __device__ __forceinline__ double mcmc_prior(int kind, const double* par, double t) {
-#pragma clang fp contract(off)
-  if (kind == 1) {
-    // priors.halfnorm_logpdf_logspace:  c - 0.5 * exp(t) / (scale * scale) + 0.5 * t
-    return par[0] - 0.5 * exp(t) / par[1] + 0.5 * t;
-  }
-  // utils._collect_priors.ls_prior:  (-2.0 * ((x / lo) ** p_lo + (x / hi) ** p_hi) - log_norm) + t,  x = exp(t)
-  const double x = exp(t);
-  const double a = pow(x / par[0], par[2]), b = pow(x / par[1], par[3]);
-  return (-2.0 * (a + b) - par[4]) + t;
-}
+#include "bgp_mcmc.h"
 
 // ONE workgroup.  h = index of the half-step to PROPOSE (0 .. nhalf); the accept phase closes half-step h - 1.
 __global__ void __launch_bounds__(1024) mcmc_step_kernel(McmcArgs a, int h) {
@@ -115,7 +77,7 @@ __global__ void __launch_bounds__(1024) mcmc_step_kernel(McmcArgs a, int h) {
 }
 
 namespace {
-struct DevBlock {  // one allocation for the whole run, released on every exit path
+struct DevBlock {  // one allocation for the whole run, released with it
   char* base = nullptr;
   size_t used = 0, cap = 0;
   ~DevBlock() {
@@ -130,41 +92,111 @@ struct DevBlock {  // one allocation for the whole run, released on every exit p
 };
 }  // namespace
 
-// See include/bgp.h.  nsteps steps of W walkers with p entries each; Ns = W / 2 proposals per half-step (W even).
-extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
-                            const double* prior_par, const double* coords0, const double* logp0, const int* movers,
-                            const int* partners, const double* zz, const double* factors, const double* logu, double* chain,
-                            double* logp, double* coords_out, double* logp_out, long long* naccepted, int* info) {
-  if (!c || !h_src || !h_fixed || !prior_kind || !prior_par || !coords0 || !logp0 || !movers || !partners || !zz || !factors ||
-      !logu || !chain || !logp || !coords_out || !logp_out || !naccepted || !info || W < 2 || (W & 1) || p < 1 || nsteps < 1) {
-    bgp_set_error("bgp_mcmc_run: bad argument (W must be even and >= 2)");
+// An open run (bgp_mcmc_begin .. bgp_mcmc_end): device block, kernel arguments, how far the plan has been enqueued, and host
+// copies of the start ensemble and of the plan handed over so far (a run whose launch-free factorisation timed out is redone
+// from them on the launch schedule).
+struct bgp_mcmc_state {
+  DevBlock blk;
+  McmcArgs a;
+  int nsteps = 0, threads = 256;
+  int enq_half = 0;  // half-steps enqueued so far
+  int failed = BGP_OK;
+  std::vector<double> coords0, logp0, zz, factors, logu;
+  std::vector<int> movers, partners;
+};
+
+static void mcmc_drain(bgp_ctx* c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (int g = 0; g < BGP_MAX_STREAMS; g++)
+    if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
+  bgp_xfer_drop_pending();
+  (void)hipGetLastError();
+}
+
+// bgp_ctx_destroy / a failed call: the run is dropped, whatever it had enqueued is drained
+void bgp_mcmc_abandon(bgp_ctx* c) {
+  if (!c || !c->mcmc) return;
+  mcmc_drain(c);
+  delete c->mcmc;
+  c->mcmc = nullptr;
+  c->ps_resident = 0;
+  c->ps_inflight = 0;
+  if (c->pending_B < 0) c->pending_B = 0;
+}
+
+// half-steps [h0, h1) of the plan that is on the device: the step kernel that opens each (and closes its predecessor) + its LML
+// batch; n <= 128: the fused kernel alone
+static int mcmc_enqueue(bgp_ctx* c, bgp_mcmc_state* r, int h0, int h1) {
+  McmcArgs& a = r->a;
+  hipStream_t st = c->stream;
+  int rc = BGP_OK;
+  c->ps_resident = 1;
+  if (c->nblk == 1) {  // proposal, Gram build, factorisation and accept test in ONE launch per half-step
+    for (int h = h0; h < h1 && rc == BGP_OK; h++) rc = bgp_launch_mcmc_small(c, st, a, h);
+  } else {
+    for (int h = h0; h < h1 && rc == BGP_OK; h++) {
+      hipLaunchKernelGGL(mcmc_step_kernel, dim3(1), dim3(r->threads), 0, st, a, h);
+      c->ps_inflight = 0;
+      rc = bgp_lml_enqueue_dev(c, a.Ns, 0);
+      // (the launch-free kernel's error word is reset in front of every call: the next step kernel folds it into info[1])
+      a.ps_err = (rc == BGP_OK && c->ps_inflight && c->ps_flags) ? c->ps_flags + PS_ERROR : nullptr;
+    }
+  }
+  c->ps_resident = 0;
+  c->ps_inflight = 0;
+  if (rc == BGP_OK) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      bgp_set_error("bgp_mcmc: %s", hipGetErrorString(e));
+      rc = BGP_ERR_HIP;
+    }
+  }
+  return rc;
+}
+
+static int mcmc_upload_start(bgp_ctx* c, bgp_mcmc_state* r) {
+  McmcArgs& a = r->a;
+  BGP_HIP(bgp_memcpy_async(a.coords, r->coords0.data(), r->coords0.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(bgp_memcpy_async(a.logp, r->logp0.data(), r->logp0.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  BGP_HIP(hipMemsetAsync(a.nacc, 0, (size_t)a.W * sizeof(long long), c->stream));
+  BGP_HIP(hipMemsetAsync(a.info, 0, 2 * sizeof(unsigned), c->stream));
+  a.ps_err = nullptr;
+  return BGP_OK;
+}
+
+// See include/bgp.h.
+extern "C" int bgp_mcmc_begin(bgp_ctx* c, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
+                              const double* prior_par, const double* coords0, const double* logp0) {
+  if (!c || !h_src || !h_fixed || !prior_kind || !prior_par || !coords0 || !logp0 || W < 2 || (W & 1) || p < 1 || nsteps < 1) {
+    bgp_set_error("bgp_mcmc_begin: bad argument (W must be even and >= 2)");
     return BGP_ERR_INVALID;
   }
-  BGP_REQUIRE_IDLE(c, "bgp_mcmc_run");
+  BGP_REQUIRE_IDLE(c, "bgp_mcmc_begin");
   const int Ns = W / 2, hp = c->d + 2, nhalf = 2 * nsteps;
   if (Ns > c->max_batch) {
-    bgp_set_error("bgp_mcmc_run: %d proposals per half-step exceed max_batch = %d", Ns, c->max_batch);
+    bgp_set_error("bgp_mcmc_begin: %d proposals per half-step exceed max_batch = %d", Ns, c->max_batch);
     return BGP_ERR_INVALID;
   }
   if (c->timing) {
-    bgp_set_error("bgp_mcmc_run: per-launch timing is on (bgp_set_timing): use the host-driven sampler");
+    bgp_set_error("bgp_mcmc_begin: per-launch timing is on (bgp_set_timing): use the host-driven sampler");
     return BGP_ERR_STATE;
   }
   for (int k = 0; k < p; k++)
     if (prior_kind[k] != 1 && prior_kind[k] != 2) {
-      bgp_set_error("bgp_mcmc_run: prior kind %d of entry %d is not one of the device's (1 half-Normal, 2 round-flat)", prior_kind[k], k);
+      bgp_set_error("bgp_mcmc_begin: prior kind %d of entry %d is not one of the device's (1 half-Normal, 2 round-flat)", prior_kind[k], k);
       return BGP_ERR_INVALID;
     }
   for (int j = 0; j < hp; j++)
     if (h_src[j] >= p) {
-      bgp_set_error("bgp_mcmc_run: canonical entry %d reads walker entry %d of %d", j, h_src[j], p);
+      bgp_set_error("bgp_mcmc_begin: canonical entry %d reads walker entry %d of %d", j, h_src[j], p);
       return BGP_ERR_INVALID;
     }
   BGP_HIP(hipSetDevice(c->device));
   const size_t plan = (size_t)nhalf * Ns;
-  DevBlock blk;
-  McmcArgs a;
+  std::unique_ptr<bgp_mcmc_state> r(new bgp_mcmc_state);
+  McmcArgs& a = r->a;
   for (int pass = 0; pass < 2; pass++) {  // pass 0 sizes the block, pass 1 hands out the pointers
+    DevBlock& blk = r->blk;
     blk.used = 0;
     a.coords = blk.take<double>((size_t)W * p);
     a.logp = blk.take<double>(W);
@@ -199,66 +231,108 @@ extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_s
   a.status = c->dstatus;
   a.ps_flags = nullptr;
   a.ps_words = 0;
+  a.ps_err = nullptr;
   if (c->nblk > 1 && bgp_persist_fits(c, Ns)) {  // a launch-free call may follow: its flag block is reset by the step kernel
     const int rcf = bgp_ps_ensure_flags(c, Ns);
     if (rcf) return rcf;
     a.ps_flags = c->ps_flags;
     a.ps_words = (int)ps_flag_words(Ns, c->nblk);
   }
-  const int threads = (Ns * p > 512) ? 1024 : 256;
+  r->nsteps = nsteps;
+  r->threads = (Ns * p > 512) ? 1024 : 256;
+  r->coords0.assign(coords0, coords0 + (size_t)W * p);
+  r->logp0.assign(logp0, logp0 + W);
   hipStream_t st = c->stream;
+  BGP_HIP(bgp_memcpy_async(const_cast<int*>(a.h_src), h_src, hp * sizeof(int), hipMemcpyHostToDevice, st));
+  BGP_HIP(bgp_memcpy_async(const_cast<double*>(a.h_fixed), h_fixed, hp * sizeof(double), hipMemcpyHostToDevice, st));
+  BGP_HIP(bgp_memcpy_async(const_cast<int*>(a.prior_kind), prior_kind, p * sizeof(int), hipMemcpyHostToDevice, st));
+  BGP_HIP(bgp_memcpy_async(const_cast<double*>(a.prior_par), prior_par, (size_t)5 * p * sizeof(double), hipMemcpyHostToDevice, st));
+  {
+    const int rcu = mcmc_upload_start(c, r.get());
+    if (rcu) return rcu;
+  }
+  c->mcmc = r.release();
+  c->pending_B = -1;  // (every other entry point answers "busy" until bgp_mcmc_end)
+  return BGP_OK;
+}
+
+extern "C" int bgp_mcmc_steps(bgp_ctx* c, int nseg, const int* movers, const int* partners, const double* zz, const double* factors,
+                              const double* logu) {
+  if (!c || !c->mcmc) {
+    bgp_set_error("bgp_mcmc_steps: no run is open (bgp_mcmc_begin)");
+    return BGP_ERR_STATE;
+  }
+  bgp_mcmc_state* r = c->mcmc;
+  McmcArgs& a = r->a;
+  if (nseg < 1 || !movers || !partners || !zz || !factors || !logu || r->enq_half + 2 * nseg > a.nhalf) {
+    bgp_set_error("bgp_mcmc_steps: bad argument (%d steps behind %d of %d)", nseg, r->enq_half / 2, r->nsteps);
+    return BGP_ERR_INVALID;
+  }
+  if (r->failed) return r->failed;
+  BGP_HIP(hipSetDevice(c->device));
+  const size_t cnt = (size_t)2 * nseg * a.Ns, off = (size_t)r->enq_half * a.Ns;
+  r->movers.insert(r->movers.end(), movers, movers + cnt);
+  r->partners.insert(r->partners.end(), partners, partners + cnt);
+  r->zz.insert(r->zz.end(), zz, zz + cnt);
+  r->factors.insert(r->factors.end(), factors, factors + cnt);
+  r->logu.insert(r->logu.end(), logu, logu + cnt);
+  hipStream_t st = c->stream;
+  int rc = BGP_OK;
   auto up = [&](const void* dst, const void* src, size_t bytes) {
-    return bgp_memcpy_async(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, st);
+    if (rc == BGP_OK && bgp_memcpy_async(const_cast<void*>(dst), src, bytes, hipMemcpyHostToDevice, st) != hipSuccess) rc = BGP_ERR_HIP;
   };
+  up(a.movers + off, movers, cnt * sizeof(int));
+  up(a.partners + off, partners, cnt * sizeof(int));
+  up(a.zz + off, zz, cnt * sizeof(double));
+  up(a.factors + off, factors, cnt * sizeof(double));
+  up(a.logu + off, logu, cnt * sizeof(double));
+  if (rc == BGP_OK) rc = mcmc_enqueue(c, r, r->enq_half, r->enq_half + 2 * nseg);
+  if (rc != BGP_OK) {
+    r->failed = rc;
+    mcmc_drain(c);
+    return rc;
+  }
+  r->enq_half += 2 * nseg;
+  return BGP_OK;
+}
+
+extern "C" int bgp_mcmc_end(bgp_ctx* c, double* chain, double* logp, double* coords_out, double* logp_out, long long* naccepted,
+                            int* info) {
+  if (!c || !c->mcmc) {
+    bgp_set_error("bgp_mcmc_end: no run is open (bgp_mcmc_begin)");
+    return BGP_ERR_STATE;
+  }
+  bgp_mcmc_state* r = c->mcmc;
+  McmcArgs& a = r->a;
+  struct Closer {  // the run ends here whatever happens
+    bgp_ctx* c;
+    ~Closer() { bgp_mcmc_abandon(c); }
+  } closer{c};
+  if (r->failed) return r->failed;
+  if (!chain || !logp || !coords_out || !logp_out || !naccepted || !info || r->enq_half != a.nhalf) {
+    bgp_set_error("bgp_mcmc_end: bad argument, or only %d of %d steps were handed over", r->enq_half / 2, r->nsteps);
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
   for (int attempt = 0; attempt < 2; attempt++) {
-    BGP_HIP(up(a.coords, coords0, (size_t)W * p * sizeof(double)));
-    BGP_HIP(up(a.logp, logp0, (size_t)W * sizeof(double)));
-    BGP_HIP(hipMemsetAsync(a.nacc, 0, (size_t)W * sizeof(long long), st));
-    BGP_HIP(hipMemsetAsync(a.info, 0, 2 * sizeof(unsigned), st));
-    if (attempt == 0) {
-      BGP_HIP(up(a.h_src, h_src, hp * sizeof(int)));
-      BGP_HIP(up(a.h_fixed, h_fixed, hp * sizeof(double)));
-      BGP_HIP(up(a.prior_kind, prior_kind, p * sizeof(int)));
-      BGP_HIP(up(a.prior_par, prior_par, (size_t)5 * p * sizeof(double)));
-      BGP_HIP(up(a.movers, movers, plan * sizeof(int)));
-      BGP_HIP(up(a.partners, partners, plan * sizeof(int)));
-      BGP_HIP(up(a.zz, zz, plan * sizeof(double)));
-      BGP_HIP(up(a.factors, factors, plan * sizeof(double)));
-      BGP_HIP(up(a.logu, logu, plan * sizeof(double)));
-    }
     int rc = BGP_OK;
-    c->ps_resident = 1;
-    a.ps_err = nullptr;
-    for (int h = 0; h <= nhalf && rc == BGP_OK; h++) {
-      hipLaunchKernelGGL(mcmc_step_kernel, dim3(1), dim3(threads), 0, st, a, h);
-      if (h == nhalf) break;
-      c->ps_inflight = 0;
-      rc = bgp_lml_enqueue_dev(c, Ns, 0);
-      // (the launch-free kernel's error word is reset in front of every call: the next step kernel folds it into info[1])
-      a.ps_err = (rc == BGP_OK && c->ps_inflight && c->ps_flags) ? c->ps_flags + PS_ERROR : nullptr;
+    if (attempt == 1) {  // the whole run again, on the launch schedule (the plan is on the device already)
+      rc = mcmc_upload_start(c, r);
+      if (rc == BGP_OK) rc = mcmc_enqueue(c, r, 0, a.nhalf);
     }
-    c->ps_resident = 0;
-    c->ps_inflight = 0;
+    if (rc == BGP_OK && c->nblk > 1) {  // the step kernel that closes the last half-step
+      hipLaunchKernelGGL(mcmc_step_kernel, dim3(1), dim3(r->threads), 0, st, a, a.nhalf);
+      if (hipGetLastError() != hipSuccess) rc = BGP_ERR_HIP;
+    }
     unsigned hinfo[2] = {0u, 0u};
-    if (rc == BGP_OK) {
-      const hipError_t e = hipGetLastError();
-      if (e != hipSuccess) {
-        bgp_set_error("bgp_mcmc_run: %s", hipGetErrorString(e));
-        rc = BGP_ERR_HIP;
-      }
-    }
     if (rc == BGP_OK && bgp_memcpy_async(hinfo, a.info, sizeof(hinfo), hipMemcpyDeviceToHost, st) != hipSuccess) rc = BGP_ERR_HIP;
-    if (rc != BGP_OK || bgp_stream_sync(st) != hipSuccess) {  // drain whatever was enqueued; the context stays usable
-      (void)hipStreamSynchronize(st);
-      for (int g = 0; g < BGP_MAX_STREAMS; g++)
-        if (c->gstream[g]) (void)hipStreamSynchronize(c->gstream[g]);
-      bgp_xfer_drop_pending();
-      (void)hipGetLastError();
+    if (rc != BGP_OK || bgp_stream_sync(st) != hipSuccess) {
       if (rc == BGP_OK) {
-        bgp_set_error("bgp_mcmc_run: the run failed on the device");
+        bgp_set_error("bgp_mcmc_end: the run failed on the device");
         rc = BGP_ERR_HIP;
       }
-      return rc;
+      return rc;  // (Closer drains)
     }
     if (hinfo[1] != 0 && attempt == 0) {
       // a launch-free factorisation gave its waits up somewhere in the run: everything behind it is void.  The whole run is
@@ -270,11 +344,30 @@ extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_s
     info[1] = attempt;
     break;
   }
-  BGP_HIP(bgp_memcpy_async(chain, a.chain, (size_t)nsteps * W * p * sizeof(double), hipMemcpyDeviceToHost, st));
-  BGP_HIP(bgp_memcpy_async(logp, a.lps, (size_t)nsteps * W * sizeof(double), hipMemcpyDeviceToHost, st));
-  BGP_HIP(bgp_memcpy_async(coords_out, a.coords, (size_t)W * p * sizeof(double), hipMemcpyDeviceToHost, st));
-  BGP_HIP(bgp_memcpy_async(logp_out, a.logp, (size_t)W * sizeof(double), hipMemcpyDeviceToHost, st));
-  BGP_HIP(bgp_memcpy_async(naccepted, a.nacc, (size_t)W * sizeof(long long), hipMemcpyDeviceToHost, st));
+  BGP_HIP(bgp_memcpy_async(chain, a.chain, (size_t)r->nsteps * a.W * a.p * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(bgp_memcpy_async(logp, a.lps, (size_t)r->nsteps * a.W * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(bgp_memcpy_async(coords_out, a.coords, (size_t)a.W * a.p * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(bgp_memcpy_async(logp_out, a.logp, (size_t)a.W * sizeof(double), hipMemcpyDeviceToHost, st));
+  BGP_HIP(bgp_memcpy_async(naccepted, a.nacc, (size_t)a.W * sizeof(long long), hipMemcpyDeviceToHost, st));
   BGP_HIP(bgp_stream_sync(st));
   return BGP_OK;
+}
+
+// The three calls in one: the whole plan handed over at once.
+extern "C" int bgp_mcmc_run(bgp_ctx* c, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
+                            const double* prior_par, const double* coords0, const double* logp0, const int* movers,
+                            const int* partners, const double* zz, const double* factors, const double* logu, double* chain,
+                            double* logp, double* coords_out, double* logp_out, long long* naccepted, int* info) {
+  if (!movers || !partners || !zz || !factors || !logu || !chain || !logp || !coords_out || !logp_out || !naccepted || !info) {
+    bgp_set_error("bgp_mcmc_run: NULL argument");
+    return BGP_ERR_INVALID;
+  }
+  int rc = bgp_mcmc_begin(c, W, p, nsteps, h_src, h_fixed, prior_kind, prior_par, coords0, logp0);
+  if (rc) return rc;
+  rc = bgp_mcmc_steps(c, nsteps, movers, partners, zz, factors, logu);
+  if (rc) {
+    bgp_mcmc_abandon(c);
+    return rc;
+  }
+  return bgp_mcmc_end(c, chain, logp, coords_out, logp_out, naccepted, info);
 }

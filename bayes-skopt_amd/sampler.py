@@ -110,7 +110,7 @@ class EnsembleSampler:
         rng, a = self._random, self.a
         all_inds = np.arange(self.nwalkers)
         for _ in range(nsteps):
-            rng.choice(1, p=[1.0])  # move selection among a single StretchMove
+            rng.random_sample()  # move selection among a single StretchMove: choice(1, p=[1.0]) draws exactly this one double
             inds = all_inds % 2
             rng.shuffle(inds)
             for split in (0, 1):
@@ -191,22 +191,35 @@ class EnsembleSampler:
         return State(coords, log_prob, rng.get_state())
 
     def _run_resident(self, run, coords, log_prob, nsteps):
-        """The same run with the state on the device (``bgp_mcmc_run``): every draw of the generator is made here, up
-        front, in the order ``run_mcmc``'s loop makes them -- a half-step's stretch factors and partners, its accept
-        draws, the next half-step's -- so the generator ends in the same state and the device replays the same moves."""
+        """The same run with the state on the device (``bgp_mcmc_begin`` / ``_steps`` / ``_end``): every draw of the generator
+        is made here, in the order ``run_mcmc``'s loop makes them -- a half-step's stretch factors and partners, its accept
+        draws, the next half-step's -- and handed over as the plan in growing segments, the next one drawn while the device
+        works through the last; the generator ends in the same state and the device replays the same moves."""
         rng, Ns = self._random, self.nwalkers // 2
-        nhalf = 2 * nsteps
-        movers = np.empty((nhalf, Ns), dtype=np.int32)
-        partners = np.empty((nhalf, Ns), dtype=np.int32)
-        zz, factors, logu = np.empty((nhalf, Ns)), np.empty((nhalf, Ns)), np.empty((nhalf, Ns))
-        for h, (mv, pt, z, f) in enumerate(self._half_step_plans(nsteps)):
-            movers[h], partners[h], zz[h], factors[h] = mv, pt, z[:, 0], f
-            with np.errstate(divide="ignore"):
-                logu[h] = np.log(rng.rand(Ns))
-        chain, lps, coords, log_prob, nacc, info = run(coords, log_prob, (movers, partners, zz, factors, logu))
+        plans = self._half_step_plans(nsteps)
+        run.begin(coords, log_prob, nsteps)
+        try:
+            done, seg = 0, 2
+            while done < nsteps:
+                seg = min(seg, nsteps - done)
+                movers = np.empty((2 * seg, Ns), dtype=np.int32)
+                partners = np.empty((2 * seg, Ns), dtype=np.int32)
+                zz, factors, logu = np.empty((2 * seg, Ns)), np.empty((2 * seg, Ns)), np.empty((2 * seg, Ns))
+                for h in range(2 * seg):
+                    mv, pt, z, f = next(plans)
+                    movers[h], partners[h], zz[h], factors[h] = mv, pt, z[:, 0], f
+                    with np.errstate(divide="ignore"):
+                        logu[h] = np.log(rng.rand(Ns))
+                run.steps((movers, partners, zz, factors, logu))
+                done += seg
+                seg = min(2 * seg, 64)
+        except BaseException:
+            run.abandon()
+            raise
+        chain, lps, coords, log_prob, nacc, info = run.end()
         if info[0]:
             raise ValueError("At least one parameter value was infinite")
-        self.n_log_prob_evals += nhalf * Ns
+        self.n_log_prob_evals += 2 * nsteps * Ns
         self.naccepted += nacc
         self._chain = chain if self._chain is None else np.concatenate([self._chain, chain])
         self._log_prob = lps if self._log_prob is None else np.concatenate([self._log_prob, lps])

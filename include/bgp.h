@@ -353,7 +353,17 @@ int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, int
  * factors + lp_new - lp_old > logu.  Outputs: chain (nsteps x W x p) and logp (nsteps x W) after every step, the final
  * ensemble (coords_out, logp_out), accept counts, info[0] != 0 when a proposal had a non-finite coordinate (emcee raises
  * ValueError there: the caller should), info[1] = 1 when a launch-free factorisation gave up its waits and the WHOLE run was
- * redone on the launch schedule (same bits).  Needs W / 2 <= max_batch, no pending batch, per-launch timing off. */
+ * redone on the launch schedule (same bits).  Needs W / 2 <= max_batch, no pending batch, per-launch timing off.
+ * bgp_mcmc_begin / bgp_mcmc_steps / bgp_mcmc_end are the same run with the plan handed over in segments (nseg steps = 2 nseg rows
+ * of every plan array per call, in order): bgp_mcmc_steps uploads its rows, enqueues their half-steps and returns at once, so the
+ * caller draws the next segment's random numbers while the device works through this one; bgp_mcmc_end (every step handed over)
+ * waits and collects.  Between begin and end the context belongs to the run: every other entry point answers BGP_ERR_STATE;
+ * bgp_ctx_destroy drops an open run.  bgp_mcmc_run = begin + one bgp_mcmc_steps with the whole plan + end. */
+int bgp_mcmc_begin(bgp_ctx* ctx, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
+                   const double* prior_par, const double* coords0, const double* logp0);
+int bgp_mcmc_steps(bgp_ctx* ctx, int nseg, const int* movers, const int* partners, const double* zz, const double* factors,
+                   const double* logu);
+int bgp_mcmc_end(bgp_ctx* ctx, double* chain, double* logp, double* coords_out, double* logp_out, long long* naccepted, int* info);
 int bgp_mcmc_run(bgp_ctx* ctx, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
                  const double* prior_par, const double* coords0, const double* logp0, const int* movers, const int* partners,
                  const double* zz, const double* factors, const double* logu, double* chain, double* logp, double* coords_out,

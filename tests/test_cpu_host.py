@@ -212,6 +212,83 @@ def test_sampler_matches_oracle_sampler_bitwise(bask):
     assert s2._random.rand() == s._random.rand()
 
 
+def test_resident_plan_replays_the_host_loop_bitwise(bask):
+    """The device-resident run (bgp_mcmc_run) gets every random number of the run as a plan drawn up front
+    (EnsembleSampler._run_resident).  A numpy replay of what mcmc_step_kernel does with that plan -- accept half-step h - 1,
+    propose half-step h, ensemble into the chain after the second half of a step -- must give the host loop's chain, accept
+    counts and generator end state bit for bit: the plan IS emcee's stream, in emcee's order."""
+    p = 3
+    rng = np.random.RandomState(0)
+    A = rng.randn(p, p)
+    icov = np.linalg.inv(A @ A.T + np.eye(p))
+    mu = np.array([1.0, -2.0, 0.5])
+
+    def lp_vec(Xb):
+        return np.array([-0.5 * (x - mu) @ icov @ (x - mu) for x in Xb])
+
+    class Resident:
+        asked = 0
+
+        def __call__(self, Xb):
+            return lp_vec(Xb)
+
+        def resident(self, n_walkers, n_dim):
+            Resident.asked += 1
+
+            class Run:
+                def begin(self, coords, log_prob, nsteps):
+                    self.coords, self.log_prob = np.array(coords), np.array(log_prob)
+                    self.chain, self.lps = np.empty((nsteps,) + self.coords.shape), np.empty((nsteps, len(self.coords)))
+                    self.nacc, self.h = np.zeros(len(self.coords), dtype=np.int64), 0
+                    self.segments = 0
+
+                def steps(self, plan):
+                    movers, partners, zz, factors, logu = plan
+                    self.segments += 1
+                    for r in range(movers.shape[0]):
+                        s, c = self.coords[movers[r]], self.coords[partners[r]]
+                        q = c - (c - s) * zz[r][:, None]
+                        new_lp = lp_vec(q)
+                        acc = factors[r] + new_lp - self.log_prob[movers[r]] > logu[r]
+                        idx = movers[r][acc]
+                        self.coords[idx], self.log_prob[idx] = q[acc], new_lp[acc]
+                        self.nacc[idx] += 1
+                        if self.h & 1:
+                            self.chain[self.h // 2], self.lps[self.h // 2] = self.coords, self.log_prob
+                        self.h += 1
+
+                def end(self):
+                    assert self.h == 2 * len(self.chain) and self.segments >= 3  # (handed over in growing segments)
+                    return self.chain, self.lps, self.coords, self.log_prob, self.nacc, np.zeros(2, dtype=np.int32)
+
+                def abandon(self):
+                    pass
+
+            return Run()
+
+    p0 = mu + 1e-2 * rng.randn(12, p)
+    ref = bask.sampler.EnsembleSampler(12, p, lp_vec)
+    ref.random_state = np.random.RandomState(5).get_state()
+    st0 = ref.run_mcmc(p0, 30)
+    st0 = ref.run_mcmc(st0.coords, 20, log_prob0=st0.log_prob)
+    s = bask.sampler.EnsembleSampler(12, p, Resident())
+    s.random_state = np.random.RandomState(5).get_state()
+    st = s.run_mcmc(p0, 30)
+    st = s.run_mcmc(st.coords, 20, log_prob0=st.log_prob)
+    assert Resident.asked == 2 and s.resident_runs == 2 and getattr(ref, "resident_runs", 0) == 0
+    np.testing.assert_array_equal(s.get_chain(), ref.get_chain())
+    np.testing.assert_array_equal(s.get_log_prob(), ref.get_log_prob())
+    np.testing.assert_array_equal(s.naccepted, ref.naccepted)
+    np.testing.assert_array_equal(st.coords, st0.coords)
+    assert s.iteration == ref.iteration == 50 and s.n_log_prob_evals == ref.n_log_prob_evals
+    assert s._random.rand() == ref._random.rand()
+    # a progress bar, or a log_prob_fn whose resident() declines, keeps the host loop
+    s3 = bask.sampler.EnsembleSampler(12, p, Resident())
+    s3.random_state = np.random.RandomState(5).get_state()
+    s3.run_mcmc(p0, 5, progress=True)
+    assert getattr(s3, "resident_runs", 0) == 0
+
+
 def test_sampler_preconditions(bask):
     s = bask.sampler.EnsembleSampler(4, 3, lambda X: np.zeros(len(X)))
     with pytest.raises(RuntimeError):
