@@ -1232,6 +1232,9 @@ class _AsyncLogProb:
             return None
         if callable(priors) or priors is None or gp._ctx._timing:  # (per-launch timing synchronises inside every batch)
             return None
+        Ns = n_walkers // 2
+        if n_walkers * n_dim + n_walkers + 3 * Ns + 2 * Ns * n_dim > 16384:  # (the step kernel keeps the ensemble in LDS)
+            return None
         priors = list(priors)
         if len(priors) != n_dim or any(getattr(f, "_bgp_device", None) is None for f in priors):
             return None

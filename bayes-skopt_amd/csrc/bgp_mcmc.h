@@ -37,9 +37,11 @@ static __device__ __forceinline__ double mcmc_prior(int kind, const double* par,
     // priors.halfnorm_logpdf_logspace:  c - 0.5 * exp(t) / (scale * scale) + 0.5 * t
     return par[0] - 0.5 * exp(t) / par[1] + 0.5 * t;
   }
-  // utils._collect_priors.ls_prior:  (-2.0 * ((x / lo) ** p_lo + (x / hi) ** p_hi) - log_norm) + t,  x = exp(t)
-  const double x = exp(t);
-  const double a = pow(x / par[0], par[2]), b = pow(x / par[1], par[3]);
+  // utils._collect_priors.ls_prior:  (-2.0 * ((x / lo) ** p_lo + (x / hi) ** p_hi) - log_norm) + t,  x = exp(t) -- with the powers
+  // taken in log space, (x / lo) ** p = exp(p (t - ln lo)) (par[0] = ln lo, par[1] = ln hi): three times cheaper than two pow() on
+  // the one workgroup that stands between two LML batches, and as close to the exact value as numpy's route through exp(t)
+  // (both carry ~|p| ulp: there the rounding of x is raised to the p-th power, here the rounding of the exponent)
+  const double a = exp(par[2] * (t - par[0])), b = exp(par[3] * (t - par[1]));
   return (-2.0 * (a + b) - par[4]) + t;
 }
 

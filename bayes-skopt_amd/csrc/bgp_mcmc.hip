@@ -16,21 +16,51 @@
 #include "bgp_common.h"
 #include "bgp_mcmc.h"
 
-// ONE workgroup.  h = index of the half-step to PROPOSE (0 .. nhalf); the accept phase closes half-step h - 1.
+// ONE workgroup.  h = index of the half-step to PROPOSE (0 .. nhalf); the accept phase closes half-step h - 1.  Every microsecond of
+// this kernel stands between two LML batches, so the ensemble, the accept flags, the new proposals and their prior terms live in
+// LDS (W p + W + 3 Ns + 2 Ns p doubles <= MCMC_LDS_DOUBLES: bgp_mcmc_begin checks) and the kernel is three rounds of memory latency
+// -- everything in, the old proposals of the accepted walkers, everything out -- instead of one per phase.
+#define MCMC_LDS_DOUBLES 16384  // 128 KB
 __global__ void __launch_bounds__(1024) mcmc_step_kernel(McmcArgs a, int h) {
 #pragma clang fp contract(off)
-  const int tid = threadIdx.x, nt = blockDim.x, p = a.p, Ns = a.Ns;
-  if (h > 0) {
-    const int g = h - 1;
-    const int* mv = a.movers + (size_t)g * Ns;
-    if (tid == 0 && a.ps_err && *a.ps_err != 0) a.info[1] = 1u;
-    for (int i = tid; i < Ns; i += nt) {
+  __shared__ double lds[MCMC_LDS_DOUBLES];
+  const int tid = threadIdx.x, nt = blockDim.x, p = a.p, Ns = a.Ns, W = a.W;
+  double* const co = lds;                  // the ensemble
+  double* const lg = co + (size_t)W * p;   // its log-probabilities
+  double* const af = lg + W;               // accept flags of half-step h - 1
+  double* const qn = af + Ns;              // proposals of half-step h
+  double* const pt = qn + (size_t)Ns * p;  // their log-prior terms
+  double* const tf = pt + (size_t)Ns * p;  // accept test of half-step h - 1: (p - 1) log z ...
+  double* const tu = tf + Ns;              // ... and log u
+  for (int e = tid; e < W * p; e += nt) co[e] = a.coords[e];
+  for (int e = tid; e < W; e += nt) lg[e] = a.logp[e];
+  // the resets the LML batch would otherwise enqueue as dispatches of their own (the previous batch, and with it every reader
+  // of these words, is over: this kernel runs behind it on the stream); the previous launch-free call's error word first
+  if (tid == 0 && h > 0 && a.ps_err && *a.ps_err != 0) a.info[1] = 1u;
+  const int g = h - 1;
+  const int* const mvg = a.movers + (size_t)(g > 0 ? g : 0) * Ns;
+  if (h > 0)
+    for (int i = tid; i < Ns; i += nt) {  // (the accept test's operands are requested with the ensemble)
       double lp = a.prior[i] + a.lml[i];
       if (!(lp > -INFINITY && lp < INFINITY)) lp = -INFINITY;  // (NaN included, as _log_prob_finish)
-      const int m = mv[i];
-      const bool acc = a.factors[(size_t)g * Ns + i] + lp - a.logp[m] > a.logu[(size_t)g * Ns + i];
-      a.status[i] = acc ? -1 : 0;  // (the batch is over: its status words carry the accept flags to the copy below)
+      af[i] = lp;  // (replaced by the accept flag below, by the same thread)
+      tf[i] = a.factors[(size_t)g * Ns + i];
+      tu[i] = a.logu[(size_t)g * Ns + i];
+    }
+  __syncthreads();
+  if (h < a.nhalf) {
+    if (a.ps_flags)
+      for (int e = tid; e < a.ps_words; e += nt) a.ps_flags[e] = 0u;
+    for (int e = tid; e < Ns; e += nt) a.status[e] = 0;
+  }
+  if (h > 0) {
+    for (int i = tid; i < Ns; i += nt) {
+      const int m = mvg[i];
+      const double lp = af[i];
+      const bool acc = tf[i] + lp - lg[m] > tu[i];
+      af[i] = acc ? 1.0 : 0.0;
       if (acc) {
+        lg[m] = lp;
         a.logp[m] = lp;
         a.nacc[m] += 1;
       }
@@ -38,41 +68,41 @@ __global__ void __launch_bounds__(1024) mcmc_step_kernel(McmcArgs a, int h) {
     __syncthreads();
     for (int e = tid; e < Ns * p; e += nt) {
       const int i = e / p;
-      if (a.status[i]) a.coords[(size_t)mv[i] * p + (e - i * p)] = a.q[e];
+      if (af[i] != 0.0) {
+        const double v = a.q[e];
+        co[(size_t)mvg[i] * p + (e - i * p)] = v;
+        a.coords[(size_t)mvg[i] * p + (e - i * p)] = v;
+      }
     }
     __syncthreads();
     if (g & 1) {  // second half of step g / 2: the ensemble goes into the chain
       const int step = g >> 1;
-      for (int e = tid; e < a.W * p; e += nt) a.chain[(size_t)step * a.W * p + e] = a.coords[e];
-      for (int e = tid; e < a.W; e += nt) a.lps[(size_t)step * a.W + e] = a.logp[e];
+      for (int e = tid; e < W * p; e += nt) a.chain[(size_t)step * W * p + e] = co[e];
+      for (int e = tid; e < W; e += nt) a.lps[(size_t)step * W + e] = lg[e];
     }
   }
   if (h >= a.nhalf) return;
-  // the resets the LML batch would otherwise enqueue as dispatches of their own (the previous batch, and with it every reader
-  // of these words, is over: this kernel runs behind it on the stream)
-  for (int e = tid; e < Ns; e += nt) a.status[e] = 0;
-  if (a.ps_flags)
-    for (int e = tid; e < a.ps_words; e += nt) a.ps_flags[e] = 0u;
   const int* mv = a.movers + (size_t)h * Ns;
   const int* pr = a.partners + (size_t)h * Ns;
   for (int e = tid; e < Ns * p; e += nt) {
     const int i = e / p, k = e - i * p;
     const double z = a.zz[(size_t)h * Ns + i];
-    const double s = a.coords[(size_t)mv[i] * p + k], c = a.coords[(size_t)pr[i] * p + k];
+    const double s = co[(size_t)mv[i] * p + k], c = co[(size_t)pr[i] * p + k];
     const double v = c - (c - s) * z;
+    qn[e] = v;
     a.q[e] = v;
     if (!(v > -INFINITY && v < INFINITY)) a.info[0] = 1u;
-    a.pterm[e] = mcmc_prior(a.prior_kind[k], a.prior_par + 5 * k, v);
+    pt[e] = mcmc_prior(a.prior_kind[k], a.prior_par + 5 * k, v);
   }
   __syncthreads();
   for (int i = tid; i < Ns; i += nt) {
     double lp = 0.0;
-    for (int k = 0; k < p; k++) lp += a.pterm[(size_t)i * p + k];
+    for (int k = 0; k < p; k++) lp += pt[(size_t)i * p + k];
     a.prior[i] = lp;
   }
   for (int e = tid; e < Ns * a.hp; e += nt) {
     const int i = e / a.hp, j = e - i * a.hp;
-    a.dh[e] = a.h_src[j] >= 0 ? a.q[(size_t)i * p + a.h_src[j]] : a.h_fixed[j];
+    a.dh[e] = a.h_src[j] >= 0 ? qn[(size_t)i * p + a.h_src[j]] : a.h_fixed[j];
   }
 }
 
@@ -177,6 +207,10 @@ extern "C" int bgp_mcmc_begin(bgp_ctx* c, int W, int p, int nsteps, const int* h
     bgp_set_error("bgp_mcmc_begin: %d proposals per half-step exceed max_batch = %d", Ns, c->max_batch);
     return BGP_ERR_INVALID;
   }
+  if (c->nblk > 1 && (size_t)W * p + W + (size_t)3 * Ns + (size_t)2 * Ns * p > MCMC_LDS_DOUBLES) {
+    bgp_set_error("bgp_mcmc_begin: an ensemble of %d walkers x %d entries does not fit the step kernel's LDS", W, p);
+    return BGP_ERR_INVALID;
+  }
   if (c->timing) {
     bgp_set_error("bgp_mcmc_begin: per-launch timing is on (bgp_set_timing): use the host-driven sampler");
     return BGP_ERR_STATE;
@@ -239,7 +273,7 @@ extern "C" int bgp_mcmc_begin(bgp_ctx* c, int W, int p, int nsteps, const int* h
     a.ps_words = (int)ps_flag_words(Ns, c->nblk);
   }
   r->nsteps = nsteps;
-  r->threads = (Ns * p > 512) ? 1024 : 256;
+  r->threads = 1024;  // (one pass over the (proposal, entry) pairs of every ensemble the reference's defaults produce)
   r->coords0.assign(coords0, coords0 + (size_t)W * p);
   r->logp0.assign(logp0, logp0 + W);
   hipStream_t st = c->stream;

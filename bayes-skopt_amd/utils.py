@@ -1,6 +1,7 @@
 """Host helpers mirroring ``bask/utils.py``: chain summary (geometric median), default priors,
 default kernel, input validation."""
 import collections.abc
+import math
 
 import numpy as np
 
@@ -74,7 +75,8 @@ def _collect_priors(kernel, out):
                     out_ = _rf(np.exp(t)) + t
                 return float(out_) if np.ndim(out_) == 0 else out_
 
-            ls_prior._bgp_device = (2, roundflat._bgp_roundflat)  # include/bgp.h bgp_mcmc_run, prior_kind 2
+            _lo, _hi, _plo, _phi, _ln = roundflat._bgp_roundflat
+            ls_prior._bgp_device = (2, (math.log(_lo), math.log(_hi), _plo, _phi, _ln))  # include/bgp.h bgp_mcmc_run, prior_kind 2
             out.extend([ls_prior] * count)
         else:
             raise NotImplementedError(f"Unable to guess priors for this kernel: {kernel}.")

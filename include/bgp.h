@@ -348,7 +348,8 @@ int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, int
  * the accept draws).  A proposal is q = c - (c - s) z (s = coords[mover], c = coords[partner]); its canonical hyper-parameters
  * are h[j] = h_src[j] >= 0 ? q[h_src[j]] : h_fixed[j] (j < d + 2); its log-prior is the sum over the p entries, in order, of
  *   prior_kind 1:  par[0] - 0.5 exp(t) / par[1] + 0.5 t                      (half-Normal on sqrt(exp t), bask/utils.py:95-99)
- *   prior_kind 2:  (-2 ((e^t / par[0])^par[2] + (e^t / par[1])^par[3]) - par[4]) + t   (round-flat on exp t, bask/priors.py:7-57)
+ *   prior_kind 2:  (-2 (exp(par[2] (t - par[0])) + exp(par[3] (t - par[1]))) - par[4]) + t   (round-flat on exp t, bask/priors.py:7-57:
+ *                  -2 ((x / lo)^p_lo + (x / hi)^p_hi) - log_norm with par = (ln lo, ln hi, p_lo, p_hi, log_norm))
  * (prior_par: p x 5); log-probability = log-prior + LML, non-finite -> -inf (bask/bayesgpr.py:351-379); accept iff
  * factors + lp_new - lp_old > logu.  Outputs: chain (nsteps x W x p) and logp (nsteps x W) after every step, the final
  * ensemble (coords_out, logp_out), accept counts, info[0] != 0 when a proposal had a non-finite coordinate (emcee raises
