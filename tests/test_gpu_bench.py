@@ -72,11 +72,14 @@ def test_bench_single_gpu_line():
     assert "10100 evaluations" in ca["workload"] and ca["fit_plus_sample_evals"] == 10100 and ca["evals_per_s"] > 1.0e5
     assert ca["cpu_baseline"]["kind"] == "reference" and ca["cpu_baseline"]["cores"] == 1 and "10100" in ca["cpu_baseline"]["sample"]
     assert ca["speedup_vs_cpu"] > 1.0 and ca["cpu_baseline"]["sample_ms"] > ca["sample_ms"]
+    # both small configurations run with the sampler's state resident on the device; the host-driven loop is timed beside it
+    assert ca["sampler"].startswith("device-resident") and ca["host_driven_ms_per_half_step"] > 0
     cb = d["config_B"]  # as stated: 500 steps, with the wall clock of a whole fit() and the reference's per-walker call beside it
     assert "500 timed MCMC steps" in cb["workload"] and cb["fit_plus_sample_evals"] == 64 * 501
     assert cb["evals_per_s"] > 2.0e4 and 0.1 < cb["acceptance_fraction"] < 0.9 and cb["fit_plus_sample_ms"] > 0
     assert all(r_["evals"] >= 32 for r_ in cb["cpu_baseline"]["runs"].values()) and cb["speedup_vs_cpu"] > 50
     assert 0.05 < cb["end_to_end"]["frac"] < 1.0 and cb["launch_free_timeouts"] == 0
+    assert cb["sampler"].startswith("device-resident") and cb["host_driven_ms_per_half_step"] > 0.9 * cb["ms_per_half_step"]
     ce = d["config_E"]
     assert ce["n_iters"] == 50 and ce["pvrs"]["n_final"] == 1024 and ce["ei128"]["n_final"] == 1024
     assert 0 < ce["pvrs"]["median_ms_per_tell"] < 500 and 0 < ce["ei128"]["median_ms_per_tell"] < 500
