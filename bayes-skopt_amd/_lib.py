@@ -75,6 +75,9 @@ SIGNATURES = {
     "bgp_predict_batch_gram": (C.c_int, [_vp, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     "bgp_comm_abort": (C.c_int, [_vp]),
     "bgp_mcmc_begin": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp]),
+    "bgp_mcmc_begin_ex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp]),
+    "bgp_mcmc_progress": (C.c_int, [_vp, _ip]),
+    "bgp_comm_init_loopback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(_vp)]),
     "bgp_mcmc_steps": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp, _dp, _dp]),
     "bgp_mcmc_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.POINTER(C.c_longlong), _ip]),
     "bgp_mcmc_run": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp,
@@ -241,9 +244,11 @@ class Context:
         self._pending, self._pending_H = H.shape[0], H  # (H stays alive until the upload has certainly happened)
         return True
 
-    def mcmc_begin(self, coords, logp, nsteps, h_src, h_fixed, prior_kind, prior_par):
-        """``bgp_mcmc_begin``: open a device-resident run of the ensemble sampler (``nsteps`` steps of the (W, p) ensemble
-        ``coords`` with log-probabilities ``logp``); the plan follows in segments through ``mcmc_steps``, ``mcmc_end`` collects."""
+    def mcmc_begin(self, coords, logp, nsteps, h_src, h_fixed, prior_kind, prior_par, comm=None, nwarp=0):
+        """``bgp_mcmc_begin_ex``: open a device-resident run of the ensemble sampler (``nsteps`` steps of the (W, p) ensemble
+        ``coords`` with log-probabilities ``logp``); the plan follows in segments through ``mcmc_steps``, ``mcmc_end`` collects.
+        ``comm``: a ``Comm`` whose ranks share every half-step's proposal block (the sharded ensemble; every rank calls with the
+        same arguments); ``nwarp`` = 2 d: the walkers' last 2 d entries are their own input-warp parameters."""
         coords = _c(np.asarray(coords, dtype=np.float64))
         W, p = coords.shape
         logp = _c(np.asarray(logp, dtype=np.float64))
@@ -253,9 +258,15 @@ class Context:
         prior_par = _c(np.asarray(prior_par, dtype=np.float64))
         if h_src.shape != (self.d + 2,) or h_fixed.shape != (self.d + 2,) or prior_kind.shape != (p,) or prior_par.shape != (p, 5):
             raise ValueError("canonical map / prior tables have the wrong shape")
-        _check(self._lib.bgp_mcmc_begin(self._h, W, p, int(nsteps), _p(h_src), _p(h_fixed), _p(prior_kind), _p(prior_par), _p(coords),
-                                        _p(logp)), "bgp_mcmc_begin")
+        _check(self._lib.bgp_mcmc_begin_ex(self._h, comm._h if comm is not None else None, int(nwarp), W, p, int(nsteps), _p(h_src),
+                                           _p(h_fixed), _p(prior_kind), _p(prior_par), _p(coords), _p(logp)), "bgp_mcmc_begin")
         self._mcmc = (W, p, int(nsteps))
+
+    def mcmc_progress(self):
+        """Steps of the open run the device has worked through (``bgp_mcmc_progress``; never blocks)."""
+        v = C.c_int(0)
+        _check(self._lib.bgp_mcmc_progress(self._h, C.byref(v)), "bgp_mcmc_progress")
+        return int(v.value)
 
     def mcmc_steps(self, plan):
         """``bgp_mcmc_steps``: hand over the next segment of the plan -- (movers, partners, zz, factors, logu), each
@@ -283,22 +294,22 @@ class Context:
 
     def mcmc_end(self):
         """``bgp_mcmc_end``: wait for the run and collect chain (nsteps, W, p), logp (nsteps, W), the final ensemble and its
-        log-probabilities, accept counts (W,) and the two info words (non-finite proposal seen; run redone on the launch
-        schedule)."""
+        log-probabilities, accept counts (W,) and the four info words (non-finite proposal seen; run redone on the launch
+        schedule; half-step of the first non-finite proposal; whether it was a NaN)."""
         W, p, nsteps = self._mcmc
         self._mcmc = None
         chain = np.empty((nsteps, W, p))
         lps = np.empty((nsteps, W))
         cout, lout = np.empty((W, p)), np.empty(W)
         nacc = np.zeros(W, dtype=np.int64)
-        info = np.zeros(2, dtype=np.int32)
+        info = np.zeros(4, dtype=np.int32)
         _check(self._lib.bgp_mcmc_end(self._h, _p(chain), _p(lps), _p(cout), _p(lout), nacc.ctypes.data_as(C.POINTER(C.c_longlong)),
                                       _p(info)), "bgp_mcmc_end")
         return chain, lps, cout, lout, nacc, info
 
-    def mcmc_run(self, coords, logp, plan, h_src, h_fixed, prior_kind, prior_par):
+    def mcmc_run(self, coords, logp, plan, h_src, h_fixed, prior_kind, prior_par, comm=None, nwarp=0):
         """``bgp_mcmc_run``: the same run with the whole plan handed over at once."""
-        self.mcmc_begin(coords, logp, np.asarray(plan[0]).shape[0] // 2, h_src, h_fixed, prior_kind, prior_par)
+        self.mcmc_begin(coords, logp, np.asarray(plan[0]).shape[0] // 2, h_src, h_fixed, prior_kind, prior_par, comm=comm, nwarp=nwarp)
         self.mcmc_steps(plan)
         return self.mcmc_end()
 
@@ -628,6 +639,18 @@ class Comm:
         buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         _check(self._lib.bgp_comm_init(int(device), self.rank, self.world, C.cast(buf, _vp), C.byref(h)), "bgp_comm_init")
         self._h = h
+
+    @classmethod
+    def loopback(cls, device, rank, world, key):
+        """Loop-back communicator (``bgp_comm_init_loopback``): rank ``rank`` of ``world`` communicators of THIS process on one
+        device, one per host thread; serves the in-stream exchange of a sharded resident sampler run only (tests)."""
+        self = cls.__new__(cls)
+        self._lib = load()
+        self.rank, self.world = int(rank), int(world)
+        h = _vp()
+        _check(self._lib.bgp_comm_init_loopback(int(device), self.rank, self.world, int(key), C.byref(h)), "bgp_comm_init_loopback")
+        self._h = h
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

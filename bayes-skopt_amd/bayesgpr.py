@@ -56,10 +56,12 @@ class BayesGPR(RegressorMixin, BaseEstimator):
       ``"cholesky"`` beyond.  The generator is consumed identically in both modes.
 
     ``resident_sampler`` (default True): ``sample`` / ``fit`` run the ensemble sampler with its walkers, proposals,
-    log-priors, accept tests and chain resident on the device (``bgp_mcmc_run``: no transfer between the first and the
-    last half-step) whenever the priors are ``guess_priors``' two families, the kernel has a canonical device form, the
-    inputs are not warped and the ensemble is not sharded; the same moves as the host-driven loop, log-probabilities
-    equal to ~1e-15 relative (the device's exp / pow in the priors instead of numpy's).
+    log-priors, accept tests and chain resident on the device (``bgp_mcmc_begin_ex`` / ``_steps`` / ``_end``: no transfer
+    between the first and the last half-step) whenever the kernel has a canonical device form and every prior is one of
+    ``guess_priors``' two families or a frozen ``scipy.stats.norm`` (the default warp priors) -- with or without a progress
+    bar, warped inputs, or an ensemble sharded over an RCCL group; the same moves as the host-driven loop, log-probabilities
+    equal to ~1e-15 relative (the device's exp in the priors instead of numpy's).  A run that has to be driven from the
+    host (custom priors, an odd ensemble, a generic kernel tree, a gloo group) says so once on stderr.
     """
 
     MVN_REFERENCE_MAX_POINTS = 512
@@ -238,6 +240,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             return float(lml[0]) if single else lml
         X = self.X_train_
         vals, grads = np.empty(len(T)), np.empty((len(T), T.shape[1]))
+        self._gram_resident = None  # (posterior_gram below overwrites the device-resident K^-1 / alpha of theta)
         for i, t in enumerate(T):
             K, Kg = self._kernel_at(t)(X, eval_gradient=True)
             res = self._ctx.posterior_gram(K, want_alpha=True, want_K_inv=True)
@@ -1197,6 +1200,20 @@ class _ShardedLogProb:
         lp[~np.isfinite(lp)] = -np.inf
         return lp
 
+    def resident(self, n_walkers, n_dim, priors=None, warp_priors=None):
+        """The sharded ensemble's run resident on every rank's device (``bgp_mcmc_begin_ex`` with the group's communicator):
+        the step kernel replicated, each rank's rows of a half-step factorised on its GPU, the all-gather of the
+        log-likelihoods ON THE STREAM between the batch and the next step kernel -- no host synchronisation per half-step
+        (``bask/bayesgpr.py:510-530`` on G GPUs).  Over gloo (CPU tests, ranks sharing a GPU) the host-driven exchange stays."""
+        if distributed.backend() is None:
+            run, self.resident_reason = _resident_run(self._gp, n_walkers, n_dim, priors, warp_priors, None)
+            return run
+        if distributed.backend() != "rccl":
+            run, self.resident_reason = None, "the process group is a gloo group: the exchange goes through the host"
+            return run
+        run, self.resident_reason = _resident_run(self._gp, n_walkers, n_dim, priors, warp_priors, distributed.communicator())
+        return run
+
     @staticmethod
     def _gather(ctx, B, local, failure):
         try:
@@ -1225,43 +1242,89 @@ class _AsyncLogProb:
 
     def resident(self, n_walkers, n_dim, priors=None, warp_priors=None):
         """The sampler asks: can the whole run stay on the device (``bgp_mcmc_begin`` / ``_steps`` / ``_end``)?  An object
-        with begin(coords, log_prob, nsteps) / steps(plan segment) / end() / abandon() when it can -- an even number of walkers, a kernel with a canonical device form, no input warp,
-        every prior one of the two families ``guess_priors`` hands out -- else None (the host-driven loop runs)."""
-        gp = self._gp
-        if not getattr(gp, "resident_sampler", True) or gp.warp_inputs or gp._generic or n_walkers % 2 or n_walkers // 2 > gp._ctx.max_batch:
-            return None
-        if callable(priors) or priors is None or gp._ctx._timing:  # (per-launch timing synchronises inside every batch)
-            return None
-        Ns = n_walkers // 2
-        if n_walkers * n_dim + n_walkers + 3 * Ns + 2 * Ns * n_dim > 16384:  # (the step kernel keeps the ensemble in LDS)
-            return None
-        priors = list(priors)
-        if len(priors) != n_dim or any(getattr(f, "_bgp_device", None) is None for f in priors):
-            return None
-        d = gp._X_train_.shape[1]
-        try:  # the canonical map as an index table: probe it with the positions themselves
-            probe = gp._canonical(np.arange(n_dim, dtype=np.float64)[None, :] + 0.25)[0]
-            fixed = gp._canonical(np.arange(n_dim, dtype=np.float64)[None, :] + 0.75)[0]
-        except Exception:
-            return None
-        src = np.where(probe != fixed, np.floor(probe).astype(np.int64), -1)
-        if probe.shape != (d + 2,) or np.any(src >= n_dim):
-            return None
-        kind = np.array([f._bgp_device[0] for f in priors], dtype=np.int32)
-        par = np.array([f._bgp_device[1] for f in priors], dtype=np.float64)
-        ctx = gp._ctx
-        h_fixed = np.where(src < 0, probe, 0.0)
+        with begin(coords, log_prob, nsteps) / steps(plan segment) / progress() / end() / abandon() when it can, else None with
+        the reason in ``resident_reason`` (the host-driven loop runs and says so once)."""
+        run, self.resident_reason = _resident_run(self._gp, n_walkers, n_dim, priors, warp_priors, None)
+        return run
 
-        class _Run:  # (the sampler hands the plan over in segments and draws the next one while the device works)
-            @staticmethod
-            def begin(coords, log_prob, nsteps):
-                ctx.mcmc_begin(coords, log_prob, nsteps, src, h_fixed, kind, par)
 
-            steps = staticmethod(ctx.mcmc_steps)
-            end = staticmethod(ctx.mcmc_end)
-            abandon = staticmethod(ctx.mcmc_abandon)
+def _device_prior(fn):
+    """(kind, five parameters) of a log-prior the step kernel of the resident sampler can evaluate (``include/bgp.h``,
+    ``bgp_mcmc_begin_ex``), or None: the two families ``guess_priors`` hands out carry theirs (``_bgp_device``); a frozen
+    ``scipy.stats.norm(loc, scale).logpdf`` -- the reference's default warp priors, ``bask/bayesgpr.py:463-466`` -- is kind 3."""
+    dev = getattr(fn, "_bgp_device", None)
+    if dev is not None:
+        return dev
+    frozen = getattr(fn, "__self__", None)
+    dist = getattr(frozen, "dist", None)
+    if getattr(fn, "__name__", "") != "logpdf" or getattr(dist, "name", None) != "norm":
+        return None
+    try:
+        args, loc, scale = dist._parse_args(*frozen.args, **frozen.kwds)
+        loc, scale = float(loc), float(scale)
+    except Exception:
+        return None
+    if args or not (np.isfinite(loc) and np.isfinite(scale) and scale > 0.0):
+        return None
+    # scipy: x = (t - loc) / scale;  -x**2 / 2.0 - log(sqrt(2 pi)) - log(scale), with numpy's constants
+    return 3, (loc, scale, float(np.log(np.sqrt(2 * np.pi))), float(np.log(np.asarray(scale))), 0.0)
 
-        return _Run
+
+def _resident_run(gp, n_walkers, n_dim, priors, warp_priors, comm):
+    """(run object, None) when the ensemble sampler's whole run can stay on the device, (None, reason) otherwise.
+    ``comm``: the communicator of a sharded ensemble (every rank decides from the same facts: the same answer everywhere)."""
+    if not getattr(gp, "resident_sampler", True):
+        return None, None  # (asked for: not a fallback)
+    if gp._generic:
+        return None, "the kernel tree has no canonical device form: its matrices are evaluated on the host"
+    if n_walkers % 2:
+        return None, "an odd number of walkers: the two halves of a step differ in size"
+    ctx = gp._ctx
+    if ctx._timing:
+        return None, "per-launch timing is on"
+    Ns = n_walkers // 2
+    world = comm.world if comm is not None else 1
+    if -(-Ns // world) > ctx.max_batch:
+        return None, "a half-step's proposals exceed max_batch"
+    if callable(priors) or priors is None:
+        return None, "the prior is one callable of the whole parameter vector"
+    priors = list(priors)
+    d = gp._X_train_.shape[1]
+    nwarp = 2 * d if gp.warp_inputs else 0
+    n_theta = n_dim - nwarp
+    if len(priors) != n_theta:
+        return None, "the number of priors differs from the number of kernel hyper-parameters"
+    table = [_device_prior(f) for f in priors]
+    if nwarp:
+        if not isinstance(warp_priors, (list, tuple)) or len(warp_priors) != 2:
+            return None, "the warp prior is one callable of (alpha, beta)"
+        wa, wb = _device_prior(warp_priors[0]), _device_prior(warp_priors[1])
+        table += [wa] * d + [wb] * d
+    if any(t is None for t in table):
+        return None, "a prior is not one of the families the device evaluates (guess_priors' two, scipy.stats.norm)"
+    try:  # the canonical map as an index table: probe it with the positions themselves
+        probe = gp._canonical(np.arange(n_theta, dtype=np.float64)[None, :] + 0.25)[0]
+        fixed = gp._canonical(np.arange(n_theta, dtype=np.float64)[None, :] + 0.75)[0]
+    except Exception:
+        return None, "the kernel's hyper-parameters do not map onto the canonical vector entry by entry"
+    src = np.where(probe != fixed, np.floor(probe).astype(np.int64), -1)
+    if probe.shape != (d + 2,) or np.any(src >= n_theta):
+        return None, "the kernel's hyper-parameters do not map onto the canonical vector entry by entry"
+    kind = np.array([t[0] for t in table], dtype=np.int32)
+    par = np.array([t[1] for t in table], dtype=np.float64)
+    h_fixed = np.where(src < 0, probe, 0.0)
+
+    class _Run:  # (the sampler hands the plan over in segments and draws the next one while the device works)
+        @staticmethod
+        def begin(coords, log_prob, nsteps):
+            ctx.mcmc_begin(coords, log_prob, nsteps, src, h_fixed, kind, par, comm=comm, nwarp=nwarp)
+
+        steps = staticmethod(ctx.mcmc_steps)
+        progress = staticmethod(ctx.mcmc_progress)
+        end = staticmethod(ctx.mcmc_end)
+        abandon = staticmethod(ctx.mcmc_abandon)
+
+    return _Run, None
 
 
 def _vec_call(fn, col):

@@ -556,7 +556,7 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
   const bool fused_small = c->nblk == 1 && !warp;
   // launch-free path (bgp_chol.hip, ps_chain_kernel): automatic below 64 matrices per call when the matrices have at
   // least two block columns; never under per-launch timing (there are no launches to time) or after a timeout
-  const bool use_ps = !fused_small && !c->timing && bgp_persist_fits(c, nb) &&
+  const bool use_ps = !fused_small && !c->timing && !c->ps_forbid && bgp_persist_fits(c, nb) &&
                       (c->persist == 1 || (c->persist == -1 && bgp_persist_auto(c, nb))) && bgp_ps_allowed(c);
   if (use_ps) c->ps_calls++;
   // (ps_resident: the sampler's step kernel has reset the statuses in front of this batch)
@@ -605,21 +605,27 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
   return BGP_OK;
 }
 
+// per-walker warped inputs (max_batch x n x d) and warp parameters (max_batch x 2 d) of a warped LML batch
+int bgp_ensure_warp_buffers(bgp_ctx* c) {
+  const size_t need = (size_t)c->max_batch * c->n * c->d;
+  if (need > c->cap_xwb) {
+    free_dev(c->dXwB);
+    c->dXwB = nullptr;
+    c->cap_xwb = 0;
+    BGP_HIP(hipMalloc(&c->dXwB, need * sizeof(double)));
+    c->cap_xwb = need;
+  }
+  if (!c->dwarpB) BGP_HIP(hipMalloc(&c->dwarpB, (size_t)c->max_batch * 2 * c->d * sizeof(double)));
+  return BGP_OK;
+}
+
 static int lml_batch_run(bgp_ctx* c, int B, const double* h, const double* warp, double* lml, int* status,
                          hipEvent_t& e0, hipEvent_t& e1, int defer_sync = 0) {
   if (B == 0) return BGP_OK;
   BGP_HIP(hipSetDevice(c->device));
-  const size_t nd = (size_t)c->n * c->d;
   if (warp) {
-    const size_t need = (size_t)c->max_batch * nd;
-    if (need > c->cap_xwb) {
-      free_dev(c->dXwB);
-      c->dXwB = nullptr;
-      c->cap_xwb = 0;
-      BGP_HIP(hipMalloc(&c->dXwB, need * sizeof(double)));
-      c->cap_xwb = need;
-    }
-    if (!c->dwarpB) BGP_HIP(hipMalloc(&c->dwarpB, (size_t)c->max_batch * 2 * c->d * sizeof(double)));
+    const int rcw = bgp_ensure_warp_buffers(c);
+    if (rcw) return rcw;
   }
   const size_t p = c->d + 2;
   for (int k = 0; k < 6; k++) c->t_ms[k] = 0.0;

@@ -99,7 +99,14 @@ __global__ void __launch_bounds__(PF_THREADS) mcmc_small_kernel(McmcArgs a, int 
     const double s = a.coords[(size_t)m * p + tid], c = a.coords[(size_t)pr * p + tid];
     const double v = c - (c - s) * z;
     sh_qv[tid] = v;
-    if (!(v > -INFINITY && v < INFINITY)) a.info[0] = 1u;
+    if (!(v > -INFINITY && v < INFINITY)) {
+      a.info[0] = 1u;
+      if (v != v) {
+        if (a.info[3] == 0u) a.info[3] = (unsigned)h + 1u;
+      } else if (a.info[2] == 0u) {
+        a.info[2] = (unsigned)h + 1u;
+      }
+    }
     sh_pt[tid] = mcmc_prior(a.prior_kind[tid], a.prior_par + 5 * tid, v);
   }
   __syncthreads();

@@ -11,10 +11,15 @@
 // out of every rank's context (no host staging on the send side): the per-half-step exchange of the exact
 // single-ensemble sharding.
 #include "bgp_common.h"
+#include "bgp_mcmc.h"
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <condition_variable>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <rccl/rccl.h>
 #include <unistd.h>
 
@@ -66,7 +71,29 @@ int load_rccl() {
 }
 }  // namespace
 
+// Loop-back group: `world` communicators of ONE process on ONE device (one per host thread, each beside its own context) that
+// exchange through device memory they all see.  It exists for the tests of the sharded sampler's row logic on a single GPU
+// (two "ranks" = two contexts driven by two threads); only the in-stream gather of bgp_comm_enqueue_lml_gather is served.
+// Per half-step: every rank copies its slot into the shared buffer of the round's parity on ITS stream and records its event;
+// the threads meet (host barrier: an event can only be waited for once it has been recorded); every rank makes its stream
+// wait for all events and copies the shared buffer into its own receive buffer.  Two parities suffice: a rank's write of round
+// g + 2 sits behind its wait for the peers' events of round g + 1, which sit behind the peers' reads of round g.
+struct LoopGroup {
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 0, members = 0, arrived = 0, aborted = 0;
+  unsigned long long generation = 0;
+  double* dshared[2] = {nullptr, nullptr};  // 2 x world x LOOP_SLOT doubles
+  std::vector<hipEvent_t> ev[2];            // per parity: one event per rank
+  std::vector<unsigned long long> round;    // per rank: rounds enqueued
+};
+#define LOOP_SLOT (4096 + 1)
+static std::mutex g_loop_mu;
+static std::map<long long, LoopGroup*> g_loops;
+
 struct bgp_comm {
+  LoopGroup* loop = nullptr;  // loop-back communicator (no RCCL behind it)
+  long long loop_key = 0;
   int device = 0, rank = 0, world = 1;
   ncclComm_t comm = nullptr;
   hipStream_t stream = nullptr;
@@ -153,6 +180,13 @@ static int comm_download(bgp_comm* c, double* host, size_t count, const char* wh
     }                                                                                           \
   } while (0)
 
+#define BGP_COMM_LIVE_OR_LOOP(c, who)                                                           \
+  do {                                                                                          \
+    if ((c)->aborted || (!(c)->comm && !(c)->loop)) {                                           \
+      bgp_set_error(who ": the communicator was aborted by an earlier failed collective");      \
+      return BGP_ERR_COMM;                                                                      \
+    }                                                                                           \
+  } while (0)
 
 #define BGP_NCCL(call)                                                                          \
   do {                                                                                          \
@@ -281,6 +315,32 @@ extern "C" void bgp_comm_destroy(bgp_comm* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream && !c->aborted) (void)hipStreamSynchronize(c->stream);
+  if (c->stream && c->aborted) {
+    // an aborted communicator may still have a staged download in flight into the pinned arena: wait for the stream with a
+    // bound before its arena entries are forgotten (bgp_xfer_forget's contract: "has been synchronised")
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(c->stream) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) usleep(200);
+    (void)hipGetLastError();
+  }
+  if (c->loop) {
+    std::lock_guard<std::mutex> glock(g_loop_mu);
+    LoopGroup* g = c->loop;
+    bool last;
+    {
+      std::lock_guard<std::mutex> lock(g->mu);
+      g->aborted = 1;  // (a member leaving ends the group for the others)
+      g->cv.notify_all();
+      last = --g->members == 0;
+    }
+    if (last) {
+      for (int par = 0; par < 2; par++) {
+        if (g->dshared[par]) (void)hipFree(g->dshared[par]);
+        for (hipEvent_t e : g->ev[par]) (void)hipEventDestroy(e);
+      }
+      g_loops.erase(c->loop_key);
+      delete g;
+    }
+  }
   if (c->ev_ctx) (void)hipEventDestroy(c->ev_ctx);
   if (c->comm) (void)g_rccl.CommDestroy(c->comm);
   if (c->dsend) (void)hipFree(c->dsend);
@@ -298,6 +358,11 @@ extern "C" int bgp_comm_abort(bgp_comm* c) {
     bgp_set_error("bgp_comm_abort: NULL argument");
     return BGP_ERR_INVALID;
   }
+  if (c->loop) {
+    std::lock_guard<std::mutex> lock(c->loop->mu);
+    c->loop->aborted = 1;
+    c->loop->cv.notify_all();
+  }
   if (!c->aborted && c->comm && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);
   c->comm = nullptr;
   c->aborted = 1;
@@ -309,6 +374,10 @@ extern "C" int bgp_comm_nranks(bgp_comm* c, int* nranks) {
   if (!c || !nranks) {
     bgp_set_error("bgp_comm_nranks: NULL argument");
     return BGP_ERR_INVALID;
+  }
+  if (c->loop && !c->aborted) {
+    *nranks = c->world;
+    return BGP_OK;
   }
   BGP_COMM_LIVE(c, "bgp_comm_nranks");
   BGP_NCCL(g_rccl.CommCount(c->comm, nranks));
@@ -332,7 +401,6 @@ extern "C" int bgp_comm_nranks(bgp_comm* c, int* nranks) {
 //                   redoes its batch by launches and EVERY rank, having seen the same word, goes round the gather again.
 // errors_out[r] = status word of rank r (0 = sound).  Returns BGP_OK when the collective itself completed -- the caller
 // looks at errors_out, the same on every rank, and every rank raises alike --, BGP_ERR_COMM when it did not (aborted).
-#define BGP_RANK_REDO 1000000
 __global__ void lml_pack_kernel(const double* __restrict__ dlml, int Bp, int per, const unsigned* __restrict__ ps_err,
                                 int local_error, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,6 +499,183 @@ extern "C" int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* c, int per_r
     }
     if (!redo || round == 1) return BGP_OK;
   }
+  return BGP_OK;
+}
+
+// ---- the sharded resident sampler's side of the communicator (bgp_mcmc.hip) ----
+int bgp_comm_rank(const bgp_comm* c, int* rank, int* world) {
+  if (!c || c->aborted || (!c->comm && !c->loop)) {
+    bgp_set_error("bgp_mcmc_begin: the communicator is gone (aborted by an earlier failed collective)");
+    return BGP_ERR_COMM;
+  }
+  *rank = c->rank;
+  *world = c->world;
+  return BGP_OK;
+}
+
+const double* bgp_comm_recv(bgp_comm* c, size_t doubles) {
+  if (!c) return nullptr;
+  if (doubles > c->cap_recv || doubles / c->world > c->cap_send) {
+    if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // (nothing of an earlier exchange reads the old buffers)
+    if (comm_reserve(c, std::max(c->cap_send, doubles / c->world), std::max(c->cap_recv, doubles)) != BGP_OK) return nullptr;
+  }
+  return c->drecv;
+}
+
+static int loop_meet(LoopGroup* g, const char* what) {
+  std::unique_lock<std::mutex> lock(g->mu);
+  if (g->aborted) {
+    bgp_set_error("%s: the loop-back group was aborted", what);
+    return BGP_ERR_COMM;
+  }
+  const unsigned long long gen = g->generation;
+  if (++g->arrived == g->world) {
+    g->arrived = 0;
+    g->generation++;
+    g->cv.notify_all();
+    return BGP_OK;
+  }
+  const bool ok = g->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return g->generation != gen || g->aborted; });
+  if (!ok || g->aborted) {
+    g->aborted = 1;
+    g->cv.notify_all();
+    bgp_set_error("%s: a rank of the loop-back group did not arrive (or the group was aborted)", what);
+    return BGP_ERR_COMM;
+  }
+  return BGP_OK;
+}
+
+int bgp_comm_enqueue_lml_gather(bgp_comm* c, bgp_ctx* ctx, hipStream_t st, int Bp, int per, const unsigned* ps_err) {
+  BGP_COMM_LIVE_OR_LOOP(c, "bgp_mcmc (sharded run)");
+  const size_t slot = (size_t)per + 1;
+  if (slot > c->cap_send || slot * c->world > c->cap_recv || (c->loop && slot > LOOP_SLOT)) {
+    bgp_set_error("bgp_mcmc (sharded run): %d rows per rank exceed the communicator's exchange buffers", per);
+    return BGP_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(lml_pack_kernel, dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, st, ctx->dlml, Bp, per, ps_err, 0, c->dsend);
+  if (!c->loop) {
+    const ncclResult_t nr = g_rccl.AllGather(c->dsend, c->drecv, slot, ncclFloat64, c->comm, st);
+    if (nr != ncclSuccess) {  // (a failure to ENQUEUE the collective leaves the peers in it: abort so that they fail at once too)
+      bgp_set_error("bgp_mcmc (sharded run): enqueueing the all-gather failed (%s); communicator aborted", g_rccl.GetErrorString(nr));
+      (void)bgp_comm_abort(c);
+      return BGP_ERR_COMM;
+    }
+    return BGP_OK;
+  }
+  LoopGroup* g = c->loop;
+  const int par = (int)(g->round[c->rank]++ & 1ull);
+  BGP_HIP(hipMemcpyAsync(g->dshared[par] + (size_t)c->rank * LOOP_SLOT, c->dsend, slot * sizeof(double), hipMemcpyDeviceToDevice, st));
+  BGP_HIP(hipEventRecord(g->ev[par][c->rank], st));
+  const int rm = loop_meet(g, "bgp_mcmc (sharded run)");
+  if (rm) return rm;
+  for (int r = 0; r < c->world; r++) {
+    if (r != c->rank) BGP_HIP(hipStreamWaitEvent(st, g->ev[par][r], 0));
+    BGP_HIP(hipMemcpyAsync(c->drecv + (size_t)r * slot, g->dshared[par] + (size_t)r * LOOP_SLOT, slot * sizeof(double),
+                           hipMemcpyDeviceToDevice, st));
+  }
+  // (no rank may re-record an event of this parity before every rank has enqueued its waits on it: two rounds on, behind the
+  // next round's meeting -- which every rank only reaches after these waits)
+  return BGP_OK;
+}
+
+int bgp_comm_wait_stream(bgp_comm* c, hipStream_t st, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned it = 0;; it++) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return BGP_OK;
+    (void)hipGetLastError();
+    if (e != hipErrorNotReady) {
+      bgp_set_error("%s: the stream failed: %s", what, hipGetErrorString(e));
+      bgp_xfer_drop_pending();
+      return BGP_ERR_HIP;
+    }
+    if ((it & 255) != 255) {
+      bgp_cpu_relax();
+      continue;
+    }
+    const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ncclResult_t ar = ncclSuccess;
+    const bool have = g_rccl.CommGetAsyncError && c->comm && g_rccl.CommGetAsyncError(c->comm, &ar) == ncclSuccess;
+    const bool bad = have && ar != ncclSuccess && ar != ncclInProgress;
+    bool loop_gone = false;
+    if (c->loop) {
+      std::lock_guard<std::mutex> lock(c->loop->mu);
+      loop_gone = c->loop->aborted != 0;
+    }
+    if (bad || loop_gone || el > comm_timeout_s()) {
+      if (bad)
+        bgp_set_error("%s: RCCL reports an asynchronous error (%s); communicator aborted", what, g_rccl.GetErrorString(ar));
+      else
+        bgp_set_error("%s: the run's collectives did not complete within %.0f s (BGP_COMM_TIMEOUT_S): a peer has died or left; "
+                      "communicator aborted", what, comm_timeout_s());
+      (void)bgp_comm_abort(c);
+      bgp_xfer_drop_pending();
+      return BGP_ERR_COMM;
+    }
+    if (el > 0.2) usleep(200);  // a long wait: stop burning the core
+  }
+}
+
+// Loop-back communicator `rank` of `world` on `device`: the communicators of one process that name the same key form a group
+// (see LoopGroup).  Test infrastructure of the sharded sampler on one GPU; no RCCL behind it.
+extern "C" int bgp_comm_init_loopback(int device, int rank, int world, long long key, bgp_comm** out) {
+  if (!out || world < 1 || world > 64 || rank < 0 || rank >= world) {
+    bgp_set_error("bgp_comm_init_loopback: bad argument (rank %d of %d)", rank, world);
+    return BGP_ERR_INVALID;
+  }
+  *out = nullptr;
+  const int ndev = bgp_device_count();
+  if (ndev <= 0 || device < 0 || device >= ndev) {
+    bgp_set_error("bgp_comm_init_loopback: no usable HIP device (count=%d, requested=%d)", ndev, device);
+    return BGP_ERR_NODEVICE;
+  }
+  BGP_HIP(hipSetDevice(device));
+  bgp_comm* c = new bgp_comm();
+  c->device = device;
+  c->rank = rank;
+  c->world = world;
+  c->loop_key = key;
+  {
+    std::lock_guard<std::mutex> glock(g_loop_mu);
+    LoopGroup*& g = g_loops[key];
+    if (!g) {
+      g = new LoopGroup();
+      g->world = world;
+      g->round.assign(world, 0ull);
+      bool ok = true;
+      for (int par = 0; par < 2 && ok; par++) {
+        ok = hipMalloc((void**)&g->dshared[par], (size_t)world * LOOP_SLOT * sizeof(double)) == hipSuccess;
+        g->ev[par].assign(world, nullptr);
+        for (int r = 0; r < world && ok; r++) ok = hipEventCreateWithFlags(&g->ev[par][r], hipEventDisableTiming) == hipSuccess;
+      }
+      if (!ok) {
+        bgp_set_error("bgp_comm_init_loopback: allocating the group's buffers failed");
+        for (int par = 0; par < 2; par++) {
+          if (g->dshared[par]) (void)hipFree(g->dshared[par]);
+          for (hipEvent_t e : g->ev[par])
+            if (e) (void)hipEventDestroy(e);
+        }
+        delete g;
+        g_loops.erase(key);
+        delete c;
+        return BGP_ERR_HIP;
+      }
+    }
+    if (g->world != world || g->members >= world) {
+      bgp_set_error("bgp_comm_init_loopback: key %lld names a group of %d ranks with %d members", key, g->world, g->members);
+      delete c;
+      return BGP_ERR_INVALID;
+    }
+    g->members++;
+    c->loop = g;
+  }
+  if (hipStreamCreate(&c->stream) != hipSuccess || comm_reserve(c, LOOP_SLOT, (size_t)LOOP_SLOT * world) != BGP_OK) {
+    bgp_set_error("bgp_comm_init_loopback: allocating the exchange buffers failed");
+    bgp_comm_destroy(c);
+    return BGP_ERR_HIP;
+  }
+  *out = c;
   return BGP_OK;
 }
 

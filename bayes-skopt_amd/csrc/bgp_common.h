@@ -198,6 +198,7 @@ struct bgp_ctx {
   long long ps_timeouts = 0;    // ... of which timed out and were redone by launches
   int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
   struct bgp_mcmc_state* mcmc = nullptr;  // an open device-resident sampler run (bgp_mcmc_begin .. bgp_mcmc_end; bgp_mcmc.hip)
+  int ps_forbid = 0;            // the device-resident sampler redoes a run after a time-out: launches only, on every rank
   int ps_resident = 0;          // the device-resident sampler is enqueuing: no per-call copy of the error word (its kernels read it)
   unsigned long long* ps_trace = nullptr;  // BGP_PS_TRACE=1: device buffer of in-kernel time stamps (bgp_debug_ps_trace)
   size_t cap_pstrace = 0;
@@ -363,8 +364,9 @@ static inline bool bgp_ps_allowed(bgp_ctx* c) {
 }
 int bgp_launch_cholesky_persist(bgp_ctx* ctx, int B, int build_gram);
 int bgp_lml_redo_if_abandoned(bgp_ctx* ctx, int B);
-int bgp_lml_enqueue_dev(bgp_ctx* ctx, int nb, int warped);
-void bgp_mcmc_abandon(bgp_ctx* ctx);  // bgp_mcmc.hip: drop an open sampler run (context teardown, failed calls)  // bgp_api.hip: Gram build + factorisation + LML of c->dh[0 .. nb), on the device only
+int bgp_lml_enqueue_dev(bgp_ctx* ctx, int nb, int warped);  // bgp_api.hip: Gram build + factorisation + LML of c->dh[0 .. nb), on the device only
+int bgp_ensure_warp_buffers(bgp_ctx* ctx);                  // bgp_api.hip: the per-walker warp buffers of a warped LML batch exist
+void bgp_mcmc_abandon(bgp_ctx* ctx);  // bgp_mcmc.hip: drop an open sampler run (context teardown, failed calls)
 // the launch-free call of a batch whose results are discarded anyway: forget it (no time-out is counted, nothing is redone)
 static inline void bgp_ps_clear_inflight(bgp_ctx* c) {
   c->ps_inflight = 0;

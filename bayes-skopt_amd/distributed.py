@@ -58,6 +58,12 @@ def backend():
     return _state["backend"]
 
 
+def communicator():
+    """The native group's ``_lib.Comm`` (None outside an RCCL group): what the sharded resident sampler enqueues its per-half-step
+    all-gather on."""
+    return _state["comm"] if _state["backend"] == "rccl" else None
+
+
 class _stdout_to_stderr:
     """Native libraries announce themselves on file descriptor 1 ("[Gloo] Rank 0 is connected to ...", RCCL's version
     banner); a job's standard output belongs to its caller (bench.py: one JSON line).  While a group is being formed,

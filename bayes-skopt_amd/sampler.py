@@ -14,9 +14,22 @@ block of proposals -- the data-parallel axis of the hot path -- 
 kernel-matrix builds + Cholesky factorisations of a half-step run as one batch on the GPU.  The
 accept/reject bookkeeping (O(W) scalar work per half-step) stays on the host.
 """
+import sys
+import time
+
 import numpy as np
 
 __all__ = ["EnsembleSampler", "walkers_independent"]
+
+_told = set()
+
+
+def _tell_once(reason):
+    """One line on stderr, once per process and reason: a run that could have stayed on the device is driven from the host."""
+    if reason and reason not in _told:
+        _told.add(reason)
+        print("[bayes_skopt_amd] ensemble sampler: this run is driven from the host, one device batch per half-step (%s)" % reason,
+              file=sys.stderr, flush=True)
 
 
 def walkers_independent(coords):
@@ -140,13 +153,15 @@ class EnsembleSampler:
             raise ValueError("The initial log_prob was NaN")
 
         nsteps = int(nsteps)
-        # a log_prob_fn that can describe itself to the device (BayesGPR with its default prior families, no warp, no
-        # sharding) runs the whole loop there: proposals, priors, LML batches, accept tests and the chain stay in HBM
-        resident = getattr(self.log_prob_fn, "resident", None) if (self.vectorize and not progress and nsteps > 0) else None
+        # a log_prob_fn that can describe itself to the device (BayesGPR with its default prior families, warped or not, sharded
+        # over an RCCL group or not) runs the whole loop there: proposals, priors, LML batches, accept tests and the chain stay in
+        # HBM; a progress bar follows the device through the plan's segments.  A run that cannot says why on stderr, once.
+        resident = getattr(self.log_prob_fn, "resident", None) if (self.vectorize and nsteps > 0) else None
         if resident is not None:
             run = resident(self.nwalkers, self.ndim, *self.args, **self.kwargs)
             if run is not None:
-                return self._run_resident(run, coords, log_prob, nsteps)
+                return self._run_resident(run, coords, log_prob, nsteps, progress)
+            _tell_once(getattr(self.log_prob_fn, "resident_reason", None))
         chain = np.empty((nsteps, self.nwalkers, self.ndim))
         lps = np.empty((nsteps, self.nwalkers))
         rng = self._random
@@ -190,14 +205,20 @@ class EnsembleSampler:
         self.iteration += nsteps
         return State(coords, log_prob, rng.get_state())
 
-    def _run_resident(self, run, coords, log_prob, nsteps):
+    def _run_resident(self, run, coords, log_prob, nsteps, progress=False):
         """The same run with the state on the device (``bgp_mcmc_begin`` / ``_steps`` / ``_end``): every draw of the generator
         is made here, in the order ``run_mcmc``'s loop makes them -- a half-step's stretch factors and partners, its accept
         draws, the next half-step's -- and handed over as the plan in growing segments, the next one drawn while the device
-        works through the last; the generator ends in the same state and the device replays the same moves."""
+        works through the last; the generator ends in the same state and the device replays the same moves.  ``progress``: the
+        bar (emcee's tqdm bar, ``bask/bayesgpr.py:522-524``) advances by the segments the device has worked through
+        (``bgp_mcmc_progress``, polled between the segments and until the last one has passed)."""
         rng, Ns = self._random, self.nwalkers // 2
+        state0 = rng.get_state()
         plans = self._half_step_plans(nsteps)
         run.begin(coords, log_prob, nsteps)
+        pbar = _progress(progress, nsteps)
+        live = not isinstance(pbar, _NoBar) and getattr(run, "progress", None) is not None
+        shown = 0
         try:
             done, seg = 0, 2
             while done < nsteps:
@@ -213,11 +234,38 @@ class EnsembleSampler:
                 run.steps((movers, partners, zz, factors, logu))
                 done += seg
                 seg = min(2 * seg, 64)
+                if live:
+                    now = run.progress()
+                    pbar.update(now - shown)
+                    shown = now
+            while live and shown < nsteps:  # every segment is on the device: follow it to the end of the plan
+                now = run.progress()
+                if now == shown:
+                    time.sleep(2e-3)
+                pbar.update(now - shown)
+                shown = now
         except BaseException:
+            pbar.close()
             run.abandon()
             raise
-        chain, lps, coords, log_prob, nacc, info = run.end()
+        try:
+            chain, lps, coords, log_prob, nacc, info = run.end()
+        finally:
+            pbar.update(nsteps - shown if not live else 0)
+            pbar.close()
         if info[0]:
+            # the host-driven loop raises from ``_check_coords`` in the half-step that proposed the value, with the generator
+            # advanced that far and no further: the same message, the same generator state
+            hf = int(info[2]) if len(info) > 2 else -1
+            if hf >= 0:
+                rng.set_state(state0)
+                replay = self._half_step_plans(nsteps)
+                for h in range(hf + 1):
+                    next(replay)
+                    if h < hf:
+                        rng.rand(Ns)
+            if len(info) > 3 and info[3]:
+                raise ValueError("At least one parameter value was NaN")
             raise ValueError("At least one parameter value was infinite")
         self.n_log_prob_evals += 2 * nsteps * Ns
         self.naccepted += nacc

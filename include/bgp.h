@@ -324,6 +324,11 @@ int bgp_comm_barrier(bgp_comm* comm);
 int bgp_comm_abort(bgp_comm* comm);
 /* ranks RCCL counts in the communicator (ncclCommCount) */
 int bgp_comm_nranks(bgp_comm* comm, int* nranks);
+/* Loop-back communicator: rank `rank` of a group of `world` communicators of THIS process on ONE device (one per host thread, each
+ * beside its own context; the communicators that name the same key form the group).  It serves the in-stream exchange of a
+ * sharded bgp_mcmc_begin_ex run with device copies and events instead of RCCL -- the row-sharding logic of the multi-GPU sampler
+ * exercised with world > 1 semantics on a single GPU (tests); every other collective answers BGP_ERR_COMM. */
+int bgp_comm_init_loopback(int device, int rank, int world, long long key, bgp_comm** out);
 /* Exact single-ensemble sharding of bask/bayesgpr.py:490-530 (ONE n_walkers ensemble, one RNG): every rank has
  * submitted its own rows of a half-step's proposal block with bgp_lml_batch_submit (possibly none); this replaces
  * bgp_lml_batch_wait and returns the log-likelihoods of ALL ranks (world * per_rank doubles, rank-major, gathered device to
@@ -352,14 +357,41 @@ int bgp_lml_batch_wait_allgather(bgp_ctx* ctx, bgp_comm* comm, int per_rank, int
  *                  -2 ((x / lo)^p_lo + (x / hi)^p_hi) - log_norm with par = (ln lo, ln hi, p_lo, p_hi, log_norm))
  * (prior_par: p x 5); log-probability = log-prior + LML, non-finite -> -inf (bask/bayesgpr.py:351-379); accept iff
  * factors + lp_new - lp_old > logu.  Outputs: chain (nsteps x W x p) and logp (nsteps x W) after every step, the final
- * ensemble (coords_out, logp_out), accept counts, info[0] != 0 when a proposal had a non-finite coordinate (emcee raises
- * ValueError there: the caller should), info[1] = 1 when a launch-free factorisation gave up its waits and the WHOLE run was
- * redone on the launch schedule (same bits).  Needs W / 2 <= max_batch, no pending batch, per-launch timing off.
+ * ensemble (coords_out, logp_out), accept counts, and info (4 ints): info[0] != 0 when a proposal had a non-finite coordinate
+ * (emcee raises ValueError there: the caller should) -- info[2] is then the index of the first such half-step and info[3] says
+ * whether its first offender was a NaN (1) or an infinity (0), as emcee's two messages distinguish --, info[1] = 1 when a
+ * launch-free factorisation gave up its waits and the WHOLE run was redone on the launch schedule (same bits).  Needs the rows of a
+ * half-step that this context factorises (W / 2, or its share of them) <= max_batch, no pending batch, per-launch timing off.  An
+ * ensemble too large for the step kernel's 160 KB of LDS (W p + W + 3 Ns + 2 Ns p > 20 480 doubles) runs the same kernel on the
+ * arrays in HBM; n <= 128 with at most 64 entries per walker takes the fused one-launch half-step.
  * bgp_mcmc_begin / bgp_mcmc_steps / bgp_mcmc_end are the same run with the plan handed over in segments (nseg steps = 2 nseg rows
  * of every plan array per call, in order): bgp_mcmc_steps uploads its rows, enqueues their half-steps and returns at once, so the
  * caller draws the next segment's random numbers while the device works through this one; bgp_mcmc_end (every step handed over)
  * waits and collects.  Between begin and end the context belongs to the run: every other entry point answers BGP_ERR_STATE;
- * bgp_ctx_destroy drops an open run.  bgp_mcmc_run = begin + one bgp_mcmc_steps with the whole plan + end. */
+ * bgp_ctx_destroy drops an open run.  bgp_mcmc_run = begin + one bgp_mcmc_steps with the whole plan + end.
+ * bgp_mcmc_progress: steps of the open run whose segment the device has worked through (never blocks): what a progress bar shows
+ * while the run is resident (emcee's tqdm bar, bask/bayesgpr.py:522-524 with progress=True, the default of fit, :550-564).
+ *
+ * bgp_mcmc_begin_ex adds the two things that change the SHAPE of a half-step:
+ *   nwarp = 2 d   walkers that carry their own input warp (warp_inputs=True, bask/bayesgpr.py:353-365): the last 2 d entries of a
+ *                 walker are [wa_1 .. wa_d, wb_1 .. wb_d] (log space) and every proposal's Gram matrix is built on the design
+ *                 matrix seen through the Beta CDFs of ITS parameters (the kernels of bgp_lml_batch_warped); h_src only reads the
+ *                 first p - 2 d entries.  Log-prior = sum over those entries, in order, + sum over k of (prior(wa_k) + prior(wb_k))
+ *                 (the reference's two loops, :360-372).  prior_kind 3:  ((-(y y)) / 2 - par[2]) - par[3], y = (t - par[0]) / par[1]
+ *                 (Normal(loc, scale) on t with par = (loc, scale, log sqrt(2 pi), log scale): scipy's norm.logpdf operation by
+ *                 operation, the default warp priors of bask/bayesgpr.py:463-466).  0: no warp.
+ *   comm          ONE ensemble sharded over the ranks of a communicator (SURVEY.md 8e option 1): every rank calls with the same
+ *                 arguments and the same plan; the step kernel runs replicated on every rank, rank r factorises rows
+ *                 [r Ns / G, (r + 1) Ns / G) of every half-step's proposal block, and an all-gather of ceil(Ns / G) + 1 doubles per
+ *                 rank (log-likelihoods + a status word) sits between the LML batch and the next step kernel ON THE CONTEXT'S
+ *                 STREAM -- no host synchronisation per half-step, the chain equals the one-GPU chain bit for bit.  A rank whose
+ *                 launch-free factorisation timed out says so in its status word and EVERY rank redoes the whole run on the launch
+ *                 schedule; bgp_mcmc_end waits with the communicator's bound (BGP_COMM_TIMEOUT_S) and returns BGP_ERR_COMM instead
+ *                 of hanging; a rank that drops its run early aborts the communicator.  NULL: one rank. */
+int bgp_mcmc_begin_ex(bgp_ctx* ctx, bgp_comm* comm, int nwarp, int W, int p, int nsteps, const int* h_src,
+                      const double* h_fixed, const int* prior_kind, const double* prior_par, const double* coords0,
+                      const double* logp0);
+int bgp_mcmc_progress(bgp_ctx* ctx, int* steps_done);
 int bgp_mcmc_begin(bgp_ctx* ctx, int W, int p, int nsteps, const int* h_src, const double* h_fixed, const int* prior_kind,
                    const double* prior_par, const double* coords0, const double* logp0);
 int bgp_mcmc_steps(bgp_ctx* ctx, int nseg, const int* movers, const int* partners, const double* zz, const double* factors,

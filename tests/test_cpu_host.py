@@ -282,11 +282,32 @@ def test_resident_plan_replays_the_host_loop_bitwise(bask):
     np.testing.assert_array_equal(st.coords, st0.coords)
     assert s.iteration == ref.iteration == 50 and s.n_log_prob_evals == ref.n_log_prob_evals
     assert s._random.rand() == ref._random.rand()
-    # a progress bar, or a log_prob_fn whose resident() declines, keeps the host loop
+    # a progress bar does not keep the run on the host (fit()'s default is progress=True) ...
     s3 = bask.sampler.EnsembleSampler(12, p, Resident())
     s3.random_state = np.random.RandomState(5).get_state()
-    s3.run_mcmc(p0, 5, progress=True)
-    assert getattr(s3, "resident_runs", 0) == 0
+    s3.run_mcmc(p0, 10, progress=True)
+    assert s3.resident_runs == 1
+    np.testing.assert_array_equal(s3.get_chain(), ref.get_chain()[:10])
+
+
+def test_a_declined_resident_run_says_why_once(bask, capsys):
+    """A log_prob_fn whose resident() declines keeps the host loop, and the reason it gives goes to stderr once per process."""
+    class Declines:
+        resident_reason = "a test reason %d" % id(object())
+
+        def __call__(self, Xb):
+            return -0.5 * (Xb * Xb).sum(axis=1)
+
+        def resident(self, n_walkers, n_dim):
+            return None
+
+    p0 = 1e-2 * np.random.RandomState(0).randn(12, 3)
+    for _ in range(3):
+        s = bask.sampler.EnsembleSampler(12, 3, Declines())
+        s.run_mcmc(p0, 4)
+        assert getattr(s, "resident_runs", 0) == 0 and s.get_chain().shape == (4, 12, 3)
+    err = capsys.readouterr().err
+    assert err.count(Declines.resident_reason) == 1 and "driven from the host" in err
 
 
 def test_sampler_preconditions(bask):

@@ -136,9 +136,9 @@ gs = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state
 calls = []
 orig = gs._ctx.lml_wait_allgather
 g1 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state=3, device=0, normalize_y=True).fit(X, y, **kw)
-# and once more with the collective counted
+# and once more driven from the host, with the collective counted
 gs2 = bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2]), random_state=3, device=0, normalize_y=True,
-                    shard_ensemble=True)
+                    shard_ensemble=True, resident_sampler=False)
 from bayes_skopt_amd import _lib
 real = _lib.Context.lml_wait_allgather
 def counted(self, comm, per_rank, local_error=0):
@@ -146,8 +146,20 @@ def counted(self, comm, per_rank, local_error=0):
     return real(self, comm, per_rank, local_error)
 _lib.Context.lml_wait_allgather = counted
 gs2.fit(X, y, **kw)
+_lib.Context.lml_wait_allgather = real
+# the sharded run resident on the device at the launch-free shard's shape (16 matrices of n = 1100), with the reference's default
+# progress bar, against the unsharded resident run and against the host-driven sharded run
+rng = np.random.RandomState(1)
+X2 = rng.uniform(size=(1100, 4)); y2 = np.sin(3.0 * X2.sum(axis=1)) + 0.1 * rng.randn(1100)
+kw2 = dict(n_desired_samples=32 * 6, n_burnin=2, n_walkers_per_thread=32)
+big = [bask.BayesGPR(kernel=bask.construct_default_kernel([0, 1, 2, 3]), random_state=5, device=0, normalize_y=True,
+                     shard_ensemble=sh, resident_sampler=res).fit(X2, y2, **kw2) for sh, res in ((True, True), (False, True), (True, False))]
+stats = big[0]._ctx.persist_stats()
 distributed.destroy_process_group()
 print(json.dumps({"same": bool(np.array_equal(gs.chain_, g1.chain_) and np.array_equal(gs2.chain_, g1.chain_)),
+                  "resident": [getattr(g._sampler, "resident_runs", 0) for g in (gs, g1, gs2)],
+                  "big_same": bool(np.array_equal(big[0].chain_, big[1].chain_) and np.array_equal(big[0].chain_, big[2].chain_)),
+                  "big_resident": [getattr(g._sampler, "resident_runs", 0) for g in big], "big_stats": stats,
                   "calls": len(calls), "per_rank": sorted(set(calls)), "torch": "torch" in sys.modules}))
 """
 
@@ -162,7 +174,12 @@ def test_device_resident_lml_gather_through_rccl():
     assert res.returncode == 0, res.stderr[-3000:]
     d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["same"] and d["torch"] is False
+    # the sharded fit is resident on the device (the all-gather sits on the context's stream between the LML batch and the next
+    # step kernel: no host call per half-step); the host-driven form gathers once per half-step
+    assert d["resident"] == [1, 1, 0]
     assert d["calls"] == 1 + 2 * 7 and d["per_rank"] == [10, 20]  # initial ensemble (20 rows) + 2 half-steps x 7 steps
+    assert d["big_same"] and d["big_resident"] == [1, 1, 0]
+    assert d["big_stats"]["calls"] >= 2 * 8 and d["big_stats"]["timeouts"] == 0  # launch-free batches beside the RCCL kernels
 
 
 _ERRPATH_WORKER = r"""

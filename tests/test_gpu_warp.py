@@ -141,7 +141,8 @@ def test_warped_device_chain_equals_oracle_chain(O):
     y = np.sin(9.0 * X[:, 0] ** 2) + X[:, 1] + 0.05 * rng.randn(n)
     y = (y - y.mean()) / y.std()
     ad = np.full(n, 1e-10)
-    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=7, warp_inputs=True)
+    gp = bask.BayesGPR(kernel=bask.construct_default_kernel(list(range(d))), random_state=7, warp_inputs=True,
+                       resident_sampler=False)  # (the host-driven loop: the resident form has its own test, test_gpu_resident.py)
     gp.fit(X, y, n_desired_samples=W, n_burnin=0, n_walkers_per_thread=W, progress=False)
     start = np.array(gp.pos_, copy=True)
     assert start.shape == (W, d + 2 + 2 * d)
