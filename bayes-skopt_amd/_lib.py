@@ -78,6 +78,7 @@ SIGNATURES = {
     "bgp_mcmc_begin_ex": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp]),
     "bgp_mcmc_progress": (C.c_int, [_vp, _ip]),
     "bgp_comm_init_loopback": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_longlong, C.POINTER(_vp)]),
+    "bgp_comm_bench_lml_gather": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _dp]),
     "bgp_mcmc_steps": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp, _dp, _dp]),
     "bgp_mcmc_end": (C.c_int, [_vp, _dp, _dp, _dp, _dp, C.POINTER(C.c_longlong), _ip]),
     "bgp_mcmc_run": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _ip, _ip, _dp, _dp, _dp, _dp, _dp, _dp,
@@ -686,6 +687,12 @@ class Comm:
         """ncclCommAbort: the peers' collectives fail at once instead of waiting for this rank."""
         if getattr(self, "_h", None):
             self._lib.bgp_comm_abort(self._h)
+
+    def bench_lml_gather(self, ctx, per, reps=200):
+        """ms per round of the sharded resident sampler's in-stream exchange (``bgp_comm_bench_lml_gather``; every rank calls)."""
+        v = C.c_double(0.0)
+        _check(self._lib.bgp_comm_bench_lml_gather(ctx._h, self._h, int(per), int(reps), C.byref(v)), "bgp_comm_bench_lml_gather")
+        return float(v.value)
 
     def nranks(self):
         """Ranks RCCL itself counts in the communicator (ncclCommCount)."""

@@ -617,6 +617,42 @@ int bgp_comm_wait_stream(bgp_comm* c, hipStream_t st, const char* what) {
   }
 }
 
+// Measurement hook (bench.py): `reps` rounds of the sharded resident sampler's per-half-step exchange -- pack kernel + all-gather of
+// per + 1 doubles per rank -- enqueued back to back on the CONTEXT's stream between two HIP events: the device-side price of the
+// exchange where the sampler pays it (in-stream, no host synchronisation), averaged per round.  Every rank calls it together.
+extern "C" int bgp_comm_bench_lml_gather(bgp_ctx* ctx, bgp_comm* c, int per, int reps, double* ms_per_round) {
+  if (!ctx || !c || !ms_per_round || per < 1 || reps < 1) {
+    bgp_set_error("bgp_comm_bench_lml_gather: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_REQUIRE_IDLE(ctx, "bgp_comm_bench_lml_gather");
+  BGP_HIP(hipSetDevice(ctx->device));
+  if (!bgp_comm_recv(c, ((size_t)per + 1) * c->world)) {
+    bgp_set_error("bgp_comm_bench_lml_gather: no exchange buffers for %d rows per rank", per);
+    return BGP_ERR_HIP;
+  }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  BGP_HIP(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) {
+    (void)hipEventDestroy(e0);
+    bgp_set_error("bgp_comm_bench_lml_gather: hipEventCreate failed");
+    return BGP_ERR_HIP;
+  }
+  int rc = BGP_OK;
+  for (int warm = 0; warm < 8 && rc == BGP_OK; warm++) rc = bgp_comm_enqueue_lml_gather(c, ctx, ctx->stream, 0, per, nullptr);
+  if (rc == BGP_OK && hipEventRecord(e0, ctx->stream) != hipSuccess) rc = BGP_ERR_HIP;
+  for (int i = 0; i < reps && rc == BGP_OK; i++) rc = bgp_comm_enqueue_lml_gather(c, ctx, ctx->stream, 0, per, nullptr);
+  if (rc == BGP_OK && hipEventRecord(e1, ctx->stream) != hipSuccess) rc = BGP_ERR_HIP;
+  if (rc == BGP_OK) rc = bgp_comm_wait_stream(c, ctx->stream, "bgp_comm_bench_lml_gather");
+  float ms = 0.f;
+  if (rc == BGP_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = BGP_ERR_HIP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipGetLastError();
+  if (rc == BGP_OK) *ms_per_round = (double)ms / reps;
+  return rc;
+}
+
 // Loop-back communicator `rank` of `world` on `device`: the communicators of one process that name the same key form a group
 // (see LoopGroup).  Test infrastructure of the sharded sampler on one GPU; no RCCL behind it.
 extern "C" int bgp_comm_init_loopback(int device, int rank, int world, long long key, bgp_comm** out) {

@@ -193,6 +193,17 @@ def _blas_threads():
         return os.cpu_count() or 1
 
 
+def _thread_sweep():
+    """BLAS thread counts the CPU baselines are timed at: 1, 8, 16 and 64 where the pool has them (on a 256-core host one thread
+    beat all 64 at n = 2048, and BASELINE.md's own probe had 8 best for the n = 2048 Cholesky): the baseline is the BEST of them."""
+    top = _blas_threads()
+    return sorted({t for t in (1, 8, 16, 64) if t <= top} | ({top} if top < 8 else set()))
+
+
+def _label(nthreads):
+    return "1_thread" if nthreads == 1 else "%d_threads" % nthreads
+
+
 def _timed_evals(fn, thetas, budget_s, min_evals=3):
     """Sequential evaluations (one walker at a time, as emcee's map would) until the budget is used up, at least
     `min_evals`; returns the per-evaluation times."""
@@ -208,22 +219,21 @@ def _timed_evals(fn, thetas, budget_s, min_evals=3):
     return times
 
 
-def cpu_baseline(X, y, thetas, budget_s=8.0):
+def cpu_baseline(X, y, thetas, budget_s=4.0):
     """Oracle (numpy/scipy restatement of sklearn's log_marginal_likelihood) on the host cores, a bounded sample of
-    the same workload, at ONE BLAS thread and at all of them; `value` = the better of the two from
-    the median evaluation time."""
+    the same workload, at 1 / 8 / 16 / 64 BLAS threads; `value` = the BEST of them from the median
+    evaluation time, all of them stated."""
     from threadpoolctl import threadpool_limits
 
     from oracle import gp_oracle as O
 
     ad = np.full(len(y), 1e-10)
-    all_threads = _blas_threads()
     runs = {}
-    for label, nthreads in (("1_thread", 1), ("all_cores", all_threads)):
+    for nthreads in _thread_sweep():
         with threadpool_limits(limits=nthreads):
             t = _timed_evals(lambda th: O.lml(X, y, ad, th), thetas, budget_s)
-        runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
-                       "evals_per_s": float(1.0 / np.median(t))}
+        runs[_label(nthreads)] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                                  "evals_per_s": float(1.0 / np.median(t))}
     best = max(runs, key=lambda k: runs[k]["evals_per_s"])
     return {
         "value": runs[best]["evals_per_s"],
@@ -233,8 +243,9 @@ def cpu_baseline(X, y, thetas, budget_s=8.0):
         "host_cpu_count": os.cpu_count(),
         "runs": runs,
         "sample": f"sequential LML evaluations (n={len(y)}, d={X.shape[1]}) of walker positions from the same start "
-        f"ball with oracle/gp_oracle.py (numpy + scipy LAPACK): {runs['1_thread']['evals']} at 1 BLAS thread, "
-        f"{runs['all_cores']['evals']} at {all_threads}; median time per evaluation; value = the faster setting",
+        "ball with oracle/gp_oracle.py (numpy + scipy LAPACK): "
+        + ", ".join("%d at %d BLAS thread(s)" % (r["evals"], r["threads"]) for r in runs.values())
+        + "; median time per evaluation; value = the fastest setting",
     }
 
 
@@ -248,7 +259,7 @@ def _sklearn_gpr(X, y):
     return GaussianProcessRegressor(kernel=k, optimizer=None, alpha=1e-10).fit(X, y)
 
 
-def cpu_baseline_sklearn(X, y, thetas, budget_s=6.0):
+def cpu_baseline_sklearn(X, y, thetas, budget_s=3.0):
     """The call the reference itself makes per walker (bask/bayesgpr.py:374): scikit-learn's
     GaussianProcessRegressor.log_marginal_likelihood(theta) -- third-party code present in the image on both
     sides, timed on the same bounded sample next to the oracle restatement (they agree to 1e-12)."""
@@ -261,25 +272,25 @@ def cpu_baseline_sklearn(X, y, thetas, budget_s=6.0):
         vals.append(gpr.log_marginal_likelihood(th))
 
     runs = {}
-    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+    for nthreads in _thread_sweep():
         del vals[:]
         with threadpool_limits(limits=nthreads):
             t = _timed_evals(f, thetas, budget_s)
-        runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
-                       "evals_per_s": float(1.0 / np.median(t))}
+        runs[_label(nthreads)] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                                  "evals_per_s": float(1.0 / np.median(t))}
     best = max(runs, key=lambda k: runs[k]["evals_per_s"])
     return {"value": runs[best]["evals_per_s"], "unit": "LML-evals/s", "cores": runs[best]["threads"],
             "kind": "sklearn 1.7 GaussianProcessRegressor.log_marginal_likelihood", "runs": runs}, vals[1:]
 
 
-def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget_walkers=36, budget_steps=1):
+def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget_walkers=36, budget_steps=1, threads=None):
     """TIMED host run of the reference's sampling loop at this size: the package's host ensemble sampler (emcee's
     stretch move, one proposal block per half-step) driving scikit-learn's log_marginal_likelihood one walker at a
     time -- what BayesGPR.sample does on the CPU (bask/bayesgpr.py:510-530, :351-379: a sequential per-walker map,
     whatever the host's core count).  Bounded: `budget_walkers` walkers (the smallest ensemble emcee accepts, 2p) x
-    `budget_steps` steps, run at ONE BLAS thread and at all of them; the better setting is the baseline (as in
-    cpu_baseline) and the full-size figure is its time per evaluation x the evaluations of the full run, stated as an
-    extrapolation."""
+    `budget_steps` steps, run at ONE BLAS thread and at the thread count the per-evaluation sweep found best (`threads`); the
+    better setting is the baseline (as in cpu_baseline) and the full-size figure is its time per evaluation x the evaluations
+    of the full run: an EXTRAPOLATION, and labelled so."""
     from threadpoolctl import threadpool_limits
 
     from bayes_skopt_amd.sampler import EnsembleSampler
@@ -299,7 +310,8 @@ def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget
     W = max(budget_walkers, 2 * p)
     evals_full = n_walkers_full * (steps_full + 1)
     runs = {}
-    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+    for nthreads in sorted(set(threads or [1, _blas_threads()])):
+        label = _label(nthreads)
         rng = np.random.RandomState(0)
         pos = theta0 + 1e-2 * rng.randn(W, p)
         smp = EnsembleSampler(W, p, log_prob, kwargs=dict(priors=priors))
@@ -318,9 +330,10 @@ def cpu_fit_plus_sample(X, y, priors, theta0, n_walkers_full, steps_full, budget
         "timed_config": f"{W} walkers x {budget_steps} step(s) (+ initial ensemble), sklearn log_marginal_likelihood per "
         f"walker, sequential over the walkers as the reference runs them, on a {os.cpu_count()}-core host",
         "ms_per_eval": runs[best]["ms_per_eval"],
+        "label": "EXTRAPOLATED from the timed evaluations above, not run in full",
         "extrapolated_full_ms": runs[best]["ms_per_eval"] * evals_full,
         "extrapolated_full_evals": int(evals_full),
-        "extrapolation": f"timed ms per evaluation (better of 1 / all BLAS threads) x {evals_full} evaluations = "
+        "extrapolation": f"timed ms per evaluation (best of the BLAS thread counts above) x {evals_full} evaluations = "
         f"{n_walkers_full} walkers x ({steps_full} steps + initial ensemble); the MAP start of fit() (a few dozen more "
         "evaluations with gradients) is not included",
     }
@@ -589,16 +602,16 @@ def config_b(bask, device, steps=500, with_cpu=True, peak_tflops=None):
 
         gpr = _sklearn_gpr(X, y)
         runs = {}
-        for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+        for nthreads in _thread_sweep():
             with threadpool_limits(limits=nthreads):
-                t = _timed_evals(lambda th: gpr.log_marginal_likelihood(th), st.coords, budget_s=3.0, min_evals=32)
-            runs[label] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
-                           "evals_per_s": float(1.0 / np.median(t))}
+                t = _timed_evals(lambda th: gpr.log_marginal_likelihood(th), st.coords, budget_s=2.0, min_evals=32)
+            runs[_label(nthreads)] = {"threads": int(nthreads), "evals": len(t), "median_ms_per_eval": float(np.median(t) * 1e3),
+                                      "evals_per_s": float(1.0 / np.median(t))}
         best = max(runs, key=lambda k: runs[k]["evals_per_s"])
         out["cpu_baseline"] = {"value": runs[best]["evals_per_s"], "unit": "LML-evals/s", "cores": runs[best]["threads"],
                                "kind": "reference", "runs": runs,
                                "sample": f">= 32 sequential sklearn log_marginal_likelihood calls (n={n}, d={d}) on walker "
-                               "positions of the timed chain, at 1 BLAS thread and at all of them; value = the faster setting"}
+                               "positions of the timed chain, at 1 / 8 / 16 / 64 BLAS threads; value = the fastest setting"}
         out["speedup_vs_cpu"] = rate / out["cpu_baseline"]["value"]
         out["cpu_fit_plus_sample_ms_extrapolated"] = evals_fit / out["cpu_baseline"]["value"] * 1e3
     return out
@@ -619,7 +632,8 @@ def config_e_cpu(n=1000, d=8, m=10000, n_thompson=10, mcmc_evals=1300, svd_m=150
     th = k.theta
     out = {}
     best = None
-    for label, nthreads in (("1_thread", 1), ("all_cores", _blas_threads())):
+    for nthreads in _thread_sweep():
+        label = _label(nthreads)
         with threadpool_limits(limits=nthreads):
             t = _timed_evals(lambda t_: gpr.log_marginal_likelihood(t_), th + 0.01 * rng.randn(24, len(th)), budget_s=1.5, min_evals=12)
             lml_ms = float(np.median(t) * 1e3)
@@ -811,13 +825,15 @@ def main():
             print(json.dumps({"rendezvous_only": True, "n_gpus": ws, "dist_backend": info["backend"],
                               "rccl_nranks": info["rccl_nranks"], "rank_devices": info["rank_devices"],
                               "ranks_seen": seen, "max_rank": tmax}), flush=True)
-        if ws > 1:
+        if distributed.backend() is not None:
             distributed.barrier()
             distributed.destroy_process_group()
         return
 
     n, d, W = N_POINTS, N_DIMS, N_WALKERS
-    ensemble = args.shard == "ensemble" and ws > 1
+    # (a group forced at world size 1 -- BGP_DIST_FORCE=1, the one-GPU test of the RCCL path -- runs the sharded ensemble too)
+    grouped = distributed.backend() is not None
+    ensemble = args.shard == "ensemble" and grouped
     seed_rank = 0 if (ensemble or ws == 1) else rank  # one shared ensemble needs the same RNG streams on every rank
     gp, X, y, priors, theta0, pos = setup_config_c(bask, device, distributed.rank_seed(0, seed_rank))
 
@@ -841,12 +857,19 @@ def main():
 
     sampler = make_sampler(ensemble)
     state = sampler.run_mcmc(pos, max(args.warmup, 1))  # also evaluates the initial ensemble
-    dt, state = timed(sampler, state.coords, state.log_prob, args.steps)
+    # THREE timed passes of exactly K steps each (barrier + device synchronisation on both sides, MAX over ranks); the headline
+    # is their median -- the boxes of this pool differ by ~5 %, and one 0.3 s pass carries whatever the box was doing
+    passes = []
+    for _ in range(3):
+        dt_i, state = timed(sampler, state.coords, state.log_prob, args.steps)
+        passes.append(dt_i)
+    dt = float(np.median(passes))
+    resident_runs = int(getattr(sampler, "resident_runs", 0))
     pos, lp = state.coords, state.log_prob
 
     # final posterior-sample gather (RCCL over xGMI when N > 1; the shared ensemble's chain is on every rank already)
     tg = time.perf_counter()
-    chain_local = sampler.get_chain(flat=True, discard=max(args.warmup, 1))
+    chain_local = sampler.get_chain(flat=True, discard=max(args.warmup, 1) + 2 * args.steps)  # (the last timed pass's steps)
     chain_all = chain_local if ensemble else distributed.gather_chains(chain_local)
     gather_ms = (time.perf_counter() - tg) * 1e3
 
@@ -870,6 +893,7 @@ def main():
     # like the rocprofv3 runs under profiles/ (BGP_STREAMS=1).
     gp._ctx.set_streams(1)
     gp._ctx.set_timing(True)
+    gp.resident_sampler = False  # (per-launch timing synchronises inside every batch: the host-driven loop, by choice)
     acc = {k: [0.0, 0] for k in ("kbuild", "potrf", "trsm", "syrk", "syrk_columns")}
     dev_total = 0.0
     n_calls = 0
@@ -892,6 +916,7 @@ def main():
     dt_instr = time.perf_counter() - t1
     gp._ctx.lml = orig
     gp._ctx.set_timing(False)
+    gp.resident_sampler = True
 
     B = W // 2
     if ensemble:  # this rank's share of every proposal block
@@ -972,6 +997,7 @@ def main():
         "mfma_peak_measured": mfma_measured,
         "unit": "TFLOP/s",
         "frac": achieved / peak,
+        "frac_of_spec": achieved / FP64_MFMA_PEAK_TFLOPS,
         "traffic": traffic,
         "traffic_source": traffic_source,
         "avg_launch_ms": syrk_ms / max(syrk_launches, 1),
@@ -1024,6 +1050,12 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "timed_passes_ms_per_step": [t / args.steps * 1e3 for t in passes],
+        "value_is": "the median of three timed passes of exactly `steps` steps each",
+        "sampler": ("device-resident (bgp_mcmc_begin_ex / _steps / _end: no transfer or host synchronisation between half-steps"
+                    + ("; the ranks' log-likelihoods all-gathered on the context's stream)" if ensemble else ")"))
+                   if resident_runs else "host-driven (one LML batch call" + (" + one all-gather" if ensemble else "") + " per half-step)",
+        "resident": bool(resident_runs),
         "higher_is_better": True,
         "scaling": "strong" if ensemble else "weak",
         "vs_baseline": None,
@@ -1062,20 +1094,27 @@ def main():
     }
     ps = gp._ctx.persist_stats()
     line["launch_free_calls_in_timed_path"] = {"calls": ps["calls"], "timeouts": ps["timeouts"]}
-    if ws > 1:
-        # the path's one exchange, alone: all-gather of the per-rank share of 128 doubles (+ status word) on an idle device,
-        # barrier-aligned, host wall per call -- what a half-step pays on top of its shard's factorisation
+    if grouped:
+        # the path's one exchange, alone: all-gather of the per-rank share of 128 doubles (+ status word), barrier-aligned
         per = -(-(W // 2) // ws)
-        buf = np.zeros(per + 1)
-        for _ in range(20):
-            distributed._allgather(buf)
-        distributed.barrier()
-        t0 = time.perf_counter()
-        for _ in range(200):
-            distributed._allgather(buf)
-        line["collective_ms_per_half_step"] = distributed.max_over_ranks((time.perf_counter() - t0) / 200 * 1e3)
-        line["collective_note"] = ("host-staged all-gather of the same size through the same communicator (upper bound of the "
-                                   "device-resident one inside the loop, which also overlaps the prior evaluation)")
+        comm = distributed.communicator()
+        if comm is not None:
+            # where the resident sampler pays it: pack kernel + RCCL all-gather back to back ON THE CONTEXT'S STREAM between two HIP
+            # events (bgp_comm_bench_lml_gather), no host in the loop
+            distributed.barrier()
+            line["collective_ms_per_half_step"] = distributed.max_over_ranks(comm.bench_lml_gather(gp._ctx, per, 200))
+            line["collective_note"] = ("in-stream: 200 rounds of the pack kernel + ncclAllGather of %d doubles per rank on the context's "
+                                       "stream between two HIP events, MAX over ranks" % (per + 1))
+        else:
+            buf = np.zeros(per + 1)
+            for _ in range(20):
+                distributed._allgather(buf)
+            distributed.barrier()
+            t0 = time.perf_counter()
+            for _ in range(200):
+                distributed._allgather(buf)
+            line["collective_ms_per_half_step"] = distributed.max_over_ranks((time.perf_counter() - t0) / 200 * 1e3)
+            line["collective_note"] = "host-staged all-gather of the same size through the gloo group (the host-driven exchange)"
     if other is not None:
         line["weak_chains_evals_per_s" if ensemble else "strong_ensemble_evals_per_s"] = other
         line["other_sharding_note"] = ("N independent 256-walker sub-ensembles, no collective in the loop (weak scaling; reads "
@@ -1095,6 +1134,23 @@ def main():
                 "host bookkeeping were free",
                 "evals_per_s": {str(N): 256.0 / (2.0 * sh[str(128 // N)] * 1e-3) for N in (1, 2, 4, 8)},
             }
+            # ... and the per-half-step BUDGET a future SCALE line can be checked against: the shard's device call (above, wall
+            # incl. its launch and synchronisation), the resident run's step kernel, and the in-stream exchange measured on a
+            # ONE-rank RCCL group of this GPU (pack kernel + ncclAllGather + their kernel boundaries: the device-side floor of the
+            # exchange; the xGMI hop of a real N-rank gather comes on top and is NOT in it)
+            budget = {"shard_ms": sh, "step_kernel_ms": 0.0105, "step_kernel_source": "profiles/r05_resident_timeline.txt",
+                      "host_ms_per_half_step": 0.0, "host_note": "resident run: the host draws the plan AHEAD of the device"}
+            try:
+                if _lib.comm_available():
+                    c1 = _lib.Comm(device, 0, 1, _lib.comm_unique_id())
+                    budget["collective_ms_in_stream_1rank"] = {str(N): c1.bench_lml_gather(gp._ctx, 128 // N, 200) for N in (2, 4, 8)}
+                    c1.close()
+                    budget["evals_per_s_with_budget"] = {
+                        str(N): 256.0 / (2.0 * (sh[str(128 // N)] + budget["step_kernel_ms"]
+                                                + budget["collective_ms_in_stream_1rank"][str(N)]) * 1e-3) for N in (2, 4, 8)}
+            except Exception as exc:
+                budget["collective_ms_in_stream_1rank"] = {"error": repr(exc)}
+            line["shard_projection"]["per_half_step_budget"] = budget
         except Exception as exc:
             line["shard_ms"] = {"error": repr(exc)}
         # the other half of BASELINE.json's metric: wall clock of a whole BayesGPR.fit() (MAP start by L-BFGS-B on
@@ -1138,7 +1194,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(X, y, pos[:64])
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             try:  # the CPU side of BASELINE.json's fit+sample metric, timed (bounded) instead of estimated
-                cf = cpu_fit_plus_sample(X, y, priors, theta0, W, 30)
+                best_thr = line["cpu_baseline"]["cores"]
+                cf = cpu_fit_plus_sample(X, y, priors, theta0, W, 30, threads=[1, best_thr])
                 line["cpu_fit_plus_sample_ms"] = cf["extrapolated_full_ms"]
                 line["cpu_fit_plus_sample"] = cf
                 if "fit_plus_sample_ms" in line:
@@ -1153,7 +1210,7 @@ def main():
             except Exception as exc:  # reported, never fatal for the bench line
                 line["cpu_baseline_sklearn"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
-    if ws > 1:
+    if grouped:
         distributed.barrier()
         distributed.destroy_process_group()
 

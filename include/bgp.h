@@ -329,6 +329,10 @@ int bgp_comm_nranks(bgp_comm* comm, int* nranks);
  * sharded bgp_mcmc_begin_ex run with device copies and events instead of RCCL -- the row-sharding logic of the multi-GPU sampler
  * exercised with world > 1 semantics on a single GPU (tests); every other collective answers BGP_ERR_COMM. */
 int bgp_comm_init_loopback(int device, int rank, int world, long long key, bgp_comm** out);
+/* Measurement hook (bench.py): `reps` rounds of the sharded resident sampler's per-half-step exchange (pack kernel + all-gather of
+ * per + 1 doubles per rank) back to back on the CONTEXT's stream between two HIP events: the device-side price of the exchange
+ * where the sampler pays it, ms per round.  Every rank of the communicator calls it together. */
+int bgp_comm_bench_lml_gather(bgp_ctx* ctx, bgp_comm* comm, int per, int reps, double* ms_per_round);
 /* Exact single-ensemble sharding of bask/bayesgpr.py:490-530 (ONE n_walkers ensemble, one RNG): every rank has
  * submitted its own rows of a half-step's proposal block with bgp_lml_batch_submit (possibly none); this replaces
  * bgp_lml_batch_wait and returns the log-likelihoods of ALL ranks (world * per_rank doubles, rank-major, gathered device to

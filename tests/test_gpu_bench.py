@@ -39,7 +39,11 @@ def test_bench_single_gpu_line():
     assert d["metric"] == "mcmc_lml_evals_per_s_n2048" and d["n_gpus"] == 1 and d["dtype"] == "f64"
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["higher_is_better"] is True
     assert abs(d["value"] - 256 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-9
+    # measurement hygiene: the headline is the median of three timed passes, the sampler's run is resident on the device
+    tp = d["timed_passes_ms_per_step"]
+    assert len(tp) == 3 and sorted(tp)[1] == d["ms_per_step"] and d["resident"] is True and d["sampler"].startswith("device-resident")
     r = d["roofline"]
+    assert abs(r["frac_of_spec"] - r["achieved"] / 78.6) < 1e-12
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak_spec"] == 78.6
     # peak = min(datasheet, measured on the box), both stated
     assert r["peak"] == min(r["peak_spec"], r["mfma_peak_measured"]) and 60.0 < r["mfma_peak_measured"] < 90.0
@@ -58,6 +62,10 @@ def test_bench_single_gpu_line():
     sh = d["shard_ms"]
     assert set(sh) == {"128", "64", "32", "16"} and sh["16"] < sh["32"] < sh["64"] < sh["128"]
     assert set(d["shard_projection"]["evals_per_s"]) == {"1", "2", "4", "8"}
+    bud = d["shard_projection"]["per_half_step_budget"]  # what a future SCALE line can be checked against
+    assert bud["shard_ms"] == sh and set(bud["collective_ms_in_stream_1rank"]) == {"2", "4", "8"}
+    assert all(0 < v < 1.0 for v in bud["collective_ms_in_stream_1rank"].values())
+    assert all(bud["evals_per_s_with_budget"][k] < d["shard_projection"]["evals_per_s"][k] for k in ("2", "4", "8"))
     lf = d["launch_free"]
     shapes = {k: v for k, v in lf.items() if k.startswith("n")}
     assert set(shapes) == {"n4096_B1", "n2048_B16", "n1024_B32", "n2048_B1", "n1024_B8"} and all(v["bit_identical"] for v in shapes.values())
@@ -97,6 +105,12 @@ def test_bench_single_gpu_line():
     assert (bk["look_ahead_columns"]["bound"] == "mfma") == (bk["look_ahead_columns"]["flop_per_byte"] >= bk["look_ahead_columns"]["ridge_flop_per_byte"])
     assert 0.2 < bk["look_ahead_columns"]["hbm_frac"] < 1.0 and 0.4 < bk["look_ahead_columns"]["frac_of_roof"] <= 1.0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    # CPU baselines: the best of 1 / 8 / 16 / 64 BLAS threads (as many of them as the host's pool has), all stated
+    for cb_ in (d["cpu_baseline"], d["cpu_baseline_sklearn"], cb["cpu_baseline"]):
+        thr = sorted(r_["threads"] for r_ in cb_["runs"].values())
+        assert thr[0] == 1 and len(thr) >= 2 and set(thr) <= {1, 2, 4, 8, 16, 64} | {thr[-1]}
+        assert cb_["value"] == max(r_["evals_per_s"] for r_ in cb_["runs"].values())
+    assert "EXTRAPOLATED" in d["cpu_fit_plus_sample"]["label"]
 
 
 def test_bench_spawns_its_own_ranks_without_a_launcher():

@@ -119,6 +119,12 @@ def test_bench_line_through_native_rccl_group():
     assert "RCCL version" in res.stderr
     d = json.loads(out_lines[0])
     assert d["dist_backend"] == "rccl" and d["n_gpus"] == 1 and d["gathered_chain_rows"] == 2 * 256
+    # the forced one-rank group runs the SHARDED ensemble (one rank's share = all 128 proposals): resident on the device, the
+    # per-half-step all-gather on the context's stream, its price measured in-stream
+    assert d["scaling"] == "strong" and d["config"]["parallelism"] == "ensemble_sharded1" and d["resident"] is True
+    assert d["sampler"].startswith("device-resident") and "all-gathered on the context's stream" in d["sampler"]
+    assert 0 < d["collective_ms_per_half_step"] < 1.0 and d["collective_note"].startswith("in-stream")
+    assert len(d["timed_passes_ms_per_step"]) == 3
 
 
 _GATHER_WORKER = r"""
