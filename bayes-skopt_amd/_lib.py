@@ -16,7 +16,20 @@ import numpy as np
 # launch schedule is a few dozen dependent launches per factorisation, each of which otherwise starts with a read of its
 # arguments across PCIe: measured on MI355X (tools/persist_probe.py, bench.py) 0.666 -> 0.627 ms for 32 matrices of n = 1024,
 # 2.22 -> 2.03 ms for one of n = 4096, 15.64 -> 15.47 ms per step at config C, results identical.
-os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# It is a PROCESS-WIDE setting (every HIP user of the process and its children inherit it): BGP_NO_ENV_DEFAULTS=1 leaves the
+# environment alone; `env_defaults()` says what this import did, bench.py records it in its line.
+_ENV_DEFAULTS = {}
+if os.environ.get("BGP_NO_ENV_DEFAULTS", "0") in ("", "0"):
+    for _k, _v in (("HIP_FORCE_DEV_KERNARG", "1"),):
+        if _k not in os.environ:
+            os.environ[_k] = _v
+            _ENV_DEFAULTS[_k] = _v
+
+
+def env_defaults():
+    """Environment variables this import set because the user had not (none with BGP_NO_ENV_DEFAULTS=1), and the value of the
+    HIP runtime switch the process runs with."""
+    return {"set_by_import": dict(_ENV_DEFAULTS), "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG")}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbgp.so")
@@ -47,6 +60,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes): every symbol include/bgp.h declares
 SIGNATURES = {
     "bgp_device_count": (C.c_int, []),
+    "bgp_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "bgp_last_error": (C.c_char_p, []),
     "bgp_version": (C.c_char_p, []),
     "bgp_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(KernelSpecStruct), C.c_int,
@@ -151,6 +165,13 @@ def _p(a):
 
 def device_count():
     return int(load().bgp_device_count())
+
+
+def device_identity(device=0):
+    """PCI bus id of a visible device (``bgp_device_pci_bus_id``): what tells ranks that all see "device 0" apart."""
+    buf = C.create_string_buffer(64)
+    _check(load().bgp_device_pci_bus_id(int(device), buf, 64), "bgp_device_pci_bus_id")
+    return buf.value.decode()
 
 
 ACQ_EI, ACQ_MEAN, ACQ_LCB, ACQ_STD = 0, 1, 2, 3  # include/bgp.h BGP_ACQ_*

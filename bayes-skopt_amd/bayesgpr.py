@@ -690,13 +690,17 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         if self._post_theta is None or getattr(self, "_X_train_", None) is None:
             raise RuntimeError("predict before fit is not supported on the MI355X path")
         if self._generic:
-            if return_mean_grad:
-                raise NotImplementedError("prediction gradients need kernel_.gradient_x, which only the canonical kernels have")
             mean, var, cov = self._rows_predict(None, X, noise_zero=False, return_cov=return_cov)
             y_mean = self.y_train_std_ * mean[0] + self.y_train_mean_
             if return_cov:
                 return y_mean, cov[0] * self.y_train_std_**2
-            return (y_mean, np.sqrt(var[0] * self.y_train_std_**2)) if return_std else y_mean
+            y_std = np.sqrt(var[0] * self.y_train_std_**2)
+            if return_mean_grad:
+                grad_mean, grad_std = self._predict_gradients_generic(X[0], y_std, return_std_grad)
+                if return_std_grad:
+                    return y_mean, y_std, grad_mean, grad_std
+                return (y_mean, y_std, grad_mean) if return_std else (y_mean, grad_mean)
+            return (y_mean, y_std) if return_std else y_mean
         self._make_resident()
         Hk = self._canonical(self._kernel_theta_for_predict())
         if return_cov:
@@ -754,6 +758,25 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         grad_std = np.zeros(d)
         if not np.allclose(y_std, 0.0):
             k_trans = cst * S if self._plan.form == "product" else cst + S
+            grad_std = -(k_trans @ (self.K_inv_ @ grad)) / y_std[0] * self.y_train_std_**2
+        return grad_mean, grad_std
+
+    def _predict_gradients_generic(self, x, y_std, want_std_grad):
+        """The same two gradients for a generic kernel tree: ``kernel_.gradient_x`` is ``kernels.gradient_x`` (skopt's method
+        restated for scikit-learn kernel objects), ``K_*`` comes from the host-evaluated kernel object, ``alpha_`` / ``K_inv_``
+        from the device (``bgp_posterior_batch_gram``)."""
+        from .kernels import gradient_x
+
+        Xt = self.X_train_
+        if self.warp_inputs:
+            x = self.warp(x[None, :])[0]
+        grad = gradient_x(self.kernel_, x, Xt)
+        grad_mean = (grad.T @ self.alpha_) * self.y_train_std_
+        if not want_std_grad:
+            return grad_mean, None
+        grad_std = np.zeros(Xt.shape[1])
+        if not np.allclose(y_std, 0.0):
+            k_trans = self.kernel_(x[None, :], Xt)[0]
             grad_std = -(k_trans @ (self.K_inv_ @ grad)) / y_std[0] * self.y_train_std_**2
         return grad_mean, grad_std
 

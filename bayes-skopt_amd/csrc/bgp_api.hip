@@ -167,6 +167,15 @@ extern "C" int bgp_device_count(void) {
   return n;
 }
 
+extern "C" int bgp_device_pci_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 16) {
+    bgp_set_error("bgp_device_pci_bus_id: bad argument");
+    return BGP_ERR_INVALID;
+  }
+  BGP_HIP(hipDeviceGetPCIBusId(buf, len, device));
+  return BGP_OK;
+}
+
 static void free_dev(void* p) {
   if (p) (void)hipFree(p);
 }
@@ -283,7 +292,7 @@ static void warn_unknown_env_once() {
   if (done) return;
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
-                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_PANELS",
+                                "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_PANELS", "BGP_NO_ENV_DEFAULTS",
                                 "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_GEN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;

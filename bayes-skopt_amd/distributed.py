@@ -35,7 +35,7 @@ import time
 
 import numpy as np
 
-__all__ = ["world", "init_process_group", "destroy_process_group", "gather_chains", "barrier", "max_over_ranks",
+__all__ = ["world", "plan_group", "init_process_group", "destroy_process_group", "gather_chains", "barrier", "max_over_ranks",
            "rank_seed", "shard_rows", "shard_log_prob", "broadcast_array", "backend", "group_info", "allgather_lml",
            "ShardedEvaluationError"]
 
@@ -189,15 +189,18 @@ def _fresh_abort(prefix):
         return False
 
 
-def _exchange_unique_id_files(rank, ws, timeout):
+def _exchange_unique_id_files(rank, ws, timeout, device_id=""):
     """Single node, files in the per-user directory, a handshake that no leftover can satisfy:
       1. every rank r > 0 writes <job>.hello.<r> = a nonce it has just drawn (and rewrites it should rank 0's initial
          clean-up remove it);
       2. rank 0 creates the id and answers every hello with <job>.ack.<r> = that nonce + the 128 id bytes; a rank only
          accepts an ack that carries ITS nonce -- written by a live rank 0 of this attempt, whatever files an earlier,
          killed attempt under the same name (a reused BGP_COMM_JOB) has left behind;
-      3. every rank writes <job>.st.<r> = b"ok:<digest of the id it holds>" or b"fail: ..." and waits for all ws of them;
-         a status only counts when it names the same id (the id is unique to the attempt).
+      3. every rank writes <job>.st.<r> = b"ok:<digest of the id it holds>:<identity of its device>" or b"fail: ..." and waits
+         for all ws of them; a status only counts when it names the same id (the id is unique to the attempt).  Two ranks that
+         name the SAME device (PCI bus id: a launcher that pins one GPU per rank through HIP_VISIBLE_DEVICES makes every rank see
+         "device 0", and only the identities tell whether those are eight GPUs or one) are every rank's verdict "fail": RCCL
+         refuses two ranks on one device, and it must not be found out inside ncclCommInitRank.
     Returns the id when ALL ranks hold it; raises RuntimeError (on every rank alike) otherwise -- before anyone has
     entered ncclCommInitRank, so one rank timing out cannot leave the others blocked in the collective."""
     from . import _lib
@@ -252,19 +255,22 @@ def _exchange_unique_id_files(rank, ws, timeout):
                     time.sleep(0.01)
     except Exception as exc:  # reported to the others below, then raised
         err = exc
-    mine = b"ok:" + _uid_digest(uid) if err is None else ("fail: %r" % (err,)).encode()
+    ok_head = b"ok:" + _uid_digest(uid) + b":" if err is None else None
+    mine = ok_head + str(device_id).encode() if err is None else ("fail: %r" % (err,)).encode()
     _write_private("%s.st.%d" % (prefix, rank), mine)
     # the verdict of every rank
     bad = None if err is None else "rank %d: %r" % (rank, err)
     pending = set(range(ws))
+    devices = {}
     while pending and bad is None:
         for r in sorted(pending):
             buf = _read_owned("%s.st.%d" % (prefix, r))
             if buf is None:
                 continue
             if buf.startswith(b"ok:"):
-                if buf == mine:
+                if buf.startswith(ok_head):
                     pending.discard(r)
+                    devices[r] = buf[len(ok_head):].decode(errors="replace")
                 # (another digest: a leftover of an earlier attempt -- wait for this attempt's status)
             elif buf.startswith(b"fail:") and os.stat("%s.st.%d" % (prefix, r)).st_mtime >= _T_START - 1.0:
                 pending.discard(r)
@@ -276,6 +282,11 @@ def _exchange_unique_id_files(rank, ws, timeout):
                 bad = "no status from rank(s) %s within %.0f s" % (sorted(pending), timeout)
             else:
                 time.sleep(0.01)
+    if bad is None:  # every rank holds the id: do they hold a device each?  (the same table on every rank: the same verdict)
+        named = sorted((dev, r) for r, dev in devices.items() if dev)
+        shared = [(a[1], b[1], a[0]) for a, b in zip(named, named[1:]) if a[0] == b[0]]
+        if shared:
+            bad = "ranks %d and %d share device %s: RCCL needs a GPU per rank" % shared[0]
     if bad is not None:
         try:  # a rank that arrives late must not walk into the collective alone
             _write_private(prefix + ".abort", bad.encode())
@@ -322,7 +333,7 @@ def _exchange_unique_id_tcp(rank, ws, timeout):
             time.sleep(0.05)
 
 
-def _exchange_unique_id(rank, ws, timeout=120.0):
+def _exchange_unique_id(rank, ws, timeout=120.0, device_id=""):
     from . import _lib
 
     if ws == 1:
@@ -330,8 +341,42 @@ def _exchange_unique_id(rank, ws, timeout=120.0):
     local = os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1") \
         and os.environ.get("BGP_COMM_TCP") != "1"
     if local:
-        return _exchange_unique_id_files(rank, ws, timeout)
+        return _exchange_unique_id_files(rank, ws, timeout, device_id)
     return _exchange_unique_id_tcp(rank, ws, timeout)
+
+
+_VISIBLE_DEVICES_VARS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
+
+
+def plan_group(ndev, local_rank, local_ws, comm_ok, name=None, device=None, pinned=None):
+    """(backend to form, device ordinal of this rank) from what this rank sees, without any exchange -- every rank of a node
+    sees the same facts, so every rank plans the same backend:
+
+    * a backend asked for by name is taken (``rccl`` without a device raises: there is no CPU fallback);
+    * at least as many visible devices as local ranks and a loadable librccl -> ``rccl``, device ``local_rank % ndev`` (the
+      driver's ``torch.distributed.run --nproc-per-node 8`` on an 8-GPU node: rank r on GPU r);
+    * FEWER visible devices than local ranks but a visible-devices variable in the environment (``HIP_VISIBLE_DEVICES`` and its
+      relatives: a launcher that pins one GPU per rank makes every rank see ONE device, ordinal 0) -> ``rccl`` is tried with
+      device ``local_rank % ndev``, and the rendezvous decides from the devices' PCI bus ids whether the ranks really hold a GPU
+      each (``_exchange_unique_id_files``); a shared GPU is every rank's verdict and the group falls back to gloo;
+    * otherwise (ranks sharing a device, or no device: the CPU tests) -> ``gloo``."""
+    if name not in (None, "rccl", "gloo"):
+        raise ValueError(f"unknown backend {name!r}: the GPU exchange is 'rccl' (libbgp's own communicator); 'gloo' is "
+                         "the CPU group of the tests and of ranks that share a device")
+    if pinned is None:
+        pinned = any(os.environ.get(v) for v in _VISIBLE_DEVICES_VARS)
+    if name is None:
+        if ndev >= max(local_ws, 1) and comm_ok:
+            name = "rccl"
+        elif ndev >= 1 and comm_ok and pinned:
+            name = "rccl"
+        else:
+            name = "gloo"
+    if name == "gloo":
+        return "gloo", None
+    if ndev < 1:
+        raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")
+    return "rccl", ((local_rank % ndev) if device is None else int(device))
 
 
 def init_process_group(backend=None, device=None):
@@ -346,31 +391,27 @@ def init_process_group(backend=None, device=None):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    name = backend or os.environ.get("BGP_DIST_BACKEND")
+    name = backend or os.environ.get("BGP_DIST_BACKEND") or None
     explicit = bool(name)
-    if name not in (None, "rccl", "gloo"):
-        raise ValueError(f"unknown backend {name!r}: the GPU exchange is 'rccl' (libbgp's own communicator); 'gloo' is "
-                         "the CPU group of the tests and of ranks that share a device")
     ndev = _lib.device_count() if name != "gloo" else 0
-    if not name:
-        # decided from what every rank of a node sees alike, without any exchange: a GPU per rank and a loadable
-        # librccl -> the native group; ranks sharing a device (RCCL refuses that) or no device at all -> gloo
-        local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
-        name = "rccl" if (ndev >= max(local_ws, 1) and _lib.comm_available()) else "gloo"
-    dev = None
+    # decided from what every rank of a node sees alike, without any exchange (plan_group)
+    name, dev = plan_group(ndev, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", ws)),
+                           bool(ndev) and name != "gloo" and _lib.comm_available(), name, device)
     if name == "rccl":
-        if ndev < 1:
-            raise RuntimeError("BGP_DIST_BACKEND=rccl needs an MI355X (no CPU fallback); use gloo for CPU tests")
-        dev = (local_rank % ndev) if device is None else int(device)
         try:
-            uid = _exchange_unique_id(rank, ws)  # raises on EVERY rank when any rank failed (single node)
+            # (raises on EVERY rank when any rank failed, or when two ranks turn out to sit on one GPU: single node)
+            try:
+                ident = _lib.device_identity(dev)
+            except Exception:
+                ident = ""  # (no identity: the shared-device check is skipped for this rank)
+            uid = _exchange_unique_id(rank, ws, device_id=ident)
             _state["comm"] = _lib.Comm(dev, rank, ws, uid)
         except Exception as exc:
             if explicit:
                 raise
             print(f"[bayes_skopt_amd.distributed] rank {rank}: native RCCL group failed ({exc}); using gloo",
                   file=sys.stderr, flush=True)
-            name = "gloo"
+            name, dev = "gloo", None
     if name == "gloo":
         import datetime
 

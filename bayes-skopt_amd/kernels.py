@@ -33,7 +33,72 @@ from sklearn.gaussian_process.kernels import (  # noqa: F401  (re-exported: the 
 )
 
 __all__ = ["RBF", "ConstantKernel", "Matern", "WhiteKernel", "Sum", "Product", "KernelPlan", "GramPlan", "analyse_kernel",
-           "param_for_white_kernel_in_sum"]
+           "param_for_white_kernel_in_sum", "gradient_x"]
+
+
+def gradient_x(kernel, x, X_train):
+    """``d k(x, X_train_i) / d x`` for every training point: (n, d).  The method skopt's kernel classes add to scikit-learn's
+    (``kernel_.gradient_x(X[0], self.X_train_)`` in skopt's ``predict(return_mean_grad=True)``, the routine
+    ``bask/bayesgpr.py:633`` forwards to, used by ``bask/optimizer.py:494`` through ``expected_minimum``), restated for
+    scikit-learn kernel objects by recursion over the expression tree: Sum -> sum of the children's gradients, Product ->
+    product rule with the children's cross-covariance rows, Exponentiation -> chain rule; leaves RBF, Matern (0.5 / 1.5 / 2.5 in
+    closed form as skopt has them, any other nu through ``d/dz [z^nu K_nu(z)] = -z^nu K_{nu-1}(z)``), RationalQuadratic,
+    ExpSineSquared, DotProduct; ConstantKernel and WhiteKernel contribute zeros."""
+    from scipy.special import gamma, kv
+    from sklearn.gaussian_process.kernels import DotProduct, Exponentiation, ExpSineSquared, RationalQuadratic
+
+    x = np.asarray(x, dtype=np.float64).ravel()
+    X_train = np.atleast_2d(np.asarray(X_train, dtype=np.float64))
+    n, d = X_train.shape
+    if isinstance(kernel, Sum):
+        return gradient_x(kernel.k1, x, X_train) + gradient_x(kernel.k2, x, X_train)
+    if isinstance(kernel, Product):
+        f = kernel.k1(x[None, :], X_train)[0]
+        g = kernel.k2(x[None, :], X_train)[0]
+        return f[:, None] * gradient_x(kernel.k2, x, X_train) + g[:, None] * gradient_x(kernel.k1, x, X_train)
+    if isinstance(kernel, Exponentiation):
+        base = kernel.kernel(x[None, :], X_train)[0]
+        return (kernel.exponent * base ** (kernel.exponent - 1.0))[:, None] * gradient_x(kernel.kernel, x, X_train)
+    if isinstance(kernel, (ConstantKernel, WhiteKernel)):
+        return np.zeros((n, d))
+    if isinstance(kernel, DotProduct):
+        return X_train.copy()
+    if isinstance(kernel, ExpSineSquared):
+        diff = x[None, :] - X_train
+        dist = np.sqrt(np.sum(diff * diff, axis=1))
+        arg = np.pi * dist / kernel.periodicity
+        k = np.exp(-2.0 * (np.sin(arg) / kernel.length_scale) ** 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            # d/dx exp(-2 sin^2(pi r / p) / l^2) = k * (-2 sin(2 pi r / p) / l^2) * (pi / p) * diff / r
+            fac = np.where(dist > 0, k * (-2.0 * np.sin(2.0 * arg) / kernel.length_scale**2) * (np.pi / kernel.periodicity) / dist, 0.0)
+        return fac[:, None] * diff
+    if isinstance(kernel, (Matern, RBF, RationalQuadratic)):
+        ell = np.broadcast_to(np.asarray(kernel.length_scale, dtype=np.float64), (d,))
+        diff = (x[None, :] - X_train) / ell           # (x - X_i) / l
+        r2 = np.sum(diff * diff, axis=1)
+        if isinstance(kernel, RationalQuadratic):
+            fac = -((1.0 + r2 / (2.0 * kernel.alpha)) ** (-kernel.alpha - 1.0))
+        elif isinstance(kernel, Matern) and not np.isinf(kernel.nu):
+            r = np.sqrt(r2)
+            nu = float(kernel.nu)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                if nu == 0.5:
+                    fac = np.where(r > 0, -np.exp(-r) / r, 0.0)
+                elif nu == 1.5:
+                    fac = -3.0 * np.exp(-np.sqrt(3.0) * r)
+                elif nu == 2.5:
+                    fac = -(5.0 / 3.0) * (1.0 + np.sqrt(5.0) * r) * np.exp(-np.sqrt(5.0) * r)
+                else:
+                    # k = c z^nu K_nu(z), z = sqrt(2 nu) r, c = 2^(1 - nu) / Gamma(nu);  dk/dr = -c sqrt(2 nu) z^nu K_{nu-1}(z)
+                    z = np.sqrt(2.0 * nu) * r
+                    dk_dr = -(2.0 ** (1.0 - nu) / gamma(nu)) * np.sqrt(2.0 * nu) * z**nu * kv(nu - 1.0, z)
+                    fac = np.where(r > 0, dk_dr / r, 0.0)
+                    if nu > 1.0:  # (the limit r -> 0 of (dk/dr) / r is finite for nu > 1: -nu / (nu - 1))
+                        fac = np.where(r > 0, fac, -nu / (nu - 1.0))
+        else:  # RBF (and Matern with nu = inf)
+            fac = -np.exp(-0.5 * r2)
+        return fac[:, None] * diff / ell
+    raise NotImplementedError("gradient_x is not implemented for %s" % type(kernel).__name__)
 
 
 def param_for_white_kernel_in_sum(kernel, kernel_str=""):

@@ -1056,6 +1056,7 @@ def main():
                     + ("; the ranks' log-likelihoods all-gathered on the context's stream)" if ensemble else ")"))
                    if resident_runs else "host-driven (one LML batch call" + (" + one all-gather" if ensemble else "") + " per half-step)",
         "resident": bool(resident_runs),
+        "env_defaults": _lib.env_defaults(),
         "higher_is_better": True,
         "scaling": "strong" if ensemble else "weak",
         "vs_baseline": None,

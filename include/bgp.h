@@ -54,6 +54,9 @@ typedef struct bgp_ctx bgp_ctx;
 
 /* Number of visible HIP devices (0 when none / runtime unusable). */
 int bgp_device_count(void);
+/* PCI bus id ("0000:05:00.0") of visible device `device` into buf (len >= 16): the identity that tells apart ranks which a
+ * launcher has pinned to one GPU each through HIP_VISIBLE_DEVICES -- they all see "device 0" (bayes-skopt_amd/distributed.py). */
+int bgp_device_pci_bus_id(int device, char* buf, int len);
 /* Text of the last error on this thread. */
 const char* bgp_last_error(void);
 /* Library version string. */
@@ -245,6 +248,10 @@ int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const d
  *   (bgp_set_persist), BGP_PS_PAIR (0 / 1: one or two chain workgroups per matrix on the launch-free path; default by shape),
  *   BGP_PS_GEN (0 / 1: the Gram blocks of a launch-free LML batch are built by a kernel in front of it / by its own tile workers
  *   at the head of their ticket list; default by shape).
+ * Runtime switch set by the PYTHON package, not read by this library: bayes-skopt_amd/_lib.py exports HIP_FORCE_DEV_KERNARG=1 (kernel
+ *   arguments in device memory: -6 % per call on the launch schedule at n = 1024 x 32) at import unless the user has set it --
+ *   a process-wide setting that every other HIP user of the process inherits, effective only if the GPU has not been initialised
+ *   before the import; BGP_NO_ENV_DEFAULTS=1 leaves the environment alone.  A C caller of libbgp.so sets it itself.
  * Waits and diagnostics (no effect on results): BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_TRACE,
  *   BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  The A/B switches of earlier rounds (BGP_FUSED_GRAM, BGP_KBUILD1,
  *   BGP_SMALL_SPLIT, BGP_PS_NCRIT / _PSPLIT / _STREAM, BGP_PANEL_WIDTH, BGP_ROWQUAD_T) left the library in round 5 with the

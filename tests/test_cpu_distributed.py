@@ -361,3 +361,132 @@ def test_rendezvous_ignores_a_consistent_set_of_stale_files(tmp_path):
         assert p.wait(timeout=180) == 0
     for r in range(3):
         assert open(tmp_path / f"got{r}.bin", "rb").read() == bytes([7]) * 128
+
+
+# ---------------------------------------------------------------------------------------------------------
+# which backend, which device: an 8-GPU node as the driver launches it, and as a launcher that pins one GPU per rank does
+# ---------------------------------------------------------------------------------------------------------
+def test_plan_group_for_eight_ranks_on_an_eight_device_node():
+    """``distributed.plan_group``: pure host logic, decided alike on every rank from what it sees (no exchange)."""
+    import bayes_skopt_amd  # noqa: F401
+    from bayes_skopt_amd import distributed as D
+
+    # torch.distributed.run --nproc-per-node 8 on an 8-GPU node: every rank sees 8 devices, rank r takes GPU r
+    assert [D.plan_group(8, lr, 8, True, pinned=False) for lr in range(8)] == [("rccl", lr) for lr in range(8)]
+    # ... and 4 ranks on the same node take GPUs 0..3
+    assert [D.plan_group(8, lr, 4, True, pinned=False) for lr in range(4)] == [("rccl", lr) for lr in range(4)]
+    # a launcher that pins one GPU per rank (HIP_VISIBLE_DEVICES=<local rank>): every rank sees ONE device, ordinal 0 -- the
+    # native group is tried and the rendezvous tells from the PCI bus ids whether those are eight GPUs (below)
+    assert [D.plan_group(1, lr, 8, True, pinned=True) for lr in range(8)] == [("rccl", 0)] * 8
+    # two visible devices per rank for eight ranks, pinned: local_rank % 2 (the rendezvous will find the shared ones)
+    assert [D.plan_group(2, lr, 8, True, pinned=True)[1] for lr in range(8)] == [0, 1] * 4
+    # ranks that share the one GPU of a box and no pinning (the GPU tests of this repository): gloo, no attempt
+    assert D.plan_group(1, 1, 2, True, pinned=False) == ("gloo", None)
+    # no device (the CPU tests), or no librccl: gloo
+    assert D.plan_group(0, 0, 2, False, pinned=False) == ("gloo", None) and D.plan_group(8, 3, 8, False, pinned=False) == ("gloo", None)
+    # by name: taken as asked; rccl without a device is an error (no CPU fallback), an unknown name too
+    assert D.plan_group(8, 5, 8, True, name="gloo") == ("gloo", None)
+    assert D.plan_group(1, 1, 2, True, name="rccl", pinned=False) == ("rccl", 0)
+    assert D.plan_group(8, 5, 8, True, name="rccl", device=2) == ("rccl", 2)
+    with pytest.raises(RuntimeError):
+        D.plan_group(0, 0, 2, False, name="rccl")
+    with pytest.raises(ValueError):
+        D.plan_group(8, 0, 8, True, name="nccl")
+    # the environment decides `pinned` when it is not given
+    old = {v: os.environ.pop(v, None) for v in D._VISIBLE_DEVICES_VARS}
+    try:
+        assert D.plan_group(1, 3, 8, True) == ("gloo", None)
+        os.environ["HIP_VISIBLE_DEVICES"] = "3"
+        assert D.plan_group(1, 3, 8, True) == ("rccl", 0)
+    finally:
+        os.environ.pop("HIP_VISIBLE_DEVICES", None)
+        os.environ.update({k: v for k, v in old.items() if v is not None})
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_rendezvous_tells_eight_pinned_gpus_from_a_shared_one(tmp_path, shared):
+    """Eight ranks that all call their GPU "device 0" (a launcher pinned one per rank): the status files carry the devices' PCI
+    bus ids; eight different ones -> every rank gets the id; two ranks on the same one -> EVERY rank refuses, before anybody
+    has entered ncclCommInitRank, naming the two."""
+    code = (
+        "import os, sys, json; sys.path.insert(0, %r); import bayes_skopt_amd; from bayes_skopt_amd import _lib, distributed;"
+        "_lib.comm_unique_id = lambda: bytes(range(128));"
+        "r = int(os.environ['RANK']);\n"
+        "bus = '0000:%%02x:00.0' %% (5 if (%r and r == 6) else r)\n"
+        "try:\n"
+        "    uid = distributed._exchange_unique_id(r, 8, timeout=60.0, device_id=bus); out = 'id ' + uid.hex()[:8]\n"
+        "except RuntimeError as exc:\n"
+        "    out = 'refused: ' + str(exc)\n"
+        "json.dump({'out': out}, open(os.path.join(%r, 'v%%d.json' %% r), 'w'))\n"
+        "import time; time.sleep(4.0 if r == 0 else 0.0)\n"  # (a real rank 0 stays alive in ncclCommInitRank; it removes the files at exit)
+    ) % (ROOT, shared, str(tmp_path))
+    script = tmp_path / "w.py"
+    script.write_text(code)
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)],
+                              env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="8",
+                                       BGP_COMM_DIR=str(tmp_path / "rdv"), BGP_COMM_JOB="pin%d" % shared)) for r in range(8)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    outs = [json.load(open(tmp_path / f"v{r}.json"))["out"] for r in range(8)]
+    if shared:
+        assert all(o.startswith("refused") and "ranks 5 and 6 share device 0000:05:00.0" in o for o in outs), outs
+    else:
+        assert outs == ["id 00010203"] * 8, outs
+
+
+def _stub_ranks(ws, mode, args, tmp_path, timeout=600):
+    """`ws` rank processes of tests/_stub_rccl_bench.py: the native ("rccl") host path with a file-backed stand-in communicator
+    and a closed-form stand-in context (no GPU)."""
+    xdir = tmp_path / "x"
+    xdir.mkdir()
+    port = _free_port()
+    procs = []
+    for r in range(ws):
+        env = {k: v for k, v in os.environ.items() if k not in ("BGP_DIST_BACKEND", "BGP_DIST_FORCE")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ws),
+                   LOCAL_WORLD_SIZE=str(ws), OMP_NUM_THREADS="1", BGP_COMM_DIR=str(tmp_path / "rdv"), BGP_COMM_JOB="stub")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_stub_rccl_bench.py"), str(xdir), mode] + list(args),
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    return outs, xdir
+
+
+@pytest.mark.parametrize("shard", ["ensemble", "chains"])
+def test_bench_two_ranks_through_the_native_backends_host_side(tmp_path, shard):
+    """`bench.py --gpus 2 --shard ensemble | chains` through the RCCL code path's HOST side with world = 2 semantics (a stand-in
+    communicator and context, tests/_stub_rccl_bench.py): the group that forms is reported as the native one (`dist_backend`,
+    `rccl_nranks` = 2, a device per rank out of the 8 visible ones), the sharded log-probability takes its native branch (submit ->
+    collective with status words), the line carries the N > 1 keys."""
+    outs, _ = _stub_ranks(2, "bench", ["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras", "--shard", shard], tmp_path)
+    assert [rc for rc, _o, _e in outs] == [0, 0], outs[0][2][-1500:] + outs[1][2][-1500:]
+    lines = [ln for ln in outs[0][1].splitlines() if ln.strip()]
+    assert len(lines) == 1 and not outs[1][1].strip()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dist_backend"] == "rccl" and d["rccl_nranks"] == 2 and d["rank_devices"] == [0, 1]
+    assert d["resident"] is False and d["sampler"].startswith("host-driven") and len(d["timed_passes_ms_per_step"]) == 3
+    assert d["collective_ms_per_half_step"] == 0.005 and d["collective_note"].startswith("in-stream")
+    if shard == "ensemble":
+        assert d["scaling"] == "strong" and d["config"]["proposals_per_gpu_per_half_step"] == 64 and d["weak_chains_evals_per_s"] > 0
+        assert d["config"]["walkers_total"] == 256 and d["gathered_chain_rows"] == 2 * 256
+    else:
+        assert d["scaling"] == "weak" and d["strong_ensemble_evals_per_s"] > 0 and d["gathered_chain_rows"] == 2 * 2 * 256
+
+
+def test_a_rank_interrupted_inside_a_half_step_takes_the_native_group_down(tmp_path):
+    """KeyboardInterrupt on rank 1 between submit and collective: it collects its pending batch, ABORTS the communicator
+    (`abort_process_group` -> `Comm.abort`, bgp_comm_abort on the real one) and goes down; rank 0, waiting in the collective,
+    fails at once with the communicator's error instead of sitting there for BGP_COMM_TIMEOUT_S."""
+    outs, xdir = _stub_ranks(2, "interrupt", [], tmp_path)
+    r = [json.load(open(xdir / f"r{k}.json")) for k in range(2)]
+    assert [rc for rc, _o, _e in outs] == [3, 3]
+    assert r[1]["out"] == "interrupted" and r[1]["aborted"]
+    assert r[0]["out"].startswith("BgpError") and "communicator aborted" in r[0]["out"] and r[0]["dt"] < 30

@@ -480,3 +480,34 @@ def test_closed_form_acquisitions_match_the_reference_classes():
     np.testing.assert_allclose(acq.Expectation()(mu, std), g["acq_mean"], rtol=1e-13)
     np.testing.assert_allclose(acq.TopTwoEI()(mu, std), g["acq_ttei"], rtol=1e-13, atol=1e-300)
     np.testing.assert_array_equal(acq.LCB()(mu, std, alpha="inf"), std)
+
+
+def test_gradient_x_of_kernel_trees_against_central_differences(bask):
+    """``kernels.gradient_x`` -- skopt's ``kernel_.gradient_x`` (the reference's prediction gradients, ``bask/bayesgpr.py:622-635`` ->
+    skopt predict) restated for scikit-learn kernel objects: every leaf and combinator against central differences of the kernel
+    object itself, and the r = 0 limits."""
+    from sklearn.gaussian_process.kernels import (RBF, ConstantKernel as C, DotProduct, Exponentiation, ExpSineSquared, Matern,
+                                                  RationalQuadratic, WhiteKernel)
+
+    gradient_x = bask.kernels.gradient_x
+    rng = np.random.RandomState(0)
+    X, x = rng.uniform(size=(9, 3)), rng.uniform(size=3)
+    trees = [C(2.0) * Matern([0.3, 0.5, 0.7], nu=2.5) * RBF(0.8) + WhiteKernel(0.1),
+             Matern(0.4, nu=1.5) + Matern([0.2, 0.9, 0.4], nu=0.5), C(0.7) * RationalQuadratic(0.7, 1.3), Matern(0.6, nu=0.7),
+             Matern(0.6, nu=1.9), C(0.5) + ExpSineSquared(1.1, 0.8) * RBF(1.0), DotProduct(0.3) + RBF(0.5),
+             Exponentiation(RBF(0.7) + C(0.2), 2.0), Matern(0.5, nu=np.inf)]
+    h = 1e-6
+    for k in trees:
+        g = gradient_x(k, x, X)
+        fd = np.empty_like(g)
+        for j in range(3):
+            e = np.zeros(3)
+            e[j] = h
+            fd[:, j] = (k((x + e)[None], X)[0] - k((x - e)[None], X)[0]) / (2 * h)
+        assert g.shape == (9, 3)
+        np.testing.assert_allclose(g, fd, rtol=0, atol=2e-9 * max(1.0, np.abs(fd).max()))
+    for k in (Matern(0.6, nu=0.7), Matern(0.6, nu=1.9), Matern(0.4, nu=0.5), Matern(0.4, nu=2.5), RBF(0.4), RationalQuadratic(0.5, 2.0)):
+        assert np.all(gradient_x(k, X[2], X)[2] == 0.0)  # at a training point the gradient with respect to that point vanishes
+    with pytest.raises(NotImplementedError):
+        from sklearn.gaussian_process.kernels import PairwiseKernel
+        gradient_x(PairwiseKernel(), x, X)
