@@ -906,7 +906,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         return self._ctx.pvrs(Hk, X, np.atleast_2d(thompson_points))
 
     def _pvrs_gram(self, X, T, has_alpha_vec):
-        """PVRS for a generic kernel tree through the bordered-inverse identity of ``bgp_pvrs`` (DESIGN.md section 4),
+        """PVRS for a generic kernel tree through the bordered-inverse identity of ``bgp_pvrs`` (DESIGN.md section 6),
         ``covs_i = sum_t [k_t^T K^-1 k_t + (k(x_t, x_i) - k_i^T K^-1 k_t)^2 / (kappa_i - k_i^T K^-1 k_i)]``, every term read off
         ONE device predictive covariance ``C = K_** - K_* K^-1 K_*^T`` over [Thompson points; candidates] per candidate chunk:
         ``C_ti``, ``C_ii`` and ``k_t^T K^-1 k_t = kappa_t - C_tt``.  K carries alpha only when it is a vector (reference quirk,

@@ -873,7 +873,7 @@ extern "C" int bgp_set_streams(bgp_ctx* c, int nstreams) {
   return BGP_OK;
 }
 
-// Launch-free factorisation of small batches (DESIGN.md section 10): -1 = as the environment says (BGP_PERSIST; unset:
+// Launch-free factorisation of small batches (DESIGN.md section 4): -1 = as the environment says (BGP_PERSIST; unset:
 // off), 0 = never, 1 = whenever the batch fits (at most 64 matrices, at least two block columns).
 // The look-ahead column launches of the trailing update (K = 128 .. 128 (P-1) on one 128-wide block column) inside the
 // "syrk" figure of bgp_last_timing: their time and count, so that a caller can rate bulk and column launches apart.

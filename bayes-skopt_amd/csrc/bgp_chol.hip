@@ -306,7 +306,7 @@ int bgp_launch_cholesky_persist(bgp_ctx* c, int B, int build_gram) {
     a.pair = (fits && (want == 1 || (want == -1 && bgp_pair_auto_rule(nblk, B)))) ? 1 : 0;
     a.nchain = a.pair ? 2 * a.Bpad : B;
     // P(I) -- the pre-update of block (I, I-1) that the chain waits for -- as ONE task behind a single chain workgroup, in four
-    // 64 x 64 quadrants (and Dg(I) in three) behind chain pairs, whose cycle runs THROUGH this task (DESIGN.md section 10; the
+    // 64 x 64 quadrants (and Dg(I) in three) behind chain pairs, whose cycle runs THROUGH this task (DESIGN.md section 4; the
     // two-slice and the mixed variants measured slower and left the library in round 5)
     a.psplit = a.pair ? 4 : 1;
     a.dsplit = a.psplit == 4 ? 3 : 1;

@@ -45,7 +45,7 @@ void bgp_xfer_forget(hipStream_t st);
 // arena.  An asynchronous copy straight from / to pageable memory makes the runtime lock and unlock the pages around it,
 // and the unlocking was measured to trail the call: after a config-E PVRS tell (640 KB of candidates up, Thompson draws
 // down) the device stayed "busy" for another 27 ms in five of six processes, which the NEXT tell's first synchronisation
-// then paid (41 -> 70 ms per tell; tools/tell_phase_probe.py).  bgp_memcpy_async / bgp_memcpy2d_async take the
+// then paid (41 -> 70 ms per tell; tools/archive/tell_phase_probe.py).  bgp_memcpy_async / bgp_memcpy2d_async take the
 // arguments of their HIP namesakes: host -> device packs the rows into the arena and copies from there; device -> host
 // lands in the arena and is unpacked into the caller's buffer by bgp_stream_sync of that stream (every entry point
 // synchronises before it returns).  Device -> device passes through.
@@ -314,7 +314,7 @@ struct PsArgs {
 static inline bool bgp_ps_gen_auto_rule(int nblk, int B) { return nblk >= 4 && nblk <= 16 && B <= 32 && B * nblk <= 192; }
 static inline size_t ps_flag_words(int B, int nblk) { return PS_HDR + (size_t)B * nblk * (8 + 2 * (size_t)nblk); }
 // Batch sizes at which the launch-free factorisation wins over the multi-launch schedule (tools/persist_probe.py on MI355X,
-// DESIGN.md section 10; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
+// DESIGN.md section 4; wall time per LML call, launch schedule / launch-free, by n and number of matrices):
 //   n =  768: 8: 0.91, 32: 1.07;   896: 16: 1.02, 48: 1.11
 //   n = 1024: 1: 0.93, 4: 0.95, 8: 0.98, 16: 1.06, 24: 1.12, 32: 1.19, 48: 1.09, 64: 0.97;  975 x 50 (config E): 1.10
 //   n = 1280: 8: 1.04, 32: 1.15, 48: 0.96;   1536: 1: 1.01, 4: 1.06, 16: 1.29, 32: 1.06, 48: 0.92

@@ -1,4 +1,4 @@
-// The launch-free factorisation of small batches (DESIGN.md section 10): ONE persistent kernel per batch -- ps_kernel -- whose first
+// The launch-free factorisation of small batches (DESIGN.md section 4): ONE persistent kernel per batch -- ps_kernel -- whose first
 // workgroups are the chain (one or two per matrix: the diagonal blocks, bgp_pf.h) and whose other workgroups are tile workers
 // (this file) that draw left-looking block tasks from ticket counters.  Same arithmetic, operand order and summation order as
 // the launch schedule (potrf_kernel / trsm4_kernel / syrk4_kernel): bit-identical factors and log-likelihoods.
@@ -210,7 +210,7 @@ static __device__ __forceinline__ int ps_ll_update(const PsArgs& a, const double
 // X_Jc per chunk -- half the bytes of a 128 x 32 column slice, which stages 128 + 128 rows and reads 160 of them -- on an
 // EIGHT-stage ring of 128-row images (the same 128 KB of LDS): seven chunks in flight instead of three.  The last panel's term is
 // pure latency (its 8 chunks, written a microsecond ago by two other workgroups, arrive at the hand-off rate of
-// MI355X_MICROARCH.md "handoff-payload"): 6.3 us -> see DESIGN.md section 10 with three 32 KB chunks in flight.  Waves as 4 x 2, each
+// MI355X_MICROARCH.md "handoff-payload"): 6.3 us -> see DESIGN.md section 4 with three 32 KB chunks in flight.  Waves as 4 x 2, each
 // 16 rows x 32 columns; wave w stages rows 16 w .. 16 w + 15 of the image (waves 0-3: X_I, 4-7: X_Jc): two instructions per
 // wave and chunk, "at most r younger chunks outstanding" = vmcnt(2 r).  Per element the k order of every other update path.
 static __device__ __forceinline__ void q8_wait_vm(int r) {

@@ -395,12 +395,12 @@ def small_batch_shards(bask_lib, X, y, pos_H, device, sizes=(128, 64, 32, 16), r
     return out
 
 
-# (the first three are the round-3 review's shapes; 2048 x 1 and 1024 x 8 are shapes the chain pairs take: DESIGN.md section 10)
+# (the first three are the round-3 review's shapes; 2048 x 1 and 1024 x 8 are shapes the chain pairs take: DESIGN.md section 4)
 LF_SHAPES = ((4096, 32, 1), (2048, 16, 16), (1024, 8, 32), (2048, 16, 1), (1024, 8, 8))
 
 
 def launch_free(bask_lib, device, peak=None, shapes=LF_SHAPES, reps=15):
-    """The launch-free factorisation of small batches (DESIGN.md section 10; automatic at these sizes) next to the launch
+    """The launch-free factorisation of small batches (DESIGN.md section 4; automatic at these sizes) next to the launch
     schedule: wall ms per LML call, the whole call's algorithmic TFLOP/s (Gram build + factorisation + solve; `frac` of the
     fp64 MFMA peak), whether the log-likelihoods are the same bits, and the path's own bookkeeping (calls, time-outs).  A
     FRESH context per shape and mode, launch-free measured first: the order no longer favours either side."""
@@ -437,7 +437,7 @@ def launch_free(bask_lib, device, peak=None, shapes=LF_SHAPES, reps=15):
 
 def launch_free_fresh_process(device, peak, timeout_s=240):
     """`launch_free` in a CHILD process started for it (python bench.py --launch-free-only): late in this long process the
-    same calls read 7-10 % slow or fast depending on where the allocator put their buffers (tools/lf_place_probe.py); a
+    same calls read 7-10 % slow or fast depending on where the allocator put their buffers (tools/archive/lf_place_probe.py); a
     number the driver records should not carry that."""
     if being_profiled():
         return None
@@ -516,7 +516,7 @@ def _device_sampler(bask, device, n, d, W, steps, warm=2):
 def config_a(bask, device, with_cpu=True):
     """BASELINE config A as stated: n = 128, d = 2, Matern-5/2, W = 100 walkers (the reference's default), 100 MCMC steps =
     10 100 log-likelihood evaluations.  Device: ONE fused launch per half-step (proposal, Gram generation, factorisation, LML and
-    accept test in the walker's workgroup: the device-resident sampler, DESIGN section 11).  CPU: the same 100 steps of the host loop (scikit-learn's log_marginal_likelihood per walker, one
+    accept test in the walker's workgroup: the device-resident sampler, DESIGN section 5).  CPU: the same 100 steps of the host loop (scikit-learn's log_marginal_likelihood per walker, one
     BLAS thread), run IN FULL -- no extrapolation."""
     n, d, W, steps = 128, 2, 100, 100
     gp, smp, st, dt, (X, y, priors, theta0) = _device_sampler(bask, device, n, d, W, steps)

@@ -253,7 +253,7 @@ int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const d
  *   a process-wide setting that every other HIP user of the process inherits, effective only if the GPU has not been initialised
  *   before the import; BGP_NO_ENV_DEFAULTS=1 leaves the environment alone.  A C caller of libbgp.so sets it itself.
  * Waits and diagnostics (no effect on results): BGP_WAIT=block, BGP_PS_TIMEOUT_MS, BGP_PS_COOLDOWN, BGP_PS_TRACE,
- *   BGP_COMM_TIMEOUT_S (DESIGN.md sections 6, 7 and 10).  The A/B switches of earlier rounds (BGP_FUSED_GRAM, BGP_KBUILD1,
+ *   BGP_COMM_TIMEOUT_S (DESIGN.md sections 2, 7 and 4).  The A/B switches of earlier rounds (BGP_FUSED_GRAM, BGP_KBUILD1,
  *   BGP_SMALL_SPLIT, BGP_PS_NCRIT / _PSPLIT / _STREAM, BGP_PANEL_WIDTH, BGP_ROWQUAD_T) left the library in round 5 with the
  *   measured-slower variants they selected. */
 int bgp_set_streams(bgp_ctx* ctx, int nstreams);
@@ -274,7 +274,7 @@ int bgp_last_timing_columns(bgp_ctx* ctx, double* ms, int* launches);
  * bgp_sample_y -- instead of ~3 launches per block column; same bits): 1 = whenever the batch fits (<= 64 matrices,
  * n > 128), 0 = never, -1 = as BGP_PERSIST says (unset: where it measured faster on MI355X: at least 6 block columns of
  * 128, matrices x block columns <= 400; and -- with two chain workgroups per matrix -- few matrices from 3 block columns on:
- * bgp_persist_auto_rule / bgp_pair_auto_rule, DESIGN.md section 10).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
+ * bgp_persist_auto_rule / bgp_pair_auto_rule, DESIGN.md section 4).  Replaces nothing in the reference; a scheduling choice behind cholesky() of
  * sklearn/_gpr.py:587. */
 int bgp_set_persist(bgp_ctx* ctx, int mode);
 /* Bookkeeping of that path: out[0] = launch-free calls enqueued by this context, out[1] = of which timed out (a wait

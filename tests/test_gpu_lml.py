@@ -1,6 +1,6 @@
 """GPU parity of the LML hot path (kernel build -> blocked Cholesky -> fused solve -> LML) through the
 C-ABI against the golden vectors (sklearn 1.7.2) and the oracle.  Tolerance: 1e-6 relative
-(BASELINE.json north_star); observed errors are reported by tools/gpu_probe.py."""
+(BASELINE.json north_star); observed errors are reported by tools/archive/gpu_probe.py."""
 import numpy as np
 import pytest
 

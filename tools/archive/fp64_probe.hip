@@ -1,5 +1,5 @@
 // fp64 throughput probe for MI355X: MFMA vs VALU FMA vs both pipes, at several occupancies.
-// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/fp64_probe.hip -o /tmp/fp64_probe && /tmp/fp64_probe
+// Build+run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/archive/fp64_probe.hip -o /tmp/fp64_probe && /tmp/fp64_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));

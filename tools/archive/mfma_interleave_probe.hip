@@ -1,6 +1,6 @@
 // Does v_mfma_f64_16x16x4_f64 issue faster when other instructions sit between consecutive MFMAs?
 // 16 accumulators per wave (the syrk2 register block), inline asm so the order is exactly as written.
-// hipcc --offload-arch=gfx950 -O3 tools/mfma_interleave_probe.hip -o tools/bin/mfma_interleave_probe
+// hipcc --offload-arch=gfx950 -O3 tools/archive/mfma_interleave_probe.hip -o tools/bin/mfma_interleave_probe
 #pragma clang diagnostic ignored "-Wunused-value"
 #pragma clang diagnostic ignored "-Wunused-result"
 #include <hip/hip_runtime.h>

@@ -4,7 +4,7 @@
 //   strided:    rows 1 KB long at a stride of `ld` doubles (the row-major n_pad x n_pad working matrices: ld = 2048 -> 16 KB)
 //   contiguous: the same 64 KB as one contiguous run (what a tile-major storage of the working matrices would give)
 // with 16 x 16-byte loads per lane in flight (the register-operand variant's pattern) over `blocks` workgroups per launch.
-// Build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/stride_rmw_probe.hip -o /tmp/srp && /tmp/srp
+// Build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 tools/archive/stride_rmw_probe.hip -o /tmp/srp && /tmp/srp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

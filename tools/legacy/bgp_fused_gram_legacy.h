@@ -1,4 +1,4 @@
-// RETIRED in round 5 (not compiled into libbgp.so; kept for the record, DESIGN.md section 6 table "BGP_FUSED_GRAM"):
+// RETIRED in round 5 (not compiled into libbgp.so; kept for the record, docs/EXPERIMENTS.md B5):
 // Gram tiles generated inside the first trailing update that touches them, instead of being written by the Gram kernel and read
 // back.  Bit-identical K and LML; measured 15.6 vs 15.9 ms per step at config C (the Gram build 0.84 -> 0.13 ms, the trailing
 // update 5.6 -> 6.2 ms: on this chip a VALU instruction costs the fp64 MFMA its issue slots), 2-5 % slower on small batches.
@@ -11,7 +11,7 @@
 // Gram kernels (bgp_kbuild.hip: differences squared and summed in dimension order with one fma each, then
 // kb_epilogue's expressions without implicit contraction): bit-identical K.  OPT-IN (BGP_FUSED_GRAM=1): measured on
 // MI355X the generation is NOT hidden under the other workgroups' MFMAs -- a VALU instruction costs the fp64 MFMA its
-// issue slots (tools/mfma_interleave_probe.hip) -- so only the saved HBM round trip of K shows: 15.6 vs 15.9 ms per step
+// issue slots (tools/archive/mfma_interleave_probe.hip) -- so only the saved HBM round trip of K shows: 15.6 vs 15.9 ms per step
 // at config C, while the trailing update's own launches get 11 % longer; small batches lose 2-5 %.
 template <int NR, int NC, int CREL, int STAT, int FORM>
 static __device__ __forceinline__ void s4_gen_c(const S4Gen& g, const S4Tile& cur, d4 (&acc)[NR][NC], int r0, int c0,

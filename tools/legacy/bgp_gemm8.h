@@ -75,7 +75,7 @@ static __device__ __forceinline__ void g8_mainloop(GemmSmem& sm, const double* _
 // Instruction choice (measured on MI355X, tools/mfma_issue_probe.hip): v_mfma_f64_16x16x4_f64 saturates
 // at ~48-50 TFLOP/s (issue-limited, ~104 clk per instruction although the pipe is busy 64), whereas the
 // four-block form v_mfma_f64_4x4x4_4b_f64 sustains 73-75 TFLOP/s (95 % of the 78.6 TF datasheet peak).
-// Lane layout of the four-block form (tools/mfma444_layout.hip):
+// Lane layout of the four-block form (tools/archive/mfma444_layout.hip):
 //     A: lane = 16*k + 4*blk + i   B: lane = 16*k + 4*blk + j   C/D: lane = 16*i + 4*blk + j
 // The four blocks are given the SAME 4x4 A sub-block (rows 4r..4r+3) and four adjacent 4-column groups
 // of B, so one instruction produces a 4x16 strip of C:

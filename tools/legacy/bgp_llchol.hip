@@ -1,5 +1,5 @@
 // EXPERIMENTAL (enabled with BGP_LEFT_LOOKING=1; the default LML path is the right-looking two-panel
-// schedule of bgp_chol.hip, which is faster on every measured configuration -- DESIGN.md section 6).
+// schedule of bgp_chol.hip, which is faster on every measured configuration -- docs/EXPERIMENTS.md).
 // Left-looking blocked Cholesky of the LML path on the fast fp64 MFMA form (v_mfma_f64_4x4x4_4b_f64).
 // trsm8_kernel below IS on the default path.
 //
