@@ -639,9 +639,16 @@ class Context:
 COMM_ID_BYTES = 128
 
 
-def comm_available():
-    """True when librccl.so can be loaded (the native multi-GPU backend)."""
-    return bool(load().bgp_comm_available())
+def comm_available(load_it=False):
+    """True when librccl.so is there for the native multi-GPU backend.  By default the library is only LOOKED for (the paths
+    bgp_comm.hip tries): loading the system's librccl into a process that may still fall back to torch's gloo group -- torch
+    brings an RCCL of its own -- ends in a double free at exit.  ``load_it=True`` really dlopens it (bgp_comm_available)."""
+    if load_it:
+        return bool(load().bgp_comm_available())
+    import ctypes.util
+
+    return any(os.path.exists(p) for p in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so")) \
+        or ctypes.util.find_library("rccl") is not None
 
 
 def comm_unique_id():

@@ -191,10 +191,11 @@ def _fresh_abort(prefix):
 
 def _exchange_unique_id_files(rank, ws, timeout, device_id=""):
     """Single node, files in the per-user directory, a handshake that no leftover can satisfy:
-      1. every rank r > 0 writes <job>.hello.<r> = a nonce it has just drawn (and rewrites it should rank 0's initial
-         clean-up remove it);
-      2. rank 0 creates the id and answers every hello with <job>.ack.<r> = that nonce + the 128 id bytes; a rank only
-         accepts an ack that carries ITS nonce -- written by a live rank 0 of this attempt, whatever files an earlier,
+      1. every rank r > 0 writes <job>.hello.<r> = a nonce it has just drawn + "|" + the identity of its device (PCI bus id;
+         and rewrites it should rank 0's initial clean-up remove it);
+      2. rank 0 collects the hellos, refuses two ranks on ONE device (answer: nonce + "!" + message -- before librccl has been
+         touched by anybody), else creates the id and answers every hello with <job>.ack.<r> = that nonce + the 128 id bytes; a
+         rank only accepts an ack that carries ITS nonce -- written by a live rank 0 of this attempt, whatever files an earlier,
          killed attempt under the same name (a reused BGP_COMM_JOB) has left behind;
       3. every rank writes <job>.st.<r> = b"ok:<digest of the id it holds>:<identity of its device>" or b"fail: ..." and waits
          for all ws of them; a status only counts when it names the same id (the id is unique to the attempt).  Two ranks that
@@ -209,40 +210,51 @@ def _exchange_unique_id_files(rank, ws, timeout, device_id=""):
     _state["job_prefix"] = prefix
     deadline = time.monotonic() + timeout
     uid, err = None, None
-    acked = set()
-
-    def serve_acks():  # rank 0: answer the hellos seen so far
-        for r in range(1, ws):
-            if r in acked:
-                continue
-            nonce = _read_owned("%s.hello.%d" % (prefix, r))
-            if nonce is not None and len(nonce) == 32:
-                _write_private("%s.ack.%d" % (prefix, r), nonce + uid)
-                acked.add(r)
 
     try:
         if rank == 0:
             _cleanup_job_files(prefix)  # (leftovers of a reused name go; a hello removed here is rewritten by its rank)
-            uid = _lib.comm_unique_id()
             import atexit
 
             atexit.register(_cleanup_job_files, prefix)
-            while len(acked) < ws - 1:
-                serve_acks()
-                if len(acked) == ws - 1:
+            # collect every rank's hello = nonce + "|" + the identity of its device ...
+            hellos = {}
+            while len(hellos) < ws - 1:
+                for r in range(1, ws):
+                    if r not in hellos:
+                        buf = _read_owned("%s.hello.%d" % (prefix, r))
+                        if buf is not None and len(buf) >= 33 and buf[32:33] == b"|":
+                            hellos[r] = (buf[:32], buf[33:].decode(errors="replace"))
+                if len(hellos) == ws - 1:
                     break
                 if _fresh_abort(prefix):
                     raise RuntimeError("another rank gave the native group up")
                 if time.monotonic() > deadline:
                     raise RuntimeError("no hello from rank(s) %s within %.0f s"
-                                       % (sorted(set(range(1, ws)) - acked), timeout))
+                                       % (sorted(set(range(1, ws)) - set(hellos)), timeout))
                 time.sleep(0.01)
+            # ... and look at the devices BEFORE librccl is touched by anybody: two ranks on one GPU are refused here, with a
+            # message instead of an id (a process that has loaded the system's librccl and then falls back to torch's gloo group
+            # carries two RCCL copies to its exit)
+            named = sorted([(str(device_id), 0)] + [(dev, r) for r, (_n, dev) in hellos.items()])
+            shared = [(a[1], b[1], a[0]) for a, b in zip(named, named[1:]) if a[0] and a[0] == b[0]]
+            if shared:
+                msg = "ranks %d and %d share device %s: RCCL needs a GPU per rank" % shared[0]
+                for r, (nonce, _dev) in hellos.items():
+                    _write_private("%s.ack.%d" % (prefix, r), nonce + b"!" + msg.encode())
+                raise RuntimeError(msg)
+            uid = _lib.comm_unique_id()
+            for r, (nonce, _dev) in hellos.items():
+                _write_private("%s.ack.%d" % (prefix, r), nonce + uid)
         else:
             nonce = os.urandom(16).hex().encode()
             hello = "%s.hello.%d" % (prefix, rank)
-            _write_private(hello, nonce)
+            mine_hello = nonce + b"|" + str(device_id).encode()
+            _write_private(hello, mine_hello)
             while uid is None:
                 buf = _read_owned("%s.ack.%d" % (prefix, rank))
+                if buf is not None and buf[:32] == nonce and buf[32:33] == b"!":
+                    raise RuntimeError(buf[33:].decode(errors="replace"))
                 if buf is not None and buf[:32] == nonce and len(buf) == 32 + _lib.COMM_ID_BYTES:
                     uid = buf[32:]
                 elif _fresh_abort(prefix):
@@ -250,8 +262,8 @@ def _exchange_unique_id_files(rank, ws, timeout, device_id=""):
                 elif time.monotonic() > deadline:
                     raise RuntimeError(f"no ncclUniqueId from rank 0 ({prefix}.ack.{rank}) within {timeout:.0f} s")
                 else:
-                    if _read_owned(hello) != nonce:
-                        _write_private(hello, nonce)
+                    if _read_owned(hello) != mine_hello:
+                        _write_private(hello, mine_hello)
                     time.sleep(0.01)
     except Exception as exc:  # reported to the others below, then raised
         err = exc

@@ -350,7 +350,7 @@ def test_rendezvous_ignores_a_consistent_set_of_stale_files(tmp_path):
            "distributed._state['attempt'] = 1; p = distributed._job_prefix(3); old = bytes([9]) * 128;"
            "dg = distributed._uid_digest(old);"
            "[distributed._write_private(p + '.ack.%%d' %% r, b'0' * 32 + old) for r in (1, 2)];"
-           "[distributed._write_private(p + '.hello.%%d' %% r, b'0' * 32) for r in (1, 2)];"
+           "[distributed._write_private(p + '.hello.%%d' %% r, b'0' * 32 + b'|0000:01:00.0') for r in (1, 2)];"
            "[distributed._write_private(p + '.st.%%d' %% r, b'ok:' + dg) for r in (0, 1, 2)];"
            "distributed._write_private(p + '.uid', old)") % ROOT
     assert subprocess.run([sys.executable, "-c", pre], env=base, timeout=120).returncode == 0
