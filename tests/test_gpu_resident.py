@@ -70,6 +70,10 @@ def test_resident_run_with_fixed_and_isotropic_kernel_parts():
 def test_cases_that_stay_on_the_host(capfd):
     """What is left for the host-driven loop: a prior the device cannot evaluate, an odd ensemble -- and each says so on stderr,
     once per process.  (Progress bars, warped inputs and ensembles beyond the step kernel's LDS run resident: below.)"""
+    from bayes_skopt_amd import sampler as sampler_module
+
+    sampler_module._told.clear()  # (once per PROCESS: earlier tests of this process may have said the same things)
+    capfd.readouterr()
     d = 2
     _, s = _sample(128, d, 20, 4, resident=True, priors=[lambda t: -0.5 * t * t] * 4)
     assert getattr(s, "resident_runs", 0) == 0
