@@ -315,6 +315,31 @@ def test_resident_run_sees_a_failed_factorisation_as_minus_infinity():
     assert np.array_equal(np.isneginf(out[0][1]), np.isneginf(out[1][1])) and np.isneginf(out[0][1]).any()
 
 
+_LOOP_CHILD = r"""
+import sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+from test_gpu_resident import _loopback_run
+ref, results = _loopback_run(2, 1100, 4, 32, 4, 1, False)
+same = all(np.array_equal(a, b) for got in results for a, b in zip(ref[:5], got[:5]))
+print("RESULT " + json.dumps({"same": bool(same), "redone": [int(got[5][1]) for got in results], "ref_redone": int(ref[5][1])}))
+"""
+
+
+def test_a_launch_free_time_out_on_a_rank_of_a_sharded_run_makes_every_rank_redo_it():
+    """Two loop-back ranks with the launch-free factorisation forced on and a wait bound no wait can meet: each rank's pack kernel
+    reads its kernel's error word on the device and sends "redo" as its status word; EVERY rank's step kernel sees the words of
+    all ranks, and at the end every rank redoes the whole run on the launch schedule (the same number of collectives again) --
+    chains identical to the single-context run, `info[1] == 1` everywhere."""
+    res = subprocess.run([sys.executable, "-c", _LOOP_CHILD % (ROOT, os.path.join(ROOT, "tests"))],
+                         env=dict(os.environ, BGP_PS_TIMEOUT_TICKS="200"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    # (the single-context reference run met its time-out in the start ensemble's evaluation already and sits in the cool-down)
+    assert d["same"] and d["redone"] == [1, 1], d
+    assert "timed out" in res.stderr
+
+
 _CHILD = r"""
 import sys, json
 sys.path.insert(0, %r)
