@@ -38,7 +38,8 @@ def _sample(n, d, walkers, steps, resident, kernel=None, seed=11, **kw):
 
 
 # (the last case: 80 proposals per half-step = two walker groups on their own streams behind the step kernel)
-@pytest.mark.parametrize("n,d,walkers,steps", [(128, 2, 100, 30), (300, 3, 40, 12), (1024, 8, 32, 6), (256, 2, 160, 5)])
+# (... and BASELINE config C's own shape: n = 2048, d = 16, 256 walkers -- 128 matrices per half-step on two walker-group streams)
+@pytest.mark.parametrize("n,d,walkers,steps", [(128, 2, 100, 30), (300, 3, 40, 12), (1024, 8, 32, 6), (256, 2, 160, 5), (2048, 16, 256, 2)])
 def test_resident_run_replays_the_host_driven_chain(n, d, walkers, steps):
     g0, s0 = _sample(n, d, walkers, steps, resident=False)
     g1, s1 = _sample(n, d, walkers, steps, resident=True)
