@@ -14,7 +14,8 @@
 //         element (row, k) lives at byte  row*128 + (((k>>1) ^ ((row>>1)&7)) << 4) + ((k&1) << 3);
 //   * the subtraction rides on the MFMA's A-negate modifier (blgp = 1 on the f64 forms): no VALU in the loop;
 //   * fragments of k-step kk+1 are read while k-step kk multiplies;
-//   * tile edge T = 64 (each wave a 32x32 block, 66 VGPRs, 32 KB of LDS: five workgroups = 20 waves per CU)
+//   * tile edge T = 64 (each wave a 32x32 block, 70 VGPRs, 32 KB of LDS: FOUR workgroups = 16 waves per CU -- the LDS is handed out
+//     in granules of 1 280 B, a 32 768-byte workgroup takes 26 of a CU's 128: tools/wg_launch_probe.hip, round 6)
 //     is what the library launches: measured on MI355X it ties the 128x128 tile (two workgroups per CU) on the
 //     largest launch of BASELINE config C (62.6 vs 63.0 TF) although it moves twice the bytes per flop from
 //     L2 and LDS, and wins everywhere else (B=16: 62.5 vs 55.4 TF; 320 tiles: 43 vs 28 TF) because small
