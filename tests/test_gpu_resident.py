@@ -69,8 +69,8 @@ def test_resident_run_with_fixed_and_isotropic_kernel_parts():
 
 
 def test_cases_that_stay_on_the_host(capfd):
-    """What is left for the host-driven loop: a prior the device cannot evaluate, an odd ensemble -- and each says so on stderr,
-    once per process.  (Progress bars, warped inputs and ensembles beyond the step kernel's LDS run resident: below.)"""
+    """What is left for the host-driven loop: a prior the device cannot evaluate, an odd ensemble, a kernel tree without a canonical
+    device form -- and each says so on stderr, once per process.  (Progress bars, warped inputs and ensembles beyond the step kernel's LDS run resident: below.)"""
     from bayes_skopt_amd import sampler as sampler_module
 
     sampler_module._told.clear()  # (once per PROCESS: earlier tests of this process may have said the same things)
@@ -82,8 +82,14 @@ def test_cases_that_stay_on_the_host(capfd):
     assert getattr(s, "resident_runs", 0) == 0
     _, s = _sample(128, d, 21, 4, resident=True)
     assert getattr(s, "resident_runs", 0) == 0
+    from sklearn.gaussian_process.kernels import Matern
+
+    _, s = _sample(128, d, 20, 4, resident=True, kernel=Matern(length_scale=0.5, nu=2.5) + Matern(length_scale=2.0, nu=1.5),
+                   priors=[lambda t: -0.5 * t * t] * 2)
+    assert getattr(s, "resident_runs", 0) == 0
     err = capfd.readouterr().err
-    assert err.count("driven from the host") == 2 and "not one of the families" in err and "odd number of walkers" in err
+    assert err.count("driven from the host") == 3 and "not one of the families" in err and "odd number of walkers" in err
+    assert "no canonical device form" in err
     # asked for: not a fallback, nothing to say
     _, s = _sample(128, d, 20, 4, resident=False)
     assert getattr(s, "resident_runs", 0) == 0 and "driven from the host" not in capfd.readouterr().err
