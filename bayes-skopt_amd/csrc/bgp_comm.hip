@@ -81,7 +81,9 @@ int load_rccl() {
 struct LoopGroup {
   std::mutex mu;
   std::condition_variable cv;
-  int world = 0, members = 0, arrived = 0, aborted = 0;
+  int world = 0, members = 0, arrived = 0;
+  int aborted = 0;  // bgp_comm_abort by a member: enqueued work may never complete
+  int left = 0;     // a member has been destroyed: nobody can MEET any more (what is enqueued still completes)
   unsigned long long generation = 0;
   double* dshared[2] = {nullptr, nullptr};  // 2 x world x LOOP_SLOT doubles
   std::vector<hipEvent_t> ev[2];            // per parity: one event per rank
@@ -328,7 +330,7 @@ extern "C" void bgp_comm_destroy(bgp_comm* c) {
     bool last;
     {
       std::lock_guard<std::mutex> lock(g->mu);
-      g->aborted = 1;  // (a member leaving ends the group for the others)
+      g->left = 1;  // (a member leaving ends the group's meetings; a peer still waiting for its complete run is not disturbed)
       g->cv.notify_all();
       last = --g->members == 0;
     }
@@ -525,8 +527,8 @@ const double* bgp_comm_recv(bgp_comm* c, size_t doubles) {
 
 static int loop_meet(LoopGroup* g, const char* what) {
   std::unique_lock<std::mutex> lock(g->mu);
-  if (g->aborted) {
-    bgp_set_error("%s: the loop-back group was aborted", what);
+  if (g->aborted || g->left) {
+    bgp_set_error("%s: the loop-back group was aborted, or a member has left it", what);
     return BGP_ERR_COMM;
   }
   const unsigned long long gen = g->generation;
@@ -536,8 +538,8 @@ static int loop_meet(LoopGroup* g, const char* what) {
     g->cv.notify_all();
     return BGP_OK;
   }
-  const bool ok = g->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return g->generation != gen || g->aborted; });
-  if (!ok || g->aborted) {
+  const bool ok = g->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return g->generation != gen || g->aborted || g->left; });
+  if (!ok || g->generation == gen) {
     g->aborted = 1;
     g->cv.notify_all();
     bgp_set_error("%s: a rank of the loop-back group did not arrive (or the group was aborted)", what);

@@ -164,9 +164,9 @@ struct DevBlock {  // one allocation for the whole run, released with it
 };
 }  // namespace
 
-// An open run (bgp_mcmc_begin .. bgp_mcmc_end): device block, kernel arguments, how far the plan has been enqueued, and host
-// copies of the start ensemble and of the plan handed over so far (a run whose launch-free factorisation timed out is redone
-// from them on the launch schedule).
+// An open run (bgp_mcmc_begin .. bgp_mcmc_end): device block, kernel arguments, how far the plan has been enqueued, and a host
+// copy of the start ensemble (a run whose launch-free factorisation timed out is redone on the launch schedule from it and from
+// the plan, which stays on the device).
 struct bgp_mcmc_state {
   DevBlock blk;
   McmcArgs a;
@@ -178,8 +178,7 @@ struct bgp_mcmc_state {
   bool warped = false;  // walkers carry their own input warp
   bgp_comm* comm = nullptr;  // sharded ensemble: the communicator whose ranks share the half-steps' proposal blocks
   int per = 0;               // ... rows per rank (ceil(Ns / world)): the all-gather moves per + 1 doubles per rank
-  std::vector<double> coords0, logp0, zz, factors, logu;
-  std::vector<int> movers, partners;
+  std::vector<double> coords0, logp0;
   std::vector<hipEvent_t> seg_ev;  // one event behind every segment handed over (bgp_mcmc_progress)
   std::vector<int> seg_steps;      // steps complete when that event has passed
   int seg_done = 0;                // events known to have passed
@@ -410,11 +409,6 @@ extern "C" int bgp_mcmc_steps(bgp_ctx* c, int nseg, const int* movers, const int
   if (r->failed) return r->failed;
   BGP_HIP(hipSetDevice(c->device));
   const size_t cnt = (size_t)2 * nseg * a.Ns, off = (size_t)r->enq_half * a.Ns;
-  r->movers.insert(r->movers.end(), movers, movers + cnt);
-  r->partners.insert(r->partners.end(), partners, partners + cnt);
-  r->zz.insert(r->zz.end(), zz, zz + cnt);
-  r->factors.insert(r->factors.end(), factors, factors + cnt);
-  r->logu.insert(r->logu.end(), logu, logu + cnt);
   hipStream_t st = c->stream;
   int rc = BGP_OK;
   auto up = [&](const void* dst, const void* src, size_t bytes) {
