@@ -10,18 +10,31 @@ C-ABI of ``include/bgp.h`` (``lib/libbgp.so``), bound with ctypes.  No CPU fallb
 __version__ = "0.1.0"
 
 from . import _lib, acquisition, distributed, init, kernels, priors, sampler, searchcv, space, utils  # noqa: F401
+from .acquisition import *  # noqa: F401,F403  (bask/__init__.py:12: the acquisition classes are top-level names)
 from .bayesgpr import BayesGPR
+from .init import r2_sequence, sb_sequence
 from .optimizer import Optimizer
 from .searchcv import BayesSearchCV
-from .utils import construct_default_kernel, geometric_median, guess_priors, r2_sequence  # noqa: F401
+from .utils import construct_default_kernel, geometric_median, guess_priors  # noqa: F401
 
+# bask/__init__.py:19-35, name for name, then this package's additions
 __all__ = [
     "BayesGPR",
-    "BayesSearchCV",
     "Optimizer",
+    "BayesSearchCV",
+    "guess_priors",
+    "evaluate_acquisitions",
+    "ExpectedImprovement",
+    "TopTwoEI",
+    "Expectation",
+    "LCB",
+    "MaxValueSearch",
+    "r2_sequence",
+    "sb_sequence",
+    "ThompsonSampling",
+    "VarianceReduction",
+    "PVRS",
     "acquisition",
     "geometric_median",
-    "guess_priors",
     "construct_default_kernel",
-    "r2_sequence",
 ]

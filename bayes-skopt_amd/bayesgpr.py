@@ -153,7 +153,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             raise ValueError(f"alpha must be a scalar or an array with same number of entries as y. "
                              f"({alpha_diag.shape[0]} != {n})")
         plan = analyse_kernel(self.kernel_)
-        want_batch = int(self.max_batch or batch_hint or 64)
+        want_batch = int(self.max_batch or batch_hint or getattr(self, "_batch_wish", None) or 64)
         ctx = self._ctx_obj
         if (ctx is None or ctx.d != X.shape[1] or ctx.form != plan.form or ctx.stationary != plan.stationary
                 or ctx.max_batch < want_batch):
@@ -575,6 +575,9 @@ class BayesGPR(RegressorMixin, BaseEstimator):
             y_std = np.std(y, axis=0)
             noise_vector = np.array(noise_vector) / np.power(y_std, 2)
         self._apply_noise_vector(len(y), noise_vector)
+        # the context the MAP start creates is the one the sampler wants (a second allocation of the matrix workspace otherwise:
+        # 2 x 15 ms + 5 ms of release at n = 2048 x 128 matrices, tools/fit_cprofile.py)
+        self._batch_wish = (int(n_threads) * int(n_walkers_per_thread) + 1) // 2
         self._map_fit(X, y)
         self.sample(
             n_threads=n_threads,

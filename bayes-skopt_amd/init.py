@@ -23,6 +23,11 @@ def _generalised_golden_ratio(d, n_iter=10):
     return x
 
 
+def phi(d, n_iter=10):
+    """The reference's public name of the generalised golden ratio (``bask/init.py:90``)."""
+    return _generalised_golden_ratio(d, n_iter)
+
+
 def r2_sequence(n, d, seed=0.5):
     """First n points of the R_d additive-recurrence quasi-random sequence
     (``bask/init.py:101-128``): z_i = (seed + i * alpha) mod 1, alpha_j = phi_d^-(j+1) mod 1."""

@@ -302,6 +302,12 @@ class _NoBar:
     def close(self):
         pass
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
 
 def _progress(progress, total):
     if progress:

@@ -9,7 +9,8 @@ from .init import r2_sequence  # noqa: F401  (re-exported like bask/utils.py:8-9
 from .kernels import ConstantKernel, Matern
 from .priors import halfnorm_logpdf_logspace, make_roundflat
 
-__all__ = ["expected_minimum", "hdi", "geometric_median", "guess_priors", "construct_default_kernel", "validate_zeroone", "r2_sequence"]
+__all__ = ["expected_minimum", "hdi", "geometric_median", "guess_priors", "construct_default_kernel", "validate_zeroone", "r2_sequence",
+           "get_progress_bar"]
 
 
 def geometric_median(X, eps=1e-5):
@@ -181,3 +182,11 @@ def hdi(samples, hdi_prob=0.95, multimodal=False, max_modes=10, grid=512):
     step = bins[1] - bins[0]
     runs = np.split(keep, np.where(np.diff(keep) >= step * 1.1)[0] + 1)
     return np.array([[r[0], r[-1]] for r in runs[:max_modes]])
+
+
+def get_progress_bar(display, total):
+    """``bask/utils.py:198-209``: a tqdm bar of ``total`` ticks when ``display is True``, an object with the same ``update`` /
+    ``close`` / context-manager interface that does nothing otherwise (or when tqdm cannot be imported)."""
+    from .sampler import _progress
+
+    return _progress(display is True, total)

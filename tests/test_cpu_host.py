@@ -142,6 +142,39 @@ def test_validate_zeroone(bask):
         bask.utils.validate_zeroone([-0.1, 0.2])
 
 
+def test_top_level_names_are_the_reference_packages(bask):
+    """``import bayes_skopt_amd as bask`` offers every name ``bask/__init__.py:19-35`` exports (the acquisition classes are
+    top-level names there), the helpers other modules of the reference import (``bask/utils.py:198`` ``get_progress_bar``,
+    ``bask/init.py:90`` ``phi``), and the constructors / methods take the reference's arguments in the reference's order."""
+    import inspect
+
+    for name in ("BayesGPR", "Optimizer", "BayesSearchCV", "guess_priors", "evaluate_acquisitions", "ExpectedImprovement",
+                 "TopTwoEI", "Expectation", "LCB", "MaxValueSearch", "r2_sequence", "sb_sequence", "ThompsonSampling",
+                 "VarianceReduction", "PVRS"):
+        assert name in bask.__all__ and getattr(bask, name) is not None, name
+    with bask.utils.get_progress_bar(False, 3) as bar:
+        bar.update(1)
+    assert bask.init.phi(1) == pytest.approx((1 + 5 ** 0.5) / 2) and bask.init.phi(2) ** 3 == pytest.approx(bask.init.phi(2) + 1)
+    x = bask.init.phi(5, n_iter=60)
+    assert x ** 6 == pytest.approx(x + 1)
+
+    def leading(f, names):
+        got = list(inspect.signature(f).parameters)[: len(names)]
+        assert got == names, (f.__qualname__, got)
+
+    leading(bask.BayesGPR.__init__, ["self", "kernel", "alpha", "optimizer", "n_restarts_optimizer", "normalize_y", "warp_inputs",
+                                     "copy_X_train", "random_state", "noise"])
+    leading(bask.BayesGPR.fit, ["self", "X", "y", "noise_vector", "n_threads", "n_desired_samples", "n_burnin",
+                                "n_walkers_per_thread", "progress", "priors", "warp_priors", "position"])
+    leading(bask.BayesGPR.sample, ["self", "X", "y", "noise_vector", "n_threads", "n_desired_samples", "n_burnin", "n_thin",
+                                   "n_walkers_per_thread", "progress", "priors", "warp_priors", "position", "add"])
+    leading(bask.BayesGPR.predict, ["self", "X", "return_std", "return_cov", "return_mean_grad", "return_std_grad"])
+    leading(bask.BayesGPR.sample_y, ["self", "X", "sample_mean", "noise", "n_samples", "random_state"])
+    leading(bask.Optimizer.tell, ["self", "x", "y", "noise_vector", "fit", "replace", "n_samples", "gp_samples", "gp_burnin",
+                                  "progress"])
+    leading(bask.evaluate_acquisitions, ["X", "gpr", "acquisition_functions", "n_samples", "progress", "random_state"])
+
+
 def test_init_sequences(bask):
     """reference tests/test_init.py:6-21"""
     assert bask.init.sb_sequence(3, 2, random_state=0).shape == (3, 2)
