@@ -116,6 +116,7 @@ SIGNATURES = {
     "bgp_debug_workspace": (C.c_int, [_vp, C.c_int, _dp, _dp]),
     "bgp_debug_cov_factor": (C.c_int, [_vp, _ip, _dp]),
     "bgp_persist_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
+    "bgp_lml_gen_stats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
     "bgp_debug_ps_trace": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong), C.c_size_t]),
     "bgp_debug_pivot_root": (C.c_int, [C.c_int, C.c_int, _dp, _dp, _dp]),
     "bgp_bench_mfma_f64": (C.c_int, [C.c_int, C.c_int, _dp]),
@@ -581,6 +582,13 @@ class Context:
         v = (C.c_longlong * 4)()
         _check(self._lib.bgp_persist_stats(self._h, v), "bgp_persist_stats")
         return {"calls": int(v[0]), "timeouts": int(v[1]), "disabled": bool(v[2]), "cooldown_left": int(v[3])}
+
+    def gen_stats(self):
+        """LML batches whose kernel-matrix blocks (all but block column 0) were generated inside the trailing update of the first
+        panel group, and the generating launches among their updates (bgp_lml_gen_stats)."""
+        v = (C.c_longlong * 2)()
+        _check(self._lib.bgp_lml_gen_stats(self._h, v), "bgp_lml_gen_stats")
+        return {"batches": int(v[0]), "launches": int(v[1])}
 
     def ps_trace(self):
         """In-kernel timeline of the last launch-free call (needs BGP_PS_TRACE=1 at context creation): (chain, tile) --

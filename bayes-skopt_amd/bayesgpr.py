@@ -577,7 +577,7 @@ class BayesGPR(RegressorMixin, BaseEstimator):
         self._apply_noise_vector(len(y), noise_vector)
         # the context the MAP start creates is the one the sampler wants (a second allocation of the matrix workspace otherwise:
         # 2 x 15 ms + 5 ms of release at n = 2048 x 128 matrices, tools/fit_cprofile.py)
-        self._batch_wish = (int(n_threads) * int(n_walkers_per_thread) + 1) // 2
+        self._batch_wish = max(64, (int(n_threads) * int(n_walkers_per_thread) + 1) // 2)  # (64: the default without a wish)
         self._map_fit(X, y)
         self.sample(
             n_threads=n_threads,

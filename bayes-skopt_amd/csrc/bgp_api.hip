@@ -293,7 +293,7 @@ static void warn_unknown_env_once() {
   done = true;
   static const char* known[] = {"BGP_COMM_DIR", "BGP_COMM_PORT", "BGP_COMM_TCP", "BGP_DIST_BACKEND", "BGP_DIST_FORCE",
                                 "BGP_COMM_JOB", "BGP_BENCH_TIMEOUT", "BGP_DEBUG_TIMES", "BGP_PANELS", "BGP_NO_ENV_DEFAULTS",
-                                "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_GEN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
+                                "BGP_PERSIST", "BGP_PS_COOLDOWN", "BGP_PS_GEN", "BGP_SYRK_GEN", "BGP_PS_PAIR", "BGP_PS_TIMEOUT_MS", "BGP_PS_TIMEOUT_TICKS", "BGP_PS_TRACE", "BGP_STREAMS", "BGP_WAIT", "BGP_COMM_TIMEOUT_S"};
   for (char** e = environ; e && *e; e++) {
     if (strncmp(*e, "BGP_", 4) != 0) continue;
     const char* eq = strchr(*e, '=');
@@ -492,6 +492,14 @@ int bgp_ps_cooldown_calls() {
   return v;
 }
 
+// See include/bgp.h.
+extern "C" int bgp_lml_gen_stats(bgp_ctx* c, long long* out) {
+  if (!c || !out) return BGP_ERR_INVALID;
+  out[0] = c->gen_batches;
+  out[1] = c->gen_launches;
+  return BGP_OK;
+}
+
 // Launch-free path bookkeeping of a context: out[0] = launch-free calls enqueued, out[1] = of which timed out (redone by
 // launches), out[2] = 1 while the path is switched off by a time-out, out[3] = eligible calls left before it is tried again
 // (0 with out[2] == 1: off for good after three time-outs, until bgp_set_persist(ctx, 1)).
@@ -578,13 +586,14 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
     // per-walker Beta-CDF warp of the design matrix, then the right-looking path on per-walker inputs
     rc = bgp_launch_warp(c, c->stream, c->dX, c->dwarpB, c->dXwB, c->n, nb, nd);
     if (rc) return rc;
-    rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, 0, 0, 1, c->dXwB, nd);
+    const int gen = !use_ps && bgp_lml_gen_eligible(c, nb);
+    rc = bgp_launch_kbuild_x(c, 0, nb, c->stream, gen ? 2 : 0, 0, 1, c->dXwB, nd);
     if (rc) return rc;
     if (use_ps) {
       rc = bgp_launch_cholesky_persist(c, nb, 0);
       if (!rc) c->ps_inflight = 1;
     } else {
-      rc = bgp_launch_cholesky(c, nb, 0);
+      rc = bgp_launch_cholesky_slice(c, 0, nb, c->stream, 0, gen);
     }
     if (rc) return rc;
   } else if (use_ps) {
@@ -593,9 +602,11 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
     if (rc) return rc;
     c->ps_inflight = 1;
   } else if (ng == 1) {
-    rc = bgp_launch_kbuild(c, nb, 0, 0, 1);
+    // (gen: the Gram kernel builds block column 0, the first panel group's updates generate the rest in their accumulators)
+    const int gen = bgp_lml_gen_eligible(c, nb);
+    rc = bgp_launch_kbuild(c, nb, gen ? 2 : 0, 0, 1);
     if (rc) return rc;
-    rc = bgp_launch_cholesky(c, nb, 0);
+    rc = bgp_launch_cholesky_slice(c, 0, nb, c->stream, 0, gen);
     if (rc) return rc;
   } else {
     BGP_HIP(hipEventRecord(c->ev_ready, c->stream));
@@ -603,9 +614,10 @@ int bgp_lml_enqueue_dev(bgp_ctx* c, int nb, int warped) {
       const int gb = std::min(gsz, nb - o);
       hipStream_t st = c->gstream[g];
       BGP_HIP(hipStreamWaitEvent(st, c->ev_ready, 0));
-      rc = bgp_launch_kbuild_slice(c, o, gb, st, 0, 0, 1);
+      const int gen = bgp_lml_gen_eligible(c, gb);
+      rc = bgp_launch_kbuild_slice(c, o, gb, st, gen ? 2 : 0, 0, 1);
       if (rc) return rc;
-      rc = bgp_launch_cholesky_slice(c, o, gb, st, 0);
+      rc = bgp_launch_cholesky_slice(c, o, gb, st, 0, gen);
       if (rc) return rc;
       BGP_HIP(hipEventRecord(c->ev_done[g], st));
       BGP_HIP(hipStreamWaitEvent(c->stream, c->ev_done[g], 0));

@@ -422,11 +422,16 @@ int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st) {
   return BGP_OK;
 }
 
+void bgp_launch_syrk4_gen(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+                          int K, int jstart, int colmode, int B, const S4Gen& gen, int stationary, int form);
+
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented) {
   return bgp_launch_cholesky_slice(ctx, 0, B, ctx->stream, augmented);
 }
 
-int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented) {
+// gen != 0 (LML path): only block column 0 of the kernel matrices has been built (bgp_launch_kbuild_x, full_square = 2); the
+// updates of the first panel group generate every other block as they touch it first.
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, int gen) {
   // augmented == 0: LML only (matrices npad x npad).  augmented != 0: posterior build on the
   // (2 npad) x (2 npad) augmented matrices [[K, .], [I, 0]] (see bgp_rowblk).
   const int nblk = ctx->nblk, npad = ctx->npad;
@@ -449,6 +454,12 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
     // with the LDS-DMA kernels, whose look-ahead column launches are cheap enough), 2 below (P = 2, 3, 4 are equal
     // within noise at n = 1024); BGP_PANELS fixes it.
     const int P = ctx->panels_auto ? (nblk >= 12 ? 4 : 2) : ctx->panels;
+    S4Gen ga{};
+    if (gen) {
+      const int rcg = bgp_lml_gen_args(ctx, off, &ga);
+      if (rcg) return rcg;
+      ctx->gen_batches++;
+    }
     int k = 0;
     while (k < nblk) {
       const int np = std::min(P, nblk - k);
@@ -463,14 +474,23 @@ int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int 
         bgp_tend(ctx, st);
         if (j + 1 < np) {  // look-ahead: block column k+j+1 with the panels k .. k+j
           bgp_tbegin(ctx, 5, st);
-          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
+          if (gen && k == 0) {
+            bgp_launch_syrk4_gen(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B, ga, ctx->ks.stationary,
+                                 ctx->ks.form);
+            ctx->gen_launches++;
+          } else
+            bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * (j + 1), k + j + 1, 1, B);
           bgp_tend(ctx, st);
         }
       }
       const int nt = nblk - (k + np);
       if (nt > 0) {
         bgp_tbegin(ctx, 3, st);
-        bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
+        if (gen && k == 0) {
+          bgp_launch_syrk4_gen(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B, ga, ctx->ks.stationary, ctx->ks.form);
+          ctx->gen_launches++;
+        } else
+          bgp_launch_syrk4(st, B8, dK, dstatus, ld, mstride, nblk, k, 128 * np, k + np, 0, B);
         bgp_tend(ctx, st);
       }
       k += np;

@@ -194,6 +194,7 @@ struct bgp_ctx {
   int ps_inflight = 0;          // a persistent call is on the stream (its error word is checked behind the sync)
   int ps_disabled = 0;          // a persistent call timed out: multi-launch path (see bgp_ps_note_timeout)
   int ps_cooldown = 0;          // eligible calls left on the multi-launch path before the launch-free one is tried again
+  long long gen_batches = 0, gen_launches = 0;  // bgp_lml_gen_stats
   long long ps_calls = 0;       // launch-free calls enqueued by this context (bgp_persist_stats)
   long long ps_timeouts = 0;    // ... of which timed out and were redone by launches
   int pending_warped = 0;       // the pending batch carries per-walker warps (redo path of bgp_lml_batch_wait)
@@ -410,4 +411,12 @@ int bgp_launch_warp(bgp_ctx* c, hipStream_t st, const double* dX, const double* 
 int bgp_launch_cholesky(bgp_ctx* ctx, int B, int augmented);
 // n <= 128: K-build + factorisation + LML of the slice [off, off+B) in ONE launch (bgp_chol.hip, potrf_kernel<1,..>)
 int bgp_launch_lml_small(bgp_ctx* ctx, int off, int B, hipStream_t st);
-int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented);
+int bgp_launch_cholesky_slice(bgp_ctx* ctx, int off, int B, hipStream_t st, int augmented, int gen = 0);
+struct S4Gen {           // what the trailing update's Gram generator reads (S4GenF, bgp_s4.h)
+  const double* Xs;     // scaled inputs, k-major: dpad x npad doubles per matrix slot
+  const double* H;      // canonical hyper-parameters, d + 2 per matrix
+  const double* alpha;  // per-point jitter added to the diagonal (nullable)
+  int n, d, dpad, npad;
+};
+int bgp_lml_gen_eligible(const bgp_ctx* ctx, int B);
+int bgp_lml_gen_args(const bgp_ctx* ctx, int off, S4Gen* out);

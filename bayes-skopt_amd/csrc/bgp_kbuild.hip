@@ -289,7 +289,9 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
                         const double* dXb, size_t xstride) {
   const int nblk = ctx->nblk, npad = ctx->npad, d = ctx->d;
   const size_t ldm = augmented ? 2 * (size_t)npad : (size_t)npad;
-  const int ntiles = full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
+  // full_square == 2: block column 0 only (the trailing update generates the other blocks at first touch, S4GenF in bgp_s4.h,
+  // from the scaled inputs the pipelined build leaves behind: always that build)
+  const int ntiles = (full_square == 2) ? nblk : full_square ? nblk * nblk : nblk * (nblk + 1) / 2;
   const int B8 = 8 * ((B + 7) / 8);
   double* dKo = ctx->dK + (size_t)off * ldm * ldm;
   const double* dH = ctx->dh + (size_t)off * (d + 2);
@@ -297,7 +299,7 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   bgp_tbegin(ctx, 0, st);
   // the pipelined build pays a second (tiny) launch and groups KB2_TPW tiles per workgroup: below ~2000 tiles the
   // plain kernel is faster (n = 1024 x 32 walkers: 0.069 vs 0.10 ms)
-  if (B8 * ntiles < 2048) {
+  if (full_square != 2 && B8 * ntiles < 2048) {
     KB_DISPATCH(ctx->ks.stationary, ctx->ks.form,
                 hipLaunchKernelGGL((kbuild_gram_kernel<S, F>), dim3(B8 * ntiles), dim3(256), 0, st, dXb, ctx->dalpha, dH,
                                    dKo, ctx->dy, dywo, ctx->n, d, npad, nblk, B, full_square, (int)ldm, use_alpha,
@@ -318,6 +320,34 @@ int bgp_launch_kbuild_x(bgp_ctx* ctx, int off, int B, hipStream_t st, int full_s
   }
   bgp_tend(ctx, st);
   BGP_HIP(hipGetLastError());
+  return BGP_OK;
+}
+
+// Gram generation inside the trailing update (bgp_launch_cholesky_slice's `gen`): where the pipelined build would run anyway
+// (the same threshold), on matrices of at least two block columns with at most 16 input dimensions (one staging pass; at d = 32
+// the generator measured +1.2 % / -0.1 % at n = 4096 x 8 / 16 matrices, against -2 .. -4.5 % at d <= 16 from 32 matrices on:
+// tools/gen_shapes_probe.py); BGP_SYRK_GEN=0 switches it off (A/B measurements).
+int bgp_lml_gen_eligible(const bgp_ctx* ctx, int B) {
+  const char* e = getenv("BGP_SYRK_GEN");  // (read per call: the tests flip it inside one process)
+  const int on = (e && e[0] == '0') ? 0 : 1;
+  const int B8 = 8 * ((B + 7) / 8);
+  return on && ctx->d <= KB_DK && ctx->nblk >= 2 && B8 * (ctx->nblk * (ctx->nblk + 1) / 2) >= 2048;
+}
+
+// ... and what the generator reads: the scaled inputs of the batch slice at `off` (written by the build of block column 0)
+int bgp_lml_gen_args(const bgp_ctx* ctx, int off, S4Gen* out) {
+  const int dpad = ((ctx->d + KB_DK - 1) / KB_DK) * KB_DK;
+  if (!ctx->dXs || (size_t)ctx->max_batch * dpad * ctx->npad > ctx->cap_xs) {
+    bgp_set_error("bgp_lml_gen_args: the scaled inputs have not been built");
+    return BGP_ERR_STATE;
+  }
+  out->Xs = ctx->dXs + (size_t)off * dpad * ctx->npad;
+  out->H = ctx->dh + (size_t)off * (ctx->d + 2);
+  out->alpha = ctx->dalpha;
+  out->n = ctx->n;
+  out->d = ctx->d;
+  out->dpad = dpad;
+  out->npad = ctx->npad;
   return BGP_OK;
 }
 

@@ -111,13 +111,142 @@ struct S4Tile {
     }                                                                    \
   } while (0)
 
+// ---- Gram generation at first touch (the trailing update of the FIRST panel group, bgp_chol.hip) ----
+// The update that touches a block of the kernel matrix first does not load it: every lane computes the Gram values of its own
+// accumulator entries -- from the k-major pre-scaled inputs xscale_kernel wrote for kbuild2_kernel, with kbuild2's arithmetic per
+// element (differences and fma in ascending dimension, kb_stationary, constant, exact diagonal, identity padding: same bits) --
+// while the first operand chunk is in flight; the Gram kernel in front of the factorisation then builds block column 0 only.
+// Why: the build is fp64-VALU bound (VALUBusy 84 %) and the update MFMA bound, and the two pipes of a SIMD work side by side for
+// different waves; and the block is neither written by one kernel nor read back by the next (2 x 2.3 GB per half-step at
+// n = 2048 x 128 matrices).
+// (struct S4Gen: bgp_common.h)
+struct S4NoGen {
+  static constexpr int active = 0;
+};
+
+// The 64-row slices of the tile's row block and column block for 16 dimensions are staged in the ring's SECOND stage (free until
+// the main loop's first barrier has been passed): xi then xj, 16 x 64 doubles each, rows permuted so that the four rows of a lane's
+// accumulator register quad (row = lq + 4 r) lie side by side.
+template <int STAT, int FORM>
+struct S4GenF {
+  static constexpr int active = 1;
+  S4Gen g;
+  template <int NR, int NC, int CREL>
+  __device__ __forceinline__ void init(const S4Tile& cur, unsigned lds_stage, d4 (&acc)[NR][NC], int r0, int c0, int lane) const {
+#pragma clang fp contract(off)
+    typedef __attribute__((address_space(3))) double* lds_dp;
+    typedef __attribute__((address_space(3))) const double* lds_cdp;
+    typedef __attribute__((address_space(3))) const d2* lds_cd2p;
+    const int tid = threadIdx.x, lr = lane & 15, lq = lane >> 4;
+    const double* Xb = g.Xs + (size_t)cur.b * g.dpad * g.npad;
+    const double* h = g.H + (size_t)cur.b * (g.d + 2);
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const int sk = tid >> 4, sseg = tid & 15;  // staging: dimension sk, rows 4 sseg .. 4 sseg + 3 of both slices
+    {  // (dpad == 16: one pass over the input dimensions -- bgp_lml_gen_eligible)
+      {
+        const double* src = Xb + (size_t)sk * g.npad;
+        const d2 a0 = *reinterpret_cast<const d2*>(src + cur.gi0 + 4 * sseg), a1 = *reinterpret_cast<const d2*>(src + cur.gi0 + 4 * sseg + 2);
+        const d2 b0 = *reinterpret_cast<const d2*>(src + cur.gj0 + 4 * sseg), b1 = *reinterpret_cast<const d2*>(src + cur.gj0 + 4 * sseg + 2);
+        // row rho = 4 sseg + e of the slice -> slot (rho & 48) + (rho & 3) * 4 + ((rho >> 2) & 3)
+        const unsigned slot = (unsigned)(((4 * sseg) & 48) + ((sseg & 3)));
+        const unsigned wi = lds_stage + (unsigned)(sk * 64 + slot) * 8u, wj = wi + 8192u;
+        *(lds_dp)(uintptr_t)(wi) = a0[0];
+        *(lds_dp)(uintptr_t)(wi + 32u) = a0[1];
+        *(lds_dp)(uintptr_t)(wi + 64u) = a1[0];
+        *(lds_dp)(uintptr_t)(wi + 96u) = a1[1];
+        *(lds_dp)(uintptr_t)(wj) = b0[0];
+        *(lds_dp)(uintptr_t)(wj + 32u) = b0[1];
+        *(lds_dp)(uintptr_t)(wj + 64u) = b1[0];
+        *(lds_dp)(uintptr_t)(wj + 96u) = b1[1];
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int k = 0; k < S4_KC; k++) {
+        double a[NR][4], b[NC];
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+          const unsigned ra = lds_stage + (unsigned)(k * 64 + r0 + 16 * i + 4 * lq) * 8u;
+          const d2 lo = *(lds_cd2p)(uintptr_t)(ra), hi = *(lds_cd2p)(uintptr_t)(ra + 16u);
+          a[i][0] = lo[0];
+          a[i][1] = lo[1];
+          a[i][2] = hi[0];
+          a[i][3] = hi[1];
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+          // (column c of the slice sits at its permuted slot too)
+          const int cc = c0 + 16 * j + lr;
+          b[j] = *(lds_cdp)(uintptr_t)(lds_stage + 8192u + (unsigned)(k * 64 + (cc & 48) + (cc & 3) * 4 + ((cc >> 2) & 3)) * 8u);
+        }
+#pragma unroll
+        for (int i = 0; i < NR; i++)
+#pragma unroll
+          for (int j = 0; j < NC; j++) {
+            if (j + CREL > i) continue;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const double df = a[i][r] - b[j];
+              acc[i][j][r] = __builtin_fma(df, df, acc[i][j][r]);
+            }
+          }
+      }
+    }
+    const double cst = exp(h[0]);
+    const bool interior = !cur.diag && cur.gi0 + 64 <= g.n && cur.gj0 + 64 <= g.n;  // (workgroup-uniform)
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < NR; i++)
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+          if (j + CREL > i) continue;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const double sv = kb_stationary<STAT>(acc[i][j][r]);
+            acc[i][j][r] = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+          }
+        }
+      return;
+    }
+    const double s2 = exp(h[g.d + 1]);
+#pragma unroll
+    for (int i = 0; i < NR; i++)
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        if (j + CREL > i) continue;
+        const int gj = cur.gj0 + GK_COLB(c0, j, lane);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int gi = cur.gi0 + GK_ROWB(r0, i, lane, r);
+          double v;
+          if (gi >= g.n || gj >= g.n) {
+            v = (gi == gj) ? 1.0 : 0.0;  // identity padding: log det and z unaffected
+          } else if (gi == gj) {
+            // fill_diagonal(1) (kernels.py:1738) -> c*1 (+1) -> + s2 (White) -> += alpha (_gpr.py:585)
+            const double base = (FORM == BGP_FORM_PRODUCT) ? cst * 1.0 : cst + 1.0;
+            v = (base + s2);
+            if (g.alpha) v += g.alpha[gi];
+          } else {
+            const double sv = kb_stationary<STAT>(acc[i][j][r]);
+            v = (FORM == BGP_FORM_PRODUCT) ? cst * sv : cst + sv;
+          }
+          acc[i][j][r] = v;
+        }
+      }
+  }
+};
+
 // One tile for a wave's NR x NC block at (r0, c0) of the T x T workgroup tile.
 // NEGA = 1: C -= A B^T (the factorisation's update), 0: C += A B^T; ZEROC: C is not loaded (starts from zero); ldc = leading
 // dimension of C when it is not the operands' (gemm4_kernel).
-template <int T, int NR, int NC, int CREL, int VAR, int NEGA = 1, int ZEROC = 0>
+// GENF: S4NoGen, or S4GenF<STAT, FORM> (T = 64): C is generated instead of loaded (every wave of the workgroup must come through
+// here exactly once: the generator has barriers of its own).
+template <int T, int NR, int NC, int CREL, int VAR, int NEGA = 1, int ZEROC = 0, class GENF = S4NoGen>
 static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsigned lds0, const S4Tile& cur,
                                                const unsigned (&voff)[T / 32], int ld, int K, int r0, int c0, int w,
-                                               int lane, int ldc = 0) {
+                                               int lane, int ldc = 0, const GENF& genf = GENF()) {
   if (ldc == 0) ldc = ld;
   constexpr unsigned OPB = T * S4_ROWB, STAGEB = 2 * OPB;
   unsigned pa[4], pb[4];
@@ -131,7 +260,10 @@ static __device__ __forceinline__ void s4_tile(unsigned long long* trace, unsign
   }
   // The empty asm makes hipcc wait for its C loads HERE (its in-order vmcnt wait also covers chunk 0, needed
   // next anyway) instead of at their first use inside the loop, where such a wait would drain the LDS-DMA queue.
-  if (ZEROC) {
+  if constexpr (GENF::active) {
+    static_assert(T == 64 && !ZEROC, "Gram generation is written for the 64 x 64 tile");
+    genf.template init<NR, NC, CREL>(cur, lds0 + STAGEB, acc, r0, c0, lane);
+  } else if (ZEROC) {
 #pragma unroll
     for (int i = 0; i < NR; i++)
 #pragma unroll

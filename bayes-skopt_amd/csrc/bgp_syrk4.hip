@@ -28,10 +28,11 @@
 // (The ring primitives live in bgp_s4.h; the tile workers of the launch-free factorisation, which use them too, in bgp_ps.hip.)
 #include "bgp_s4.h"
 
-template <int T, int VAR>
+// GENF = S4GenF<STAT, FORM>: the launch touches its blocks FIRST (panel group 0): C is generated, not loaded (bgp_s4.h).
+template <int T, int VAR, class GENF = S4NoGen>
 __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
     syrk4_kernel(double* __restrict__ Kbuf, const int* __restrict__ status, int ld, size_t mstride, int nblk, int kp,
-                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace, int pw) {
+                 int K, int jstart, int colmode, int B, int total, unsigned long long* __restrict__ trace, int pw, GENF genf) {
   constexpr unsigned STAGEB = 2 * T * S4_ROWB;
   constexpr int NRF = T / 32;  // MFMA tiles per wave and direction (each wave a T/2 x T/2 block)
   __shared__ __attribute__((aligned(1024))) char smem[2 * STAGEB];
@@ -51,13 +52,13 @@ __global__ void __launch_bounds__(256, (T == 128) ? 2 : 4)
   }
   S4_STAMP(0);
   if (!cur.diag) {
-    s4_tile<T, NRF, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane);
+    s4_tile<T, NRF, NRF, -64, VAR, 1, 0, GENF>(trace, lds0, cur, voff, ld, K, wr * (T / 2), wc * (T / 2), w, lane, 0, genf);
   } else if (w < 2) {
     // Diagonal tile: only its lower triangle is ever read again.  Waves 0 / 1: the two (T/2)^2 triangles on the
     // diagonal; waves 2 / 3: the square below the diagonal cut into two row halves (3/3/2/2 MFMA tiles at T = 64).
-    s4_tile<T, NRF, NRF, 0, VAR>(trace, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane);
+    s4_tile<T, NRF, NRF, 0, VAR, 1, 0, GENF>(trace, lds0, cur, voff, ld, K, w * (T / 2), w * (T / 2), w, lane, 0, genf);
   } else {
-    s4_tile<T, NRF / 2, NRF, -64, VAR>(trace, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane);
+    s4_tile<T, NRF / 2, NRF, -64, VAR, 1, 0, GENF>(trace, lds0, cur, voff, ld, K, T / 2 + (w - 2) * (T / 4), 0, w, lane, 0, genf);
   }
   S4_STAMP(3);
   if ((VAR & 4) && trace && threadIdx.x == 0) trace[(size_t)cur.q * 8 + 7] = wall_clock64();
@@ -68,7 +69,17 @@ void bgp_launch_syrk4(hipStream_t st, int B8, double* dK, const int* dstatus, in
   const int total = B8 * (colmode == 2 ? s4_ntile<64>(nblk, 0) : s4_ntile<64>(nblk - jstart, colmode));
   const int pw = S4_PW;  // tile columns per L2-resident column panel (s4_panel_decode; 4 .. 16 measured within 2 %)
   hipLaunchKernelGGL((syrk4_kernel<64, 0>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K, jstart,
-                     colmode, B, total, nullptr, pw);
+                     colmode, B, total, nullptr, pw, S4NoGen());
+}
+
+// The same launch for blocks no kernel has written yet: their Gram values are generated in the accumulators (S4GenF).
+void bgp_launch_syrk4_gen(hipStream_t st, int B8, double* dK, const int* dstatus, int ld, size_t mstride, int nblk, int kp,
+                          int K, int jstart, int colmode, int B, const S4Gen& gen, int stationary, int form) {
+  const int total = B8 * s4_ntile<64>(nblk - jstart, colmode);
+  const int pw = S4_PW;
+  KB_DISPATCH(stationary, form,
+              hipLaunchKernelGGL((syrk4_kernel<64, 0, S4GenF<S, F>>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride,
+                                 nblk, kp, K, jstart, colmode, B, total, nullptr, pw, S4GenF<S, F>{gen}));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -364,8 +375,8 @@ extern "C" int bgp_debug_launch_syrk4(int T, int var, hipStream_t st, int B8, do
   const int total = B8 * (T == 128 ? s4_ntile<128>(nt, colmode) : s4_ntile<64>(nt, colmode));
 #define S4_CASE(TT, V)                                                                                               \
   if (T == TT && var == V) {                                                                                         \
-    hipLaunchKernelGGL((syrk4_kernel<TT, V>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,    \
-                       jstart, colmode, B, total, trace, S4_PW);                                            \
+    hipLaunchKernelGGL((syrk4_kernel<TT, V, S4NoGen>), dim3(total), dim3(256), 0, st, dK, dstatus, ld, mstride, nblk, kp, K,    \
+                       jstart, colmode, B, total, trace, S4_PW, S4NoGen());                                 \
     return total;                                                                                                    \
   }
   S4_CASE(128, 0) S4_CASE(128, 4) S4_CASE(64, 0) S4_CASE(64, 1) S4_CASE(64, 2) S4_CASE(64, 3) S4_CASE(64, 4)

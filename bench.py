@@ -80,6 +80,19 @@ def trailing_flops_split(n, nb=NB):
     return col, total - col
 
 
+def gram_generated_flops(n, d, nb=NB):
+    """Gram flops the trailing update's generating launches carry when the library builds only block column 0 with the Gram
+    kernel (csrc/bgp_s4.h S4GenF, bgp_lml_gen_stats): (3 d + 14) flop per pair of the lower triangle outside block
+    column 0, split as trailing_flops_split splits the update: (look-ahead columns of the first panel group, its bulk update).
+    Pairs of block column j: nb (n - j nb) - nb^2 / 2 (their sum over all columns is the n^2 / 2 of lml_flops)."""
+    nblk = n // nb
+    np0 = min(4 if nblk >= 12 else 2, nblk)
+    per = lambda j: nb * (n - j * nb) - nb * nb / 2.0  # noqa: E731
+    col = sum(per(j) for j in range(1, np0))
+    bulk = sum(per(j) for j in range(np0, nblk))
+    return col * (3 * d + 14), bulk * (3 * d + 14)
+
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E ~ 8 TB/s (6.29 TB/s measured streaming copy)
 HBM_COPY_MEASURED_GBS = 6290.0
 PIVOT_CHAIN_NS = 81.0      # measured latency of one pivot of the in-register 16 x 16 micro-Cholesky (tools/potrf_bench, PF_TRACE)
@@ -351,6 +364,7 @@ def config_d_roofline(bask_lib, device, peak_tflops):
     ctx.lml(H)  # warm-up
     ctx.set_timing(True)
     reps, syrk_ms, launches, total_ms = 5, 0.0, 0, 0.0
+    gen0 = ctx.gen_stats()["batches"]
     for _ in range(reps):
         lml = ctx.lml(H)
         tm = ctx.last_timing()
@@ -358,16 +372,21 @@ def config_d_roofline(bask_lib, device, peak_tflops):
         launches += tm["syrk"]["launches"]
         total_ms += tm["device_total_ms"]
     ctx.set_timing(False)
+    generated = ctx.gen_stats()["batches"] - gen0 == reps
     t0 = time.perf_counter()
     ctx.lml(H[:1])
     b1_ms = (time.perf_counter() - t0) * 1e3
     ctx.close()
     flops = float(sum(trailing_flops_per_launch(n))) * B * reps
-    achieved = flops / (syrk_ms * 1e-3) / 1e12
+    gen_fl = float(sum(gram_generated_flops(n, d))) * B * reps if generated else 0.0
+    achieved = (flops + gen_fl) / (syrk_ms * 1e-3) / 1e12
     return {
         "workload": f"n={n}, d={d}, {B} matrices per batch (BASELINE config D)",
-        "kernel": "syrk4_kernel<64> (trailing update, four-panel groups: K = 128..512)",
+        "kernel": "syrk4_kernel<64> (trailing update, four-panel groups: K = 128..512"
+        + ("; the first group's launches generate the Gram blocks they touch first)" if generated else ")"),
         "achieved": achieved, "peak": peak_tflops, "unit": "TFLOP/s", "frac": achieved / peak_tflops,
+        "achieved_update_only": flops / (syrk_ms * 1e-3) / 1e12, "frac_update_only": flops / (syrk_ms * 1e-3) / 1e12 / peak_tflops,
+        "gram_generated_gflop_per_factorisation": gen_fl / (B * reps) / 1e9,
         "avg_launch_ms": syrk_ms / max(launches, 1), "launches_per_factorisation": launches // reps,
         "ms_per_batch_of_8": total_ms / reps, "ms_single_matrix_wall": b1_ms,
         "algorithmic_flops_per_factorisation": float(sum(trailing_flops_per_launch(n))),
@@ -910,6 +929,7 @@ def main():
         n_calls += 1
         return out
 
+    gen_before = gp._ctx.gen_stats()
     gp._ctx.lml = timed_lml
     t1 = time.perf_counter()
     sampler.run_mcmc(pos, args.steps, log_prob0=lp, skip_initial_state_check=True)
@@ -925,7 +945,15 @@ def main():
     fl = trailing_flops_per_launch(n)
     syrk_ms, syrk_launches = acc["syrk"]
     flops_per_call = float(sum(fl)) * B
-    achieved = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    # the library builds only block column 0 with the Gram kernel and generates every other block in the accumulators of the first
+    # panel group's updates (bgp_lml_gen_stats): those launches then carry the Gram flops of their blocks as well -- fp64 VALU work
+    # on the SAME pipe as the fp64 MFMAs (tools/dp_share_probe.hip: the two do not overlap on gfx950; one 78.6 TF peak for both)
+    gen_after = gp._ctx.gen_stats()
+    n_streams_timed = 1
+    generated = n_calls > 0 and gen_after["batches"] - gen_before["batches"] >= n_calls * n_streams_timed
+    gen_col_fl, gen_bulk_fl = gram_generated_flops(n, d) if generated else (0.0, 0.0)
+    update_only = flops_per_call * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
+    achieved = (flops_per_call + (gen_col_fl + gen_bulk_fl) * B) * n_calls / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
     # fp64 MFMA peak: min(datasheet, on-box micro-benchmark of back-to-back v_mfma_f64_16x16x4_f64), both stated.  Run
     # right behind the instrumented pass: the chip is power-limited under fp64 MFMA load, so numerator and denominator
     # should see the same clocks
@@ -965,10 +993,12 @@ def main():
     by_kind = None
     if col_ms > 0 and syrk_ms > col_ms:
         by_kind = {
-            "bulk": {"tflops": f_bulk * B * n_calls / ((syrk_ms - col_ms) * 1e-3) / 1e12, "ms_per_half_step": (syrk_ms - col_ms) / n_calls,
-                     "launches_per_half_step": (syrk_launches - col_launches) / n_calls},
-            "look_ahead_columns": {"tflops": f_col * B * n_calls / (col_ms * 1e-3) / 1e12, "ms_per_half_step": col_ms / n_calls,
-                                   "launches_per_half_step": col_launches / n_calls},
+            "bulk": {"tflops": (f_bulk + gen_bulk_fl) * B * n_calls / ((syrk_ms - col_ms) * 1e-3) / 1e12,
+                     "tflops_update_only": f_bulk * B * n_calls / ((syrk_ms - col_ms) * 1e-3) / 1e12,
+                     "ms_per_half_step": (syrk_ms - col_ms) / n_calls, "launches_per_half_step": (syrk_launches - col_launches) / n_calls},
+            "look_ahead_columns": {"tflops": (f_col + gen_col_fl) * B * n_calls / (col_ms * 1e-3) / 1e12,
+                                   "tflops_update_only": f_col * B * n_calls / (col_ms * 1e-3) / 1e12,
+                                   "ms_per_half_step": col_ms / n_calls, "launches_per_half_step": col_launches / n_calls},
         }
         for v in by_kind.values():
             v["frac_of_peak"] = v["tflops"] / peak
@@ -990,8 +1020,13 @@ def main():
     roofline = {
         "bound": "mfma",
         "kernel": "syrk4_kernel<64> (blocked-Cholesky trailing update, four-panel groups K = 128..512, LDS-DMA ring, fp64 "
-        "v_mfma_f64_16x16x4_f64)",
+        "v_mfma_f64_16x16x4_f64" + ("; the first group's launches generate the Gram blocks they touch first in their accumulators)"
+                                    if generated else ")"),
         "achieved": achieved,
+        "achieved_update_only": update_only,
+        "frac_update_only": update_only / peak,
+        "gram_generated_in_kernel": bool(generated),
+        "gram_generated_gflop_per_factorisation": (gen_col_fl + gen_bulk_fl) / 1e9,
         "peak": peak,
         "peak_spec": FP64_MFMA_PEAK_TFLOPS,
         "mfma_peak_measured": mfma_measured,
@@ -1006,7 +1041,9 @@ def main():
         "by_launch_kind": by_kind,
         "note": "measured with all launches on one stream (kernel alone on the GPU); the timed pass overlaps two "
         "walker-group streams. algorithmic flops = sum_j nb*m_j*(m_j+1) per matrix x the matrices of a launch (SURVEY "
-        "8d); peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
+        "8d) + -- when gram_generated_in_kernel -- the (3d+14) flop per pair of the Gram blocks the first panel group's launches "
+        "compute instead of loading (every block outside block column 0; fp64 VALU on the pipe the fp64 MFMAs use); "
+        "achieved_update_only leaves those out; peak = min(datasheet fp64 matrix peak 78.6 TF, bgp_bench_mfma_f64 measured on this box) -- "
         "MI355X_MICROARCH.md has no fp64 row; traffic = HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
         "+ WRITE_SIZE, separate passes; see traffic_source)",
     }
@@ -1022,11 +1059,14 @@ def main():
                                      peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, frac_of_measured_copy=gbs / HBM_COPY_MEASURED_GBS,
                                      algorithmic_gb_per_half_step=hb["trsm"] * B / 1e9, ms_per_half_step=kms["trsm"]))
     if kms["kbuild"] > 0:
-        gbs = hb["kbuild"] * B / (kms["kbuild"] * 1e-3) / 1e9
-        fk = n * n / 2.0 * (3 * d + 14) * B
+        # (generated: the Gram kernel writes block column 0 only -- nblk tiles of the nblk (nblk + 1) / 2)
+        kshare = (2.0 / (n // NB + 1)) if generated else 1.0
+        gbs = hb["kbuild"] * kshare * B / (kms["kbuild"] * 1e-3) / 1e9
+        fk = (n * n / 2.0 * (3 * d + 14) - (gen_col_fl + gen_bulk_fl)) * B
         roofline_kernels.append(dict(kernel="xscale_kernel + kbuild2_kernel (Gram build)", bound="hbm (written once) / fp64 VALU",
                                      achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS,
-                                     algorithmic_gb_per_half_step=hb["kbuild"] * B / 1e9, ms_per_half_step=kms["kbuild"],
+                                     algorithmic_gb_per_half_step=hb["kbuild"] * kshare * B / 1e9, ms_per_half_step=kms["kbuild"],
+                                     block_column_0_only=bool(generated),
                                      valu={"algorithmic_tflops": fk / (kms["kbuild"] * 1e-3) / 1e12, "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
                                            "frac": fk / (kms["kbuild"] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                            "note": "(3d+14) flop per pair (SURVEY 8d) against the fp64 vector peak; the kernel executes 78 "

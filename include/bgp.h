@@ -247,7 +247,9 @@ int bgp_predict_batch_gram(bgp_ctx* ctx, int B, int m, const double* Ks, const d
  *   BGP_STREAMS (this call), BGP_PANELS (block columns per trailing update, 1..64; default 4 from n = 1536, else 2), BGP_PERSIST
  *   (bgp_set_persist), BGP_PS_PAIR (0 / 1: one or two chain workgroups per matrix on the launch-free path; default by shape),
  *   BGP_PS_GEN (0 / 1: the Gram blocks of a launch-free LML batch are built by a kernel in front of it / by its own tile workers
- *   at the head of their ticket list; default by shape).
+ *   at the head of their ticket list; default by shape), BGP_SYRK_GEN (0 / 1: on the launch schedule, every Gram block by the
+ *   kernel in front / all but block column 0 in the accumulators of the first panel group's updates; default 1 where the
+ *   pipelined Gram kernel would run, see bgp_lml_gen_stats).
  * Runtime switch set by the PYTHON package, not read by this library: bayes-skopt_amd/_lib.py exports HIP_FORCE_DEV_KERNARG=1 (kernel
  *   arguments in device memory: -6 % per call on the launch schedule at n = 1024 x 32) at import unless the user has set it --
  *   a process-wide setting that every other HIP user of the process inherits, effective only if the GPU has not been initialised
@@ -283,6 +285,12 @@ int bgp_set_persist(bgp_ctx* ctx, int mode);
  * (BGP_PS_COOLDOWN, 256; after the third time-out the path stays off until bgp_set_persist(ctx, 1)).  A context that shares
  * its device with other contexts, processes or collectives should call bgp_set_persist(ctx, 0). */
 int bgp_persist_stats(bgp_ctx* ctx, long long* out4);
+/* Gram generation inside the trailing update (launch schedule of the LML path; csrc/bgp_s4.h S4GenF): the kernel matrix K(X, X) of
+ * sklearn/_gpr.py:582-585 is built by the Gram kernel for block column 0 only; every other block is computed in the accumulators
+ * of the update of the first panel group that touches it first (same arithmetic per element: same bits; BGP_SYRK_GEN=0 builds every
+ * block with the Gram kernel in front).  out[0] = LML batches (per walker-group stream) factorised that way by this context,
+ * out[1] = generating launches among their trailing updates. */
+int bgp_lml_gen_stats(bgp_ctx* ctx, long long* out2);
 /* Enable (1) / disable (0) per-kernel event timing (adds synchronisation; off by default). */
 int bgp_set_timing(bgp_ctx* ctx, int enable);
 /* Debugging aid (BGP_PS_TRACE=1): in-kernel wall-clock stamps (100 MHz) of the last launch-free call.  dims = {matrices,

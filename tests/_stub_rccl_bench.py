@@ -153,6 +153,9 @@ class StubContext:
         t["device_total_ms"] = 4.0
         return t
 
+    def gen_stats(self):
+        return {"batches": 0, "launches": 0}
+
     def persist_stats(self):
         return {"calls": 0, "timeouts": 0, "disabled": False, "cooldown_left": 0}
 

@@ -379,3 +379,35 @@ def test_a_failing_call_on_one_thread_leaves_another_threads_downloads_alone(lib
     ta.join()
     assert not errs, errs
     assert counts["ok"] == 150 and counts["notpd"] > 0, counts
+
+
+@pytest.mark.parametrize("n,d,B,stationary,form,warp", [
+    (2048, 16, 128, "matern52", "product", False),  # BASELINE config C's batch: four-panel groups, two walker-group streams
+    (1000, 8, 64, "matern52", "product", False),    # 8 block columns (two-panel groups), ragged last block
+    (1290, 16, 24, "matern32", "sum", False),       # all 16 staged dimensions real; 11 block columns, 10 ragged rows
+    (1290, 32, 24, "matern32", "sum", False),       # more than 16 input dimensions: not generated (nothing to differ)
+    (700, 3, 104, "rbf", "product", False),         # 3 of 16 staged dimensions are real
+    (515, 5, 136, "matern12", "sum", False),        # three rows in the last block column, batch beyond one chunk (max_batch 72)
+    (900, 4, 72, "matern52", "product", True),      # per-walker warped inputs
+])
+def test_gram_blocks_generated_inside_the_trailing_update_are_the_gram_kernels(lib, O, monkeypatch, n, d, B, stationary, form,
+                                                                               warp):
+    """The first panel group's updates generate the kernel-matrix blocks they touch first in their accumulators (S4GenF,
+    csrc/bgp_s4.h) and the Gram kernel builds block column 0 only; BGP_SYRK_GEN=0 builds every block with the Gram kernel as
+    before.  Same arithmetic per element: the log-likelihoods of the two schedules are bit-identical, and they are the oracle's."""
+    X, y = synth(n, d, 7 + n)
+    rs = np.random.RandomState(n + B)
+    H = np.concatenate([[0.2], np.full(d, np.log(0.5)), [np.log(0.03)]]) + 0.2 * rs.randn(B, d + 2)
+    H[1, -1] = -np.inf  # (noise level 0: the White term drops out of the diagonal)
+    W = 0.3 * rs.randn(B, 2 * d) if warp else None
+    ctx = lib.Context(X, y, 1e-10, form=form, stationary=stationary, max_batch=min(B, 72))
+    ctx.set_persist(0)  # the launch schedule (the launch-free kernel has its own generation)
+    monkeypatch.setenv("BGP_SYRK_GEN", "0")
+    ref = ctx.lml_warped(H, W) if warp else ctx.lml(H)
+    monkeypatch.setenv("BGP_SYRK_GEN", "1")
+    got = ctx.lml_warped(H, W) if warp else ctx.lml(H)
+    ctx.close()
+    assert np.array_equal(got, ref), float(np.max(np.abs(got - ref)))
+    if not warp and n <= 1300:
+        rows = [0, 2, 3, 4, 5]  # (row 1 has no noise: conditioned by the 1e-10 jitter alone, it is no fixed point for a tolerance)
+        np.testing.assert_allclose(got[rows], O.lml_batch(X, y, np.full(n, 1e-10), H[rows], stationary, form), rtol=RTOL)
