@@ -544,3 +544,19 @@ def test_gradient_x_of_kernel_trees_against_central_differences(bask):
     with pytest.raises(NotImplementedError):
         from sklearn.gaussian_process.kernels import PairwiseKernel
         gradient_x(PairwiseKernel(), x, X)
+
+
+def test_bench_counts_the_generated_gram_flops_once():
+    """bench.py's split of the Gram flops the trailing update's generating launches carry (look-ahead columns of the first panel
+    group, its bulk update): together with block column 0 they are the (3 d + 14) n^2 / 2 of ``lml_flops`` -- nothing counted twice."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n, d in ((2048, 16), (1024, 8), (4096, 3), (256, 2)):
+        col, bulk = bench.gram_generated_flops(n, d)
+        col0 = (128 * n - 128 * 128 / 2.0) * (3 * d + 14)
+        assert col >= 0 and bulk >= 0
+        assert col + bulk + col0 == pytest.approx(n * n / 2.0 * (3 * d + 14))
+    assert bench.gram_generated_flops(2048, 16)[0] / (3 * 16 + 14) == 128 * (1920 + 1792 + 1664) - 3 * 8192

@@ -384,10 +384,10 @@ def test_a_failing_call_on_one_thread_leaves_another_threads_downloads_alone(lib
 @pytest.mark.parametrize("n,d,B,stationary,form,warp", [
     (2048, 16, 128, "matern52", "product", False),  # BASELINE config C's batch: four-panel groups, two walker-group streams
     (1000, 8, 64, "matern52", "product", False),    # 8 block columns (two-panel groups), ragged last block
-    (1290, 16, 24, "matern32", "sum", False),       # all 16 staged dimensions real; 11 block columns, 10 ragged rows
+    (1290, 16, 32, "matern32", "sum", False),       # all 16 staged dimensions real; 11 block columns, 10 ragged rows
     (1290, 32, 24, "matern32", "sum", False),       # more than 16 input dimensions: not generated (nothing to differ)
     (700, 3, 104, "rbf", "product", False),         # 3 of 16 staged dimensions are real
-    (515, 5, 136, "matern12", "sum", False),        # three rows in the last block column, batch beyond one chunk (max_batch 72)
+    (515, 5, 288, "matern12", "sum", False),        # three rows in the last block column; two chunks of max_batch = 144
     (900, 4, 72, "matern52", "product", True),      # per-walker warped inputs
 ])
 def test_gram_blocks_generated_inside_the_trailing_update_are_the_gram_kernels(lib, O, monkeypatch, n, d, B, stationary, form,
@@ -400,14 +400,27 @@ def test_gram_blocks_generated_inside_the_trailing_update_are_the_gram_kernels(l
     H = np.concatenate([[0.2], np.full(d, np.log(0.5)), [np.log(0.03)]]) + 0.2 * rs.randn(B, d + 2)
     H[1, -1] = -np.inf  # (noise level 0: the White term drops out of the diagonal)
     W = 0.3 * rs.randn(B, 2 * d) if warp else None
-    ctx = lib.Context(X, y, 1e-10, form=form, stationary=stationary, max_batch=min(B, 72))
+    ctx = lib.Context(X, y, 1e-10, form=form, stationary=stationary, max_batch=min(B, 144))
     ctx.set_persist(0)  # the launch schedule (the launch-free kernel has its own generation)
+    if n != 2048:
+        ctx.set_streams(1)  # (config C's batch keeps the automatic two walker-group streams: 64 matrices each; the smaller batches
+        # would fall below the rule's size per group)
     monkeypatch.setenv("BGP_SYRK_GEN", "0")
     ref = ctx.lml_warped(H, W) if warp else ctx.lml(H)
+    assert ctx.gen_stats() == {"batches": 0, "launches": 0}
     monkeypatch.setenv("BGP_SYRK_GEN", "1")
     got = ctx.lml_warped(H, W) if warp else ctx.lml(H)
+    stats = ctx.gen_stats()
     ctx.close()
     assert np.array_equal(got, ref), float(np.max(np.abs(got - ref)))
+    if d <= 16:
+        # every chunk / walker group of the call went that way: the look-ahead columns of the first panel group (P - 1 of them,
+        # P = 4 from 12 block columns, else 2) and its bulk update generate
+        nblk = -(-n // 128)
+        per_batch = min(4 if nblk >= 12 else 2, nblk)
+        assert stats["batches"] >= 1 and stats["launches"] == per_batch * stats["batches"], stats
+    else:
+        assert stats == {"batches": 0, "launches": 0}
     if not warp and n <= 1300:
         rows = [0, 2, 3, 4, 5]  # (row 1 has no noise: conditioned by the 1e-10 jitter alone, it is no fixed point for a tolerance)
         np.testing.assert_allclose(got[rows], O.lml_batch(X, y, np.full(n, 1e-10), H[rows], stationary, form), rtol=RTOL)
