@@ -38,7 +38,10 @@ import scipy.stats as st  # noqa: E402
 
 # (n, d, walkers, steps, warped walkers)
 SHAPES = [(128, 2, 100, 25, False), (1024, 8, 64, 8, False), (975, 8, 100, 6, False), (300, 3, 40, 10, False), (2048, 16, 40, 4, False),
-          (640, 4, 48, 8, False), (1536, 8, 32, 5, False), (300, 3, 40, 8, True), (100, 2, 24, 12, True), (200, 40, 256, 2, False)]
+          (640, 4, 48, 8, False), (1536, 8, 32, 5, False), (300, 3, 40, 8, True), (100, 2, 24, 12, True), (200, 40, 256, 2, False),
+          # the launch schedule with the Gram blocks generated inside the trailing update (resident run) against the Gram kernel in
+          # front (host-driven twin, BGP_SYRK_GEN=0): BASELINE config C's ensemble, and a two-panel-group shape
+          (2048, 16, 256, 2, False), (1100, 8, 256, 3, False)]
 gps = []
 for n, d, W, steps, warp in SHAPES:
     rng = np.random.RandomState(n)
@@ -64,6 +67,7 @@ while time.time() < t_end:
         wp = (st.norm(loc=0.0, scale=0.3).logpdf, st.norm(loc=0.0, scale=0.3).logpdf)
         out = []
         for resident in (False, True):
+            os.environ["BGP_SYRK_GEN"] = "1" if resident else "0"
             gp.resident_sampler = resident
             smp = bask.sampler.EnsembleSampler(W, p, _AsyncLogProb(gp), kwargs=dict(priors=priors, warp_priors=wp))
             smp.random_state = np.random.RandomState(seed + 1).get_state()
@@ -80,9 +84,11 @@ while time.time() < t_end:
         runs += 1
         halfsteps += 2 * steps
     rounds += 1
+os.environ.pop("BGP_SYRK_GEN", None)
+generated = sum(gp._ctx.gen_stats()["batches"] for gp, _ in gps)
 stats = [gp._ctx.persist_stats() for gp, _ in gps]
 timeouts = sum(s["timeouts"] for s in stats)
 print("resident soak: %d rounds, %d resident runs (%d half-steps) against their host-driven twins: positions and accept counts identical, "
-      "log-probabilities within %.2e relative; launch-free calls %d, time-outs %d" % (
-          rounds, runs, halfsteps, worst, sum(s["calls"] for s in stats), timeouts))
+      "log-probabilities within %.2e relative; launch-free calls %d, time-outs %d; LML batches with their Gram blocks generated inside the "
+      "trailing update %d" % (rounds, runs, halfsteps, worst, sum(s["calls"] for s in stats), timeouts, generated))
 assert timeouts == 0
