@@ -51,6 +51,12 @@ def test_bench_single_gpu_line():
     # HBM bytes per launch: collected by two rocprofv3 --pmc child passes of this very run when the profiler is there
     # (else the committed passes); the algorithmic C round trip alone is 0.45 GB per launch
     assert r["traffic_source"].startswith(("live", "profiles/")) and 0.45e9 < r["traffic"] < 2.0e9
+    # the first panel group's launches compute the Gram blocks they touch first (config C: d = 16): `achieved` counts those flops
+    # with the launches that carry them, `achieved_update_only` leaves them out; the Gram kernel builds block column 0 only
+    assert r["gram_generated_in_kernel"] is True and abs(r["gram_generated_gflop_per_factorisation"] - 0.1142784) < 1e-9
+    assert 0.93 < r["achieved_update_only"] / r["achieved"] < 0.97 and abs(r["frac_update_only"] - r["achieved_update_only"] / r["peak"]) < 1e-12
+    assert d["kernel_ms_per_half_step"]["kbuild"] < 0.3
+    assert d["roofline_n4096"]["gram_generated_gflop_per_factorisation"] == 0.0  # (d = 32: not generated)
     bk = r["by_launch_kind"]  # the same kernel's bulk launches against its look-ahead column launches
     assert 0.5 < bk["look_ahead_columns"]["frac_of_peak"] < bk["bulk"]["frac_of_peak"] < 1.0
     assert abs(bk["bulk"]["ms_per_half_step"] + bk["look_ahead_columns"]["ms_per_half_step"] - d["kernel_ms_per_half_step"]["syrk"]) < 1e-6
